@@ -1,0 +1,172 @@
+/*
+ * probreg_hip.h - C ABI of libprobreg_hip.so, the MI355X (gfx950) engine behind
+ * probreg's CPD / FilterReg EM hot path.
+ *
+ * Every entry point names the reference interface it replaces (paths relative
+ * to the neka-nat/probreg tree, v0.3.7).  Conventions:
+ *   - all functions return 0 on success, a negative prg_status on failure;
+ *     prg_last_error() returns a thread-local message for the last failure;
+ *   - "hd" pointers may be host OR device pointers (copied with
+ *     hipMemcpyDefault); "dev" pointers must be device pointers;
+ *   - point clouds are row-major (count x D) float32, D = 2 or 3;
+ *   - one handle = one device = one HIP stream; calls on a handle are
+ *     asynchronous on that stream unless the name ends in a host read-back
+ *     (get_*, *_host) which synchronises the stream;
+ *   - no torch / numpy types appear anywhere in this file.
+ */
+#ifndef PROBREG_HIP_H
+#define PROBREG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum prg_status {
+    PRG_OK = 0,
+    PRG_ERR_INVALID = -1,   /* bad argument (ValueError / AssertionError in the reference) */
+    PRG_ERR_HIP = -2,       /* HIP runtime error; message holds hipGetErrorString */
+    PRG_ERR_STATE = -3,     /* call order violated (e.g. estep before set_target) */
+    PRG_ERR_NOMEM = -4
+} prg_status;
+
+typedef enum prg_tf_kind {
+    PRG_TF_RIGID = 0,       /* probreg.cpd.RigidCPD    (cpd.py:123-192) */
+    PRG_TF_AFFINE = 1,      /* probreg.cpd.AffineCPD   (cpd.py:195-244) */
+    PRG_TF_NONRIGID = 2     /* probreg.cpd.NonRigidCPD (cpd.py:247-303) */
+} prg_tf_kind;
+
+const char* prg_last_error(void);
+int prg_version(void);
+int prg_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout of the two small fp64 device blocks every CPD plan owns.
+ *
+ * MOMENTS (PRG_NMOMENTS doubles) - the per-iteration all-reduce payload:
+ *   [0]      S0   = sum_m p1_m                        (n_p,            cpd.py:88)
+ *   [1..3]   Sx   = sum_m px_m                        (xp.sum(px,0),   cpd.py:169)
+ *   [4..6]   Sy   = sum_m p1_m y_m                    (source.T @ p1,  cpd.py:170)
+ *   [7..15]  Sxy  = sum_m px_m y_m^T   row-major 3x3  (px.T @ source,  cpd.py:173)
+ *   [16..21] Syy  = sum_m p1_m y_m y_m^T  (xx,xy,xz,yy,yz,zz)          (cpd.py:179/234)
+ *   [22]     Sxx  = sum_n pt1_n |x_n|^2               (cpd.py:183/237)
+ *   [23]     reserved
+ *   [24..26] sum_n x_n   [27] sum_n |x_n|^2   (target sums for the sigma2 initialiser,
+ *                                              math_utils.py:28-29; local shard, all-reduced)
+ *   [28..31] reserved (zero)
+ * PARAMS (PRG_NPARAMS doubles):
+ *   [0..8]   linear part, row-major 3x3: rot (rigid) or b (affine)   transformation.py:43-78
+ *   [9..11]  t
+ *   [12]     scale (1 for affine)
+ *   [13]     sigma2        [14] q        [15] n_p of the last E-step
+ *   [16]     iteration counter (as double)
+ *   [17..31] reserved
+ * ---------------------------------------------------------------------------------------- */
+#define PRG_NMOMENTS 32
+#define PRG_NPARAMS 32
+
+typedef struct prg_cpd prg_cpd;
+
+/* Plan life cycle.  `hip_stream` is a hipStream_t (NULL = the device's null stream).
+ * Replaces: CoherentPointDrift.__init__ backend selection, cpd.py:42-59. */
+int prg_cpd_create(prg_cpd** out, int device, void* hip_stream);
+int prg_cpd_destroy(prg_cpd* h);
+
+/* Upload the (already centred) source cloud, replicated on every device.
+ * Replaces: CoherentPointDrift.set_source, cpd.py:61-62. */
+int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim);
+
+/* Upload this device's contiguous shard of the target cloud; n_global is the number of
+ * target points over all shards (it enters `c`, cpd.py:78-79, and q0, cpd.py:148).
+ * Replaces: the `target` argument of CoherentPointDrift.registration, cpd.py:106. */
+int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int dim, int64_t n_global);
+
+/* Optional: make the plan accumulate its moments into caller-owned device memory
+ * (PRG_NMOMENTS doubles) so the caller can all-reduce them in place (RCCL). */
+int prg_cpd_bind_moments(prg_cpd* h, double* moments_dev);
+/* Device addresses of the blocks (for in-place collectives / zero-copy views). */
+int prg_cpd_moments_ptr(prg_cpd* h, double** moments_dev);
+int prg_cpd_params_ptr(prg_cpd* h, double** params_dev);
+
+/* sigma2 initialiser, step 1: local target sums -> MOMENTS[24..27] (others zeroed).
+ * Replaces: mu.squared_kernel_sum, math_utils.py:28-29 -> cc/math_utils.cc:5-15
+ * (closed form, never materialises M x N). All-reduce MOMENTS between step 1 and 2. */
+int prg_cpd_init_sums(prg_cpd* h);
+/* step 2: sigma2_0 and q0 = 1 + N*D/2*log(sigma2_0) into PARAMS, linear part and t from
+ * `init_params_host` (12 doubles + scale, NULL = identity / zero / 1).
+ * Replaces: RigidCPD._initialize cpd.py:145-153, AffineCPD._initialize :209-217,
+ * NonRigidCPD._initialize :277-282. */
+int prg_cpd_init_params(prg_cpd* h, const double* init_params_host);
+
+/* One E-step on the local shard with the transformation currently in PARAMS:
+ * transform (transformation.py:49-50 / 77-78 / 101-102), column pass (den, cpd.py:74-82),
+ * row pass (P1, PX in residual form, cpd.py:84-87) and the fp64 moment reduction.
+ * Result: MOMENTS[0..22] (local partial sums).  `w` is the uniform-noise weight.
+ * Replaces: CoherentPointDrift.expectation_step, cpd.py:71-88. */
+int prg_cpd_estep(prg_cpd* h, double w);
+
+/* M-step from (all-reduced) MOMENTS into PARAMS; identical on every rank.
+ * Replaces: RigidCPD._maximization_step cpd.py:160-192 (update_scale as there) and
+ * AffineCPD._maximization_step cpd.py:219-244. */
+int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale);
+
+/* Host read-back / overwrite of PARAMS (synchronises the stream). */
+int prg_cpd_get_params(prg_cpd* h, double* params_host);
+int prg_cpd_set_params(prg_cpd* h, const double* params_host);
+int prg_cpd_get_moments(prg_cpd* h, double* moments_host);
+
+/* Materialise the EstepResult of the last prg_cpd_estep in the reference's terms
+ * (cpd.py:17, :84-88): pt1[n_local], p1[m], px[m*dim] as float64; any pointer may be NULL.
+ * p1 / px are this shard's partial sums over its local target points. */
+int prg_cpd_get_estep(prg_cpd* h, double* pt1_hd, double* p1_hd, double* px_hd);
+/* Transformed source (m x dim, float32) used by the last E-step. */
+int prg_cpd_get_tsource(prg_cpd* h, float* tsource_hd);
+
+/* M-step from explicitly supplied EstepResult arrays (the reference's public
+ * maximization_step(target, estep_res) signature, cpd.py:90-93): uploads pt1/p1/px
+ * (float64, host or device), rebuilds MOMENTS[0..22] on the device, no M-step yet. */
+int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p1_hd, const double* px_hd);
+
+/* Tuning knobs (0 keeps the current / automatic value): points per lane (2 or 4) and the
+ * number of segments the reduction axis is split into, for the column and row pass. */
+int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_row);
+
+/* ---- non-rigid CPD ------------------------------------------------------------------- */
+/* Build G_ij = exp(-|y_i-y_j|^2/(2*beta)) (float32, M x M) once per source.
+ * Replaces: NonRigidTransformation.__init__ transformation.py:91-99 -> mu.rbf_kernel
+ * math_utils.py:36-37 -> cc/math_utils.cc:17-19. */
+int prg_cpd_nonrigid_build_g(prg_cpd* h, double beta);
+/* Copy G (m*m float32, row-major) out - parity tests / `tf.g` attribute. */
+int prg_cpd_nonrigid_get_g(prg_cpd* h, float* g_hd);
+/* Set / get W (m x dim float64).  W = 0 after build_g (cpd.py:281). */
+int prg_cpd_nonrigid_set_w(prg_cpd* h, const double* w_hd);
+int prg_cpd_nonrigid_get_w(prg_cpd* h, double* w_hd);
+/* Device address of the per-point E-step block (4*m doubles: p1[m], px0[m], px1[m], px2[m])
+ * followed by MOMENTS-style scalars; this is the non-rigid all-reduce payload. */
+int prg_cpd_rowacc_ptr(prg_cpd* h, double** rowacc_dev, int64_t* count);
+/* Non-rigid M-step: W = solve(diag(p1) G + lmd*sigma2_prev*I, px - diag(p1) Y), T = Y + G W,
+ * sigma2 = (tr(X^T diag(pt1) X) - 2 tr(px^T T) + tr(T^T diag(p1) T)) / (n_p D), q := sigma2.
+ * Replaces: NonRigidCPD._maximization_step, cpd.py:284-303. */
+int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd);
+
+/* ---- direct Gauss transform ------------------------------------------------------------ */
+/* out[c*t + i] = sum_j weights[c*s + j] * exp(-|target_i - source_j|^2 / h^2), float64 out.
+ * Replaces: gauss_transform._gauss_transform_direct / Direct.compute / GaussTransform.compute
+ * (gauss_transform.py:10-25, 46-60). */
+int prg_gauss_transform_direct(int device, void* hip_stream, const float* source_hd, int64_t s,
+                               const float* target_hd, int64_t t, int dim, const double* weights_hd,
+                               int n_weight_rows, double h, double* out_hd);
+
+/* sum_{m,n} |x_m - y_n|^2 / (M*D*N), closed form in fp64 on the device.
+ * Replaces: mu.squared_kernel_sum, math_utils.py:28-29. */
+int prg_squared_kernel_sum(int device, void* hip_stream, const float* x_hd, int64_t m,
+                           const float* y_hd, int64_t n, int dim, double* out_host);
+/* Dense K = exp(-|x_i-y_j|^2/(2*beta)) float32 (rows = x). Replaces mu.rbf_kernel, math_utils.py:36-37. */
+int prg_rbf_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd,
+                   int64_t n, int dim, double beta, float* out_hd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROBREG_HIP_H */

@@ -1,0 +1,409 @@
+"""Coherent Point Drift on MI355X - drop-in for ``probreg.cpd`` (reference probreg/cpd.py).
+
+Same public surface as the reference: ``EstepResult`` / ``MstepResult`` (cpd.py:17-18),
+``CoherentPointDrift`` with ``set_source`` / ``set_callbacks`` / ``expectation_step`` /
+``maximization_step`` / ``registration`` (cpd.py:29-120), ``RigidCPD`` (:123-192), ``AffineCPD``
+(:195-244), ``NonRigidCPD`` (:247-303) and ``registration_cpd`` (:407-456).
+
+What is different underneath: the E-step (M x N responsibilities, P1, Pt1, PX), the sigma2
+initialiser, the transform of the source and the M-step all run in ``libprobreg_hip.so`` on the
+GPU; the M x N matrix is never materialised.  ``use_cuda`` is accepted and ignored (the engine is
+always the HIP one; there is no NumPy path).  Under ``torchrun`` (torch.distributed initialised)
+the target cloud is sharded over the ranks and one all-reduce per iteration combines the moments.
+"""
+import abc
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from . import dist as pdist
+from . import transformation as tf
+from .engine import CpdPlan
+from .log import log
+
+EstepResult = namedtuple("EstepResult", ["pt1", "p1", "px", "n_p"])
+MstepResult = namedtuple("MstepResult", ["transformation", "sigma2", "q"])
+MstepResult.__doc__ = """Result of Maximization step.
+
+    Attributes:
+        transformation (tf.Transformation): Transformation from source to target.
+        sigma2 (float): Variance of Gaussian distribution.
+        q (float): Result of likelihood.
+"""
+
+
+def _as_points(x):
+    """ndarray or Open3D PointCloud (duck-typed ``.points``) -> float64 ndarray (cpd.py:444)."""
+    if hasattr(x, "points") and not isinstance(x, np.ndarray):
+        x = x.points
+    return np.asarray(x, dtype=np.float64)
+
+
+def _params_block(linear, t, scale, dim):
+    p = np.zeros(13)
+    lin = np.identity(3)
+    lin[:dim, :dim] = np.asarray(linear, dtype=np.float64)
+    p[:9] = lin.ravel()
+    p[9:9 + dim] = np.asarray(t, dtype=np.float64)
+    p[12] = scale
+    return p
+
+
+class CoherentPointDrift(abc.ABC):
+    """Coherent Point Drift algorithm (abstract; reference cpd.py:29-120).
+
+    Args:
+        source (numpy.ndarray, optional): Source point cloud data.
+        use_cuda (bool, optional): accepted for compatibility, ignored.
+        device (int, optional): GPU index (default: the process's current torch device).
+    """
+
+    _kind = None
+
+    def __init__(self, source=None, use_cuda=False, device=None):
+        self._source = None if source is None else _as_points(source)
+        self._tf_type = None
+        self._callbacks = []
+        self._device = device
+        self._plan = None
+        self.xp = np
+
+    # -- reference API ------------------------------------------------------------------------
+    def set_source(self, source):
+        self._source = _as_points(source)
+
+    def set_callbacks(self, callbacks):
+        self._callbacks.extend(callbacks)
+
+    def expectation_step(self, t_source, target, sigma2, w=0.0):
+        """Expectation step for CPD (reference cpd.py:71-88) on explicit arrays.
+
+        Runs the two GPU pair sweeps on ``t_source`` as given (identity transform) and returns the
+        reference's ``EstepResult(pt1, p1, px, n_p)`` as float64 arrays.
+        """
+        t_source = np.asarray(t_source)
+        target = np.asarray(target)
+        assert t_source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
+        # centre in fp64 before the fp32 upload (pairwise differences are translation invariant)
+        c = target.mean(axis=0)
+        plan = CpdPlan(self._device)
+        try:
+            plan.set_source(t_source - c)
+            plan.set_target(target - c)
+            p = np.zeros(_lib.PRG_NPARAMS)
+            p[:13] = _params_block(np.identity(t_source.shape[1]), np.zeros(t_source.shape[1]), 1.0,
+                                   t_source.shape[1])
+            p[13] = sigma2
+            plan.set_params(p)
+            plan.estep(w)
+            pt1, p1, px = plan.get_estep()
+        finally:
+            plan.close()
+        px = px + np.outer(p1, c)  # undo the centring: sum_n P x_n = sum_n P (x_n - c) + p1 c
+        return EstepResult(pt1, p1, px, float(np.sum(p1)))
+
+    def maximization_step(self, target, estep_res, sigma2_p=None):
+        return self._maximization_step(self._source, target, estep_res, sigma2_p)
+
+    @abc.abstractmethod
+    def _maximization_step(self, source, target, estep_res, sigma2_p=None):
+        return None
+
+    # -- plan handling ------------------------------------------------------------------------
+    def _centres(self, source, target_full):
+        """fp64 centres subtracted before the fp32 upload (input conditioning)."""
+        return source.mean(axis=0), target_full.mean(axis=0)
+
+    def _setup_plan(self, target):
+        """Upload clouds (target sharded over ranks), run the sigma2 initialiser. Returns the plan."""
+        source = self._source
+        target = _as_points(target)
+        assert source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
+        if source.shape[1] != target.shape[1] or source.shape[1] not in (2, 3):
+            raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
+        rank, world = pdist.world()
+        cy, cx = self._centres(source, target)
+        lo, hi = pdist.shard_bounds(target.shape[0], rank, world)
+        plan = self._plan if self._plan is not None else CpdPlan(self._device)
+        self._plan = plan
+        self._cy, self._cx = cy, cx
+        if not getattr(self, "_source_uploaded", False):
+            plan.set_source(source - cy)
+        plan.set_target(target[lo:hi] - cx, n_global=target.shape[0])
+        mom = plan.moments_tensor() if world > 1 else None
+        plan.init_sums()
+        if mom is not None:
+            pdist.all_reduce_sum_(mom)
+        return plan
+
+    def _all_reduce_moments(self, plan):
+        if plan._moments_tensor is not None:
+            pdist.all_reduce_sum_(plan._moments_tensor)
+
+    @abc.abstractmethod
+    def _initialize(self, target):
+        return MstepResult(None, None, None)
+
+    @abc.abstractmethod
+    def _device_mstep(self, plan):
+        pass
+
+    @abc.abstractmethod
+    def _result_from_params(self, params):
+        pass
+
+    def registration(self, target, w=0.0, maxiter=50, tol=0.001):
+        """EM driver (reference cpd.py:106-120); the loop body runs on the GPU.
+
+        The host reads the 32-double parameter block back only when it has to: every iteration if
+        there are callbacks, DEBUG logging or a non-negative ``tol`` (the convergence test needs
+        ``q``), otherwise once at the end.
+        """
+        assert self._tf_type is not None, "transformation type is None."
+        res = self._initialize(target)
+        plan = self._plan
+        q = res.q
+        need_host = bool(self._callbacks) or tol >= 0 or log.isEnabledFor(10)
+        for i in range(maxiter):
+            plan.estep(w)
+            self._all_reduce_moments(plan)
+            self._device_mstep(plan)
+            if need_host:
+                res = self._result_from_params(plan.get_params())
+                for c in self._callbacks:
+                    c(res.transformation)
+                log.debug("Iteration: {}, Criteria: {}".format(i, res.q))
+                if abs(res.q - q) < tol:
+                    break
+                q = res.q
+        if not need_host and maxiter > 0:
+            res = self._result_from_params(plan.get_params())
+        return res
+
+
+class RigidCPD(CoherentPointDrift):
+    """Coherent Point Drift for rigid transformation (reference cpd.py:123-192).
+
+    Args:
+        source (numpy.ndarray, optional): Source point cloud data.
+        update_scale (bool, optional): If this flag is True, compute the scale parameter.
+        tf_init_params (dict, optional): Parameters to initialize transformation.
+        use_cuda (bool, optional): accepted for compatibility, ignored.
+    """
+
+    _kind = _lib.PRG_TF_RIGID
+
+    def __init__(self, source=None, update_scale=True, tf_init_params={}, use_cuda=False, device=None):
+        super(RigidCPD, self).__init__(source, use_cuda, device)
+        self._tf_type = tf.RigidTransformation
+        self._update_scale = update_scale
+        self._tf_init_params = tf_init_params
+
+    def _initialize(self, target):
+        dim = self._source.shape[1]
+        plan = self._setup_plan(target)
+        ip = dict(self._tf_init_params)
+        ip.pop("xp", None)
+        rot = np.asarray(ip.get("rot", np.identity(dim)), dtype=np.float64)
+        t = np.asarray(ip.get("t", np.zeros(dim)), dtype=np.float64)
+        scale = float(ip.get("scale", 1.0))
+        # centred frame: z - cx = s R (y - cy) + t'  with  t' = t + s R cy - cx
+        t_c = t + scale * rot @ self._cy - self._cx
+        plan.init_params(_params_block(rot, t_c, scale, dim))
+        return self._result_from_params(plan.get_params())
+
+    def _device_mstep(self, plan):
+        plan.mstep(_lib.PRG_TF_RIGID, self._update_scale)
+
+    def _result_from_params(self, params):
+        dim = self._source.shape[1]
+        rot = params[:9].reshape(3, 3)[:dim, :dim].copy()
+        scale = float(params[12])
+        t = params[9:9 + dim] + self._cx - scale * rot @ self._cy
+        return MstepResult(tf.RigidTransformation(rot, t, scale), float(params[13]), float(params[14]))
+
+    def maximization_step(self, target, estep_res, sigma2_p=None):
+        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._update_scale)
+
+    def _maximization_step(self, source, target, estep_res, sigma2_p=None, update_scale=True):
+        """Rigid M-step from explicit EstepResult arrays (reference cpd.py:160-192), on the GPU."""
+        return _mstep_from_arrays(self, source, target, estep_res, _lib.PRG_TF_RIGID, update_scale)
+
+
+class AffineCPD(CoherentPointDrift):
+    """Coherent Point Drift for affine transformation (reference cpd.py:195-244)."""
+
+    _kind = _lib.PRG_TF_AFFINE
+
+    def __init__(self, source=None, tf_init_params={}, use_cuda=False, device=None):
+        super(AffineCPD, self).__init__(source, use_cuda, device)
+        self._tf_type = tf.AffineTransformation
+        self._tf_init_params = tf_init_params
+
+    def _initialize(self, target):
+        dim = self._source.shape[1]
+        plan = self._setup_plan(target)
+        ip = dict(self._tf_init_params)
+        ip.pop("xp", None)
+        b = np.asarray(ip.get("b", np.identity(dim)), dtype=np.float64)
+        t = np.asarray(ip.get("t", np.zeros(dim)), dtype=np.float64)
+        t_c = t + b @ self._cy - self._cx
+        plan.init_params(_params_block(b, t_c, 1.0, dim))
+        return self._result_from_params(plan.get_params())
+
+    def _device_mstep(self, plan):
+        plan.mstep(_lib.PRG_TF_AFFINE, True)
+
+    def _result_from_params(self, params):
+        dim = self._source.shape[1]
+        b = params[:9].reshape(3, 3)[:dim, :dim].copy()
+        t = params[9:9 + dim] + self._cx - b @ self._cy
+        return MstepResult(tf.AffineTransformation(b, t), float(params[13]), float(params[14]))
+
+    def _maximization_step(self, source, target, estep_res, sigma2_p=None):
+        """Affine M-step from explicit EstepResult arrays (reference cpd.py:219-244), on the GPU."""
+        return _mstep_from_arrays(self, source, target, estep_res, _lib.PRG_TF_AFFINE, True)
+
+
+def _mstep_from_arrays(obj, source, target, estep_res, kind, update_scale):
+    source = _as_points(source)
+    target = _as_points(target)
+    pt1, p1, px, n_p = estep_res
+    cy, cx = source.mean(axis=0), target.mean(axis=0)
+    plan = CpdPlan(obj._device)
+    try:
+        plan.set_source(source - cy)
+        plan.set_target(target - cx)
+        # moments in the centred frame: px' = px - p1 cx
+        plan.moments_from_estep(pt1, p1, np.asarray(px) - np.outer(p1, cx))
+        p = np.zeros(_lib.PRG_NPARAMS)
+        p[0] = p[4] = p[8] = p[12] = 1.0
+        p[13] = 1.0
+        plan.set_params(p)
+        plan.mstep(kind, update_scale)
+        params = plan.get_params()
+    finally:
+        plan.close()
+    obj_cy, obj_cx = getattr(obj, "_cy", None), getattr(obj, "_cx", None)
+    obj._cy, obj._cx = cy, cx
+    try:
+        return obj._result_from_params(params)
+    finally:
+        obj._cy, obj._cx = obj_cy, obj_cx
+
+
+class NonRigidCPD(CoherentPointDrift):
+    """Coherent Point Drift for nonrigid transformation (reference cpd.py:247-303).
+
+    Args:
+        source (numpy.ndarray, optional): Source point cloud data.
+        beta (float, optional): Parameter of RBF kernel.
+        lmd (float, optional): Parameter for regularization term.
+        use_cuda (bool, optional): accepted for compatibility, ignored.
+    """
+
+    _kind = _lib.PRG_TF_NONRIGID
+
+    def __init__(self, source=None, beta=2.0, lmd=2.0, use_cuda=False, device=None):
+        super(NonRigidCPD, self).__init__(source, use_cuda, device)
+        self._tf_type = tf.NonRigidTransformation
+        self._beta = beta
+        self._lmd = lmd
+        self._tf_obj = None
+        if self._source is not None:
+            self._build()
+
+    def _centres(self, source, target_full):
+        # G is built from the float32 source exactly as the reference's pybind cast sees it
+        # (cc/math_utils.cc:17-19), so the non-rigid path does not re-centre the clouds.
+        z = np.zeros(source.shape[1])
+        return z, z
+
+    def _build(self):
+        self._plan = CpdPlan(self._device)
+        self._plan.set_source(self._source)
+        self._source_uploaded = True
+        self._plan.build_g(self._beta)
+        self._tf_obj = tf.NonRigidTransformation(None, self._source, self._beta, _plan=self._plan)
+
+    def set_source(self, source):
+        self._source = _as_points(source)
+        self._build()
+
+    def _initialize(self, target):
+        plan = self._setup_plan(target)
+        plan.init_params(None)
+        self._tf_obj.w = np.zeros_like(self._source)
+        plan.set_w(self._tf_obj.w)
+        return self._result_from_params(plan.get_params())
+
+    def _all_reduce_moments(self, plan):
+        super(NonRigidCPD, self)._all_reduce_moments(plan)
+        rank, world = pdist.world()
+        if world > 1:
+            self._all_reduce_rowacc(plan)
+
+    def _all_reduce_rowacc(self, plan):
+        import torch
+
+        ptr_, count = plan.rowacc_tensor_view()
+
+        class _View(object):
+            __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr_, False), "version": 2}
+
+        t = torch.as_tensor(_View(), device="cuda:%d" % plan.device)
+        pdist.all_reduce_sum_(t)
+
+    def _device_mstep(self, plan):
+        plan.mstep_nonrigid(self._lmd)
+
+    def _result_from_params(self, params):
+        if params[16] > 0:
+            self._tf_obj.w = self._plan.get_w()
+        return MstepResult(self._tf_obj, float(params[13]), float(params[14]))
+
+    def maximization_step(self, target, estep_res, sigma2_p=None):
+        return self._maximization_step(self._source, target, estep_res, sigma2_p)
+
+    def _maximization_step(self, source, target, estep_res, sigma2_p=None):
+        raise NotImplementedError(
+            "NonRigidCPD.maximization_step on explicit arrays is not exposed; use registration()."
+        )
+
+
+def registration_cpd(source, target, tf_type_name="rigid", w=0.0, maxiter=50, tol=0.001, callbacks=[],
+                     use_cuda=False, **kwargs):
+    """CPD Registraion (reference cpd.py:407-456).
+
+    Args:
+        source (numpy.ndarray): Source point cloud data.
+        target (numpy.ndarray): Target point cloud data.
+        tf_type_name (str, optional): Transformation type('rigid', 'affine', 'nonrigid')
+        w (float, optional): Weight of the uniform distribution, 0 < `w` < 1.
+        maxitr (int, optional): Maximum number of iterations to EM algorithm.
+        tol (float, optional): Tolerance for termination.
+        callback (:obj:`list` of :obj:`function`, optional): Called after each iteration.
+            `callback(probreg.Transformation)`
+        use_cuda (bool, optional): accepted for compatibility, ignored (always the HIP engine).
+
+    Keyword Args:
+        update_scale (bool, optional): If this flag is true and tf_type is rigid transformation,
+            then the scale is treated. The default is true.
+        tf_init_params (dict, optional): Parameters to initialize transformation (for rigid or affine).
+
+    Returns:
+        MstepResult: Result of the registration (transformation, sigma2, q)
+    """
+    if tf_type_name == "rigid":
+        cpd = RigidCPD(_as_points(source), use_cuda=use_cuda, **kwargs)
+    elif tf_type_name == "affine":
+        cpd = AffineCPD(_as_points(source), use_cuda=use_cuda, **kwargs)
+    elif tf_type_name == "nonrigid":
+        cpd = NonRigidCPD(_as_points(source), use_cuda=use_cuda, **kwargs)
+    elif tf_type_name == "nonrigid_constrained":
+        raise NotImplementedError("ConstrainedNonRigidCPD is a next-row (SURVEY.md section 8f), not built yet.")
+    else:
+        raise ValueError("Unknown transformation type %s" % tf_type_name)
+    cpd.set_callbacks(callbacks)
+    return cpd.registration(_as_points(target), w, maxiter, tol)

@@ -1,0 +1,877 @@
+// CPD EM iteration for MI355X (gfx950): E-step pair sweeps, fp64 moment reduction, device M-step.
+//
+// Reference behaviour (neka-nat/probreg v0.3.7):
+//   E-step   probreg/cpd.py:71-88          M-step rigid  probreg/cpd.py:160-192
+//   M-step affine probreg/cpd.py:219-244   transforms    probreg/transformation.py:49-50, 77-78
+//
+// Design: the M x N responsibility matrix is never stored.
+//   k_colpass  lane owns R target columns, streams a segment of the transformed source through
+//              SGPRs (scalar loads, wave-uniform), keeps an online (min d^2, sum exp2) pair.
+//   k_colfinal merges the segment partials in fp64 -> b_n = -log2(den_n + c), pt1_n.
+//   k_rowpass  lane owns R source rows, streams a segment of (x_n, b_n) through SGPRs and
+//              accumulates p1, u = sum P (x - z), e = sum P |x - z|^2 (residual form, fp32).
+//   k_row_moments  sums the segment partials per row in fp64, rebuilds px = u + p1 z and the
+//              23 fp64 moments the rigid / affine M-step needs (the RCCL all-reduce payload).
+//   k_mstep    one thread, fp64: 3x3 one-sided Jacobi SVD / 3x3 solve, sigma2, q.
+#include <math.h>
+
+#include "cpd_plan.h"
+#include "cpd_sweeps.h"
+
+namespace {
+
+constexpr double kLog2e = 1.4426950408889634;
+constexpr double kEps32 = 1.1920928955078125e-07;  // np.finfo(np.float32).eps, cpd.py:81,189
+constexpr int kBlock = 256;
+constexpr int kMomComp = 24;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout / upload helpers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack_cloud(const float* __restrict__ in, int64_t n, int dim,
+                                                       float4* __restrict__ out, int64_t cap, float pad,
+                                                       float aux) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap) return;
+    float4 v;
+    if (i < n) {
+        v.x = in[i * dim];
+        v.y = in[i * dim + 1];
+        v.z = dim > 2 ? in[i * dim + 2] : 0.f;
+        v.w = aux;
+    } else {
+        v.x = v.y = v.z = pad;
+        v.w = 0.f;
+    }
+    out[i] = v;
+}
+
+// sum of coordinates and of squared norms: partials [nblk][4]
+__global__ __launch_bounds__(kBlock) void k_cloud_sums(const float4* __restrict__ pts, int64_t n,
+                                                       double* __restrict__ part) {
+    __shared__ double sh[4][4];
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a[4] = {0, 0, 0, 0};
+    if (i < n) {
+        float4 v = pts[i];
+        a[0] = v.x; a[1] = v.y; a[2] = v.z;
+        a[3] = (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double s = wave_sum(a[c]);
+        if (lane == 0) sh[wv][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) part[(int64_t)blockIdx.x * 4 + threadIdx.x] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// out[off + c] (=|+=) sum_b part[b][ncomp] ; one block of 256 threads, ncomp <= 32
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ part, int nblk, int ncomp,
+                                                            double* __restrict__ out, int off) {
+    __shared__ double sh[8][32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double s = 0.0;
+    if (c < ncomp)
+        for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * ncomp + c];
+    sh[slice][c] = s;
+    __syncthreads();
+    if (threadIdx.x < ncomp) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x];
+        out[off + threadIdx.x] = t;
+    }
+}
+
+__global__ void k_zero_doubles(double* p, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+// sigma2_0 = [M sum|x|^2 + N sum|y|^2 - 2 (sum x).(sum y)] / (D M N)   (math_utils.py:28-29 in closed form)
+// q0 = 1 + N D / 2 log(sigma2_0)                                           (cpd.py:148)
+__global__ void k_init_params(const double* __restrict__ moments, const double* __restrict__ srcsum,
+                              double* __restrict__ params, double m, double nglobal, int dim,
+                              const double* __restrict__ init /* 13 doubles or null */) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double* ts = moments + 24;
+    double cross = ts[0] * srcsum[0] + ts[1] * srcsum[1] + ts[2] * srcsum[2];
+    double sigma2 = (m * ts[3] + nglobal * srcsum[3] - 2.0 * cross) / (dim * m * nglobal);
+    for (int i = 0; i < PRG_NPARAMS; ++i) params[i] = 0.0;
+    if (init) {
+        for (int i = 0; i < 13; ++i) params[i] = init[i];
+    } else {
+        params[0] = params[4] = params[8] = 1.0;
+        params[12] = 1.0;
+    }
+    params[13] = sigma2;
+    params[14] = 1.0 + nglobal * dim * 0.5 * log(sigma2);
+}
+
+// z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).
+__global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __restrict__ src4, float4* __restrict__ z4,
+                                                             int64_t m, int64_t cap,
+                                                             const double* __restrict__ params) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap) return;
+    float4 o;
+    if (i < m) {
+        const double s = params[12];
+        float4 y = src4[i];
+        double yx = y.x, yy = y.y, yz = y.z;
+        o.x = (float)(s * (params[0] * yx + params[1] * yy + params[2] * yz) + params[9]);
+        o.y = (float)(s * (params[3] * yx + params[4] * yy + params[5] * yz) + params[10]);
+        o.z = (float)(s * (params[6] * yx + params[7] * yy + params[8] * yz) + params[11]);
+        o.w = 0.f;
+    } else {
+        o.x = o.y = o.z = prg::kSrcPad;
+        o.w = 0.f;
+    }
+    z4[i] = o;
+}
+
+// (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip)
+
+// Merge the S partial (min, sum) pairs of each column in fp64; apply cpd.py:78-82:
+//   den == 0 -> eps32 (then the whole column of P is 0/eps = 0), den += c.
+// Writes b_n = -log2(den_n) into tgt4[n].w so that P_mn = exp2(kk d2 + b_n), and pt1_n = den/(den+c).
+__global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, const float2* __restrict__ colpart,
+                                                     int nseg, int64_t ncap, int64_t n, float* __restrict__ pt1,
+                                                     const double* __restrict__ params, double w, double m_over_n,
+                                                     int dim) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double sigma2 = params[13];
+    const float kkf = (float)(-kLog2e / (2.0 * sigma2));
+    const double kk = (double)kkf;
+    float gmin = INFINITY;
+    for (int s = 0; s < nseg; ++s) gmin = fminf(gmin, colpart[(int64_t)s * ncap + i].x);
+    double ssum = 0.0;
+    for (int s = 0; s < nseg; ++s) {
+        const float2 p = colpart[(int64_t)s * ncap + i];
+        ssum += (double)p.y * exp2(kk * ((double)p.x - (double)gmin));
+    }
+    const double den = ssum * exp2(kk * (double)gmin);  // underflows to 0 exactly where fp64 exp() does
+    double c = pow(2.0 * M_PI * sigma2, dim * 0.5);
+    c *= w / (1.0 - w) * m_over_n;
+    float b, p;
+    if (den == 0.0) {
+        b = -INFINITY;
+        p = 0.f;
+    } else {
+        const double tot = den + c;
+        b = (float)(-log2(tot));
+        p = (float)(den / tot);
+    }
+    reinterpret_cast<float*>(tgt4 + i)[3] = b;
+    pt1[i] = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp64 moment reduction: per row, then per block -> mompart[nblk][24]
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_reduce_store(double (&a)[kMomComp], double* __restrict__ mompart) {
+    __shared__ double sh[4][kMomComp];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < kMomComp; ++c) {
+        const double s = wave_sum(a[c]);
+        if (lane == 0) sh[wv][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMomComp)
+        mompart[(int64_t)blockIdx.x * kMomComp + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__device__ __forceinline__ void row_moment_terms(double (&a)[kMomComp], double p1, const double (&px)[3],
+                                                 const double (&y)[3]) {
+    a[0] = p1;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[1 + i] = px[i];
+        a[4 + i] = p1 * y[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[7 + 3 * i + j] = px[i] * y[j];
+    }
+    a[16] = p1 * y[0] * y[0];
+    a[17] = p1 * y[0] * y[1];
+    a[18] = p1 * y[0] * y[2];
+    a[19] = p1 * y[1] * y[1];
+    a[20] = p1 * y[1] * y[2];
+    a[21] = p1 * y[2] * y[2];
+}
+
+__global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict__ rowpart, int nseg, int64_t mcap,
+                                                        int64_t m, const float4* __restrict__ src4,
+                                                        const float4* __restrict__ z4, double* __restrict__ rowacc,
+                                                        double* __restrict__ mompart) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a[kMomComp];
+#pragma unroll
+    for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
+    if (i < m) {
+        double p1 = 0, u[3] = {0, 0, 0}, e = 0;
+        for (int s = 0; s < nseg; ++s) {
+            const float* __restrict__ o = rowpart + (int64_t)s * 5 * mcap + i;
+            p1 += o[0];
+            u[0] += o[mcap];
+            u[1] += o[2 * mcap];
+            u[2] += o[3 * mcap];
+            e += o[4 * mcap];
+        }
+        const float4 zf = z4[i], yf = src4[i];
+        const double z[3] = {zf.x, zf.y, zf.z};
+        const double y[3] = {yf.x, yf.y, yf.z};
+        double px[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) px[k] = u[k] + p1 * z[k];  // exact identity: sum P x = sum P (x - z) + p1 z
+        row_moment_terms(a, p1, px, y);
+        // sum_n pt1_n |x_n|^2 restricted to this row: sum_n P |x|^2 = p1 |z|^2 + 2 z.u + e
+        a[22] = p1 * (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) + 2.0 * (z[0] * u[0] + z[1] * u[1] + z[2] * u[2]) + e;
+        rowacc[i] = p1;
+        rowacc[mcap + i] = px[0];
+        rowacc[2 * mcap + i] = px[1];
+        rowacc[3 * mcap + i] = px[2];
+    }
+    block_reduce_store(a, mompart);
+}
+
+// Moments from explicit EstepResult arrays (public maximization_step path, cpd.py:90-93):
+// rows (p1, px) -> comps 0..21 ; columns (pt1, x) -> comp 22.  grid covers max(M, N) items.
+__global__ __launch_bounds__(kBlock) void k_moments_from_arrays(const double* __restrict__ pt1,
+                                                                const double* __restrict__ p1,
+                                                                const double* __restrict__ px, int dim, int64_t m,
+                                                                int64_t n, const float4* __restrict__ src4,
+                                                                const float4* __restrict__ tgt4,
+                                                                double* __restrict__ mompart) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a[kMomComp];
+#pragma unroll
+    for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
+    if (i < m) {
+        const float4 yf = src4[i];
+        const double y[3] = {yf.x, yf.y, yf.z};
+        double pxi[3] = {px[i * dim], px[i * dim + 1], dim > 2 ? px[i * dim + 2] : 0.0};
+        row_moment_terms(a, p1[i], pxi, y);
+    }
+    if (i < n) {
+        const float4 xf = tgt4[i];
+        a[22] = pt1[i] * ((double)xf.x * xf.x + (double)xf.y * xf.y + (double)xf.z * xf.z);
+    }
+    block_reduce_store(a, mompart);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device M-step (fp64, one thread)
+// ---------------------------------------------------------------------------------------------
+// One-sided Jacobi SVD of a d x d (d <= 3) matrix: a = U diag(sv) V^T.  Returns U, V, sv (unsorted).
+__device__ void jacobi_svd(const double a[3][3], int d, double U[3][3], double V[3][3], double sv[3]) {
+    double g[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            g[i][j] = (i < d && j < d) ? a[i][j] : 0.0;
+            V[i][j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < d - 1; ++p)
+            for (int q = p + 1; q < d; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < d; ++i) {
+                    alpha += g[i][p] * g[i][p];
+                    beta += g[i][q] * g[i][q];
+                    gamma += g[i][p] * g[i][q];
+                }
+                const double lim = 1e-300 + 1e-17 * sqrt(alpha * beta);
+                if (fabs(gamma) <= lim) continue;
+                off = fmax(off, fabs(gamma) / sqrt(alpha * beta));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+                for (int i = 0; i < d; ++i) {
+                    const double gp = g[i][p], gq = g[i][q];
+                    g[i][p] = c * gp - s * gq;
+                    g[i][q] = s * gp + c * gq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq;
+                    V[i][q] = s * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    double nmax = 0.0;
+    for (int j = 0; j < d; ++j) {
+        double nn = 0;
+        for (int i = 0; i < d; ++i) nn += g[i][j] * g[i][j];
+        sv[j] = sqrt(nn);
+        nmax = fmax(nmax, sv[j]);
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
+    bool ok[3] = {false, false, false};
+    for (int j = 0; j < d; ++j) {
+        ok[j] = sv[j] > 1e-14 * nmax && sv[j] > 0.0;
+        if (ok[j])
+            for (int i = 0; i < d; ++i) U[i][j] = g[i][j] / sv[j];
+    }
+    // complete U to an orthonormal basis where singular values vanish (rank-deficient `a`)
+    if (d == 2) {
+        if (ok[0] && !ok[1]) { U[0][1] = -U[1][0]; U[1][1] = U[0][0]; }
+        else if (!ok[0] && ok[1]) { U[0][0] = U[1][1]; U[1][0] = -U[0][1]; }
+        else if (!ok[0] && !ok[1]) { U[0][0] = U[1][1] = 1.0; U[0][1] = U[1][0] = 0.0; }
+    } else if (d == 3) {
+        int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
+        if (nbad == 1) {
+            int b = !ok[0] ? 0 : (!ok[1] ? 1 : 2);
+            int p = (b + 1) % 3, q = (b + 2) % 3;
+            U[0][b] = U[1][p] * U[2][q] - U[2][p] * U[1][q];
+            U[1][b] = U[2][p] * U[0][q] - U[0][p] * U[2][q];
+            U[2][b] = U[0][p] * U[1][q] - U[1][p] * U[0][q];
+        } else if (nbad >= 2) {
+            int gidx = ok[0] ? 0 : (ok[1] ? 1 : (ok[2] ? 2 : -1));
+            if (gidx < 0) {
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
+            } else {
+                // pick the coordinate axis least aligned with the good column, Gram-Schmidt, cross
+                int ax = 0;
+                double best = fabs(U[0][gidx]);
+                for (int i = 1; i < 3; ++i)
+                    if (fabs(U[i][gidx]) < best) { best = fabs(U[i][gidx]); ax = i; }
+                double v[3] = {0, 0, 0};
+                v[ax] = 1.0;
+                double dp = U[ax][gidx];
+                double nn = 0;
+                for (int i = 0; i < 3; ++i) { v[i] -= dp * U[i][gidx]; nn += v[i] * v[i]; }
+                nn = sqrt(nn);
+                int p = (gidx + 1) % 3, q = (gidx + 2) % 3;
+                for (int i = 0; i < 3; ++i) U[i][p] = v[i] / nn;
+                U[0][q] = U[1][gidx] * U[2][p] - U[2][gidx] * U[1][p];
+                U[1][q] = U[2][gidx] * U[0][p] - U[0][gidx] * U[2][p];
+                U[2][q] = U[0][gidx] * U[1][p] - U[1][gidx] * U[0][p];
+            }
+        }
+    }
+}
+
+__device__ double det3(const double a[3][3], int d) {
+    if (d == 2) return a[0][0] * a[1][1] - a[0][1] * a[1][0];
+    return a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+}
+
+// kind: PRG_TF_RIGID (cpd.py:160-192) or PRG_TF_AFFINE (cpd.py:219-244).
+__global__ void k_mstep(const double* __restrict__ mom, double* __restrict__ params, int kind, int update_scale,
+                        int dim) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int d = dim;
+    const double S0 = mom[0];
+    double mu_x[3], mu_y[3], A[3][3], YPY[3][3];
+    for (int i = 0; i < 3; ++i) {
+        mu_x[i] = mom[1 + i] / S0;  // cpd.py:169
+        mu_y[i] = mom[4 + i] / S0;  // cpd.py:170
+    }
+    // a = px^T (Y - mu_y) - mu_x (p1^T (Y - mu_y)) ; the second term is identically 0   (cpd.py:173-175)
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = mom[7 + 3 * i + j] - mom[1 + i] * mu_y[j];
+    const double syy[3][3] = {{mom[16], mom[17], mom[18]}, {mom[17], mom[19], mom[20]}, {mom[18], mom[20], mom[21]}};
+    double tr_yp1y = 0.0, mux2 = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) YPY[i][j] = syy[i][j] - S0 * mu_y[i] * mu_y[j];  // (Y-mu)^T diag(p1) (Y-mu)
+        if (i < d) tr_yp1y += YPY[i][i];
+        mux2 += mu_x[i] * mu_x[i];
+    }
+    const double tr_xp1x = mom[22] - S0 * mux2;  // cpd.py:183 / 237
+    double L[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double t[3] = {0, 0, 0};
+    double scale = 1.0, sigma2, q;
+    if (kind == PRG_TF_RIGID) {
+        double U[3][3], V[3][3], sv[3];
+        jacobi_svd(A, d, U, V, sv);
+        // rot = U diag(1,..,det(U V^T)) V^T with the correction on the smallest singular value (cpd.py:176-179)
+        int jmin = 0;
+        for (int j = 1; j < d; ++j)
+            if (sv[j] < sv[jmin]) jmin = j;
+        const double dd = det3(U, d) * det3(V, d);
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double r = 0;
+                for (int k = 0; k < d; ++k) r += (k == jmin ? dd : 1.0) * U[i][k] * V[j][k];
+                L[i][j] = r;
+            }
+        double tr_atr = 0.0;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) tr_atr += A[i][j] * L[i][j];  // trace(a^T rot), cpd.py:180
+        scale = update_scale ? tr_atr / tr_yp1y : 1.0;                // cpd.py:182
+        for (int i = 0; i < d; ++i) {
+            double r = 0;
+            for (int j = 0; j < d; ++j) r += L[i][j] * mu_y[j];
+            t[i] = mu_x[i] - scale * r;  // cpd.py:183
+        }
+        if (update_scale)
+            sigma2 = (tr_xp1x - scale * tr_atr) / (S0 * d);  // cpd.py:186
+        else
+            sigma2 = (tr_xp1x + tr_yp1y - scale * tr_atr) / (S0 * d);  // cpd.py:188 (sic)
+        sigma2 = fmax(sigma2, kEps32);                                  // cpd.py:189
+        q = (tr_xp1x - 2.0 * scale * tr_atr + scale * scale * tr_yp1y) / (2.0 * sigma2);
+        q += d * S0 * 0.5 * log(sigma2);  // cpd.py:190-191
+    } else {
+        // b = solve(yp1y^T, a^T)^T : Gaussian elimination with partial pivoting on the d x d system (cpd.py:235)
+        double Mx[3][6];
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                Mx[i][j] = YPY[j][i];
+                Mx[i][d + j] = A[j][i];
+            }
+        for (int c = 0; c < d; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < d; ++r)
+                if (fabs(Mx[r][c]) > fabs(Mx[piv][c])) piv = r;
+            if (piv != c)
+                for (int j = 0; j < 2 * d; ++j) { double tmp = Mx[c][j]; Mx[c][j] = Mx[piv][j]; Mx[piv][j] = tmp; }
+            for (int r = c + 1; r < d; ++r) {
+                const double f = Mx[r][c] / Mx[c][c];
+                for (int j = c; j < 2 * d; ++j) Mx[r][j] -= f * Mx[c][j];
+            }
+        }
+        double Xs[3][3];
+        for (int col = 0; col < d; ++col)
+            for (int r = d - 1; r >= 0; --r) {
+                double v = Mx[r][d + col];
+                for (int j = r + 1; j < d; ++j) v -= Mx[r][j] * Xs[j][col];
+                Xs[r][col] = v / Mx[r][r];
+            }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) L[i][j] = Xs[j][i];
+        double tr_ab = 0.0;
+        for (int i = 0; i < d; ++i) {
+            double r = 0;
+            for (int j = 0; j < d; ++j) {
+                r += L[i][j] * mu_y[j];
+                tr_ab += A[i][j] * L[i][j];  // trace(a b^T), cpd.py:238,240
+            }
+            t[i] = mu_x[i] - r;  // cpd.py:236
+        }
+        sigma2 = (tr_xp1x - tr_ab) / (S0 * d);  // cpd.py:239
+        sigma2 = fmax(sigma2, kEps32);
+        q = (tr_xp1x - 2.0 * tr_ab + tr_ab) / (2.0 * sigma2) + d * S0 * 0.5 * log(sigma2);  // cpd.py:242-243
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) params[3 * i + j] = L[i][j];
+        params[9 + i] = t[i];
+    }
+    params[12] = scale;
+    params[13] = sigma2;
+    params[14] = q;
+    params[15] = S0;
+    params[16] += 1.0;
+}
+
+// EstepResult materialisation helpers
+__global__ __launch_bounds__(kBlock) void k_float_to_double(const float* __restrict__ in, double* __restrict__ out,
+                                                            int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ __launch_bounds__(kBlock) void k_pack_px(const double* __restrict__ rowacc, int64_t mcap, int64_t m,
+                                                    int dim, double* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    for (int k = 0; k < dim; ++k) out[i * dim + k] = rowacc[(int64_t)(1 + k) * mcap + i];
+}
+__global__ __launch_bounds__(kBlock) void k_unpack_points(const float4* __restrict__ in, int64_t m, int dim,
+                                                          float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const float4 v = in[i];
+    out[i * dim] = v.x;
+    out[i * dim + 1] = v.y;
+    if (dim > 2) out[i * dim + 2] = v.z;
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
+
+// choose the segment count so that the grid has a few thousand blocks and segments stay long
+int auto_segments(int64_t nblk_x, int64_t stream_len) {
+    int64_t s = prg::ceil_div(6144, nblk_x);
+    int64_t max_by_len = stream_len / 256;
+    if (s > max_by_len) s = max_by_len;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+int free_plan_buffers(prg_cpd* h) {
+    if (h->src4) (void)hipFree(h->src4);
+    if (h->z4) (void)hipFree(h->z4);
+    if (h->tgt4) (void)hipFree(h->tgt4);
+    if (h->pt1) (void)hipFree(h->pt1);
+    if (h->colpart) (void)hipFree(h->colpart);
+    if (h->rowpart) (void)hipFree(h->rowpart);
+    if (h->rowacc) (void)hipFree(h->rowacc);
+    if (h->mompart) (void)hipFree(h->mompart);
+    if (h->stage) (void)hipFree(h->stage);
+    h->src4 = h->z4 = h->tgt4 = nullptr;
+    h->pt1 = nullptr;
+    h->colpart = nullptr;
+    h->rowpart = nullptr;
+    h->rowacc = nullptr;
+    h->mompart = nullptr;
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    return PRG_OK;
+}
+
+template <typename T>
+int ensure_buffer(T** p, int64_t* have, int64_t need) {
+    if (*p && *have >= need) return PRG_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    PRG_HIP(hipMalloc((void**)p, (size_t)need * sizeof(T)));
+    *have = need;
+    return PRG_OK;
+}
+
+int cap_for(int64_t n) { return (int)prg::round_up(n + 1024, 1024); }
+
+int mom_blocks(const prg_cpd* h) {
+    int64_t items = h->M > h->N ? h->M : h->N;
+    return (int)prg::ceil_div(items, kBlock);
+}
+
+int ensure_mompart(prg_cpd* h) {
+    int64_t need = (int64_t)mom_blocks(h) * kMomComp + 64;
+    return ensure_buffer(&h->mompart, &h->mompart_elems, need);
+}
+
+}  // namespace
+
+namespace prg {
+int ensure_stage(prg_cpd* h, size_t bytes) {
+    if (h->stage && h->stage_bytes >= bytes) return PRG_OK;
+    if (h->stage) {
+        PRG_HIP(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->stage);
+    }
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    PRG_HIP(hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    return PRG_OK;
+}
+}  // namespace prg
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int prg_cpd_create(prg_cpd** out, int device, void* hip_stream) {
+    PRG_REQUIRE(out != nullptr, PRG_ERR_INVALID, "prg_cpd_create: out is NULL");
+    int count = 0;
+    PRG_HIP(hipGetDeviceCount(&count));
+    PRG_REQUIRE(device >= 0 && device < count, PRG_ERR_INVALID, "prg_cpd_create: device %d out of range (%d devices)",
+                device, count);
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_cpd_create: hipSetDevice(%d) failed", device);
+    prg_cpd* h = new (std::nothrow) prg_cpd();
+    PRG_REQUIRE(h != nullptr, PRG_ERR_NOMEM, "prg_cpd_create: out of host memory");
+    h->device = device;
+    h->stream = (hipStream_t)hip_stream;
+    hipError_t e = hipMalloc((void**)&h->state, (PRG_NMOMENTS + PRG_NPARAMS) * sizeof(double));
+    if (e != hipSuccess) {
+        delete h;
+        prg::set_error("prg_cpd_create: hipMalloc failed: %s", hipGetErrorString(e));
+        return PRG_ERR_HIP;
+    }
+    h->moments = h->state;
+    h->params = h->state + PRG_NMOMENTS;
+    k_zero_doubles<<<1, 64, 0, h->stream>>>(h->state, PRG_NMOMENTS + PRG_NPARAMS);
+    *out = h;
+    return PRG_OK;
+}
+
+int prg_cpd_destroy(prg_cpd* h) {
+    if (!h) return PRG_OK;
+    prg::DeviceGuard g(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_plan_buffers(h);
+    prg::nonrigid_free(h);
+    if (h->state) (void)hipFree(h->state);
+    delete h;
+    return PRG_OK;
+}
+
+int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
+    PRG_REQUIRE(h && source_hd, PRG_ERR_INVALID, "prg_cpd_set_source: NULL argument");
+    PRG_REQUIRE(m > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID,
+                "prg_cpd_set_source: need m > 0 and dim in {2,3} (got m=%lld dim=%d)", (long long)m, dim);
+    PRG_REQUIRE(!h->have_target || h->D == dim, PRG_ERR_INVALID,
+                "prg_cpd_set_source: dim %d does not match target dim %d", dim, h->D);
+    prg::DeviceGuard g(h->device);
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    const int64_t cap = cap_for(m);
+    if (cap != h->Mcap) {
+        if (h->src4) (void)hipFree(h->src4);
+        if (h->z4) (void)hipFree(h->z4);
+        if (h->rowacc) (void)hipFree(h->rowacc);
+        h->src4 = h->z4 = nullptr;
+        h->rowacc = nullptr;
+        PRG_HIP(hipMalloc((void**)&h->src4, cap * sizeof(float4)));
+        PRG_HIP(hipMalloc((void**)&h->z4, cap * sizeof(float4)));
+        PRG_HIP(hipMalloc((void**)&h->rowacc, 4 * cap * sizeof(double)));
+    }
+    h->M = m;
+    h->D = dim;
+    h->Mcap = cap;
+    PRG_TRY(prg::ensure_stage(h, (size_t)m * dim * sizeof(float)));
+    PRG_HIP(hipMemcpyAsync(h->stage, source_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, h->stream));
+    k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, m, dim, h->src4, cap, prg::kSrcPad,
+                                                       0.f);
+    k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, m, dim, h->z4, cap, prg::kSrcPad, 0.f);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipStreamSynchronize(h->stream));  // the caller's buffer may be pageable host memory
+    h->have_source = true;
+    h->have_estep = false;
+    prg::nonrigid_free(h);
+    return PRG_OK;
+}
+
+int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int dim, int64_t n_global) {
+    PRG_REQUIRE(h && target_hd, PRG_ERR_INVALID, "prg_cpd_set_target: NULL argument");
+    PRG_REQUIRE(n_local > 0 && n_global >= n_local && (dim == 2 || dim == 3), PRG_ERR_INVALID,
+                "prg_cpd_set_target: need 0 < n_local <= n_global and dim in {2,3}");
+    PRG_REQUIRE(!h->have_source || h->D == dim, PRG_ERR_INVALID,
+                "prg_cpd_set_target: dim %d does not match source dim %d", dim, h->D);
+    prg::DeviceGuard g(h->device);
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    const int64_t cap = cap_for(n_local);
+    if (cap != h->Ncap) {
+        if (h->tgt4) (void)hipFree(h->tgt4);
+        if (h->pt1) (void)hipFree(h->pt1);
+        h->tgt4 = nullptr;
+        h->pt1 = nullptr;
+        PRG_HIP(hipMalloc((void**)&h->tgt4, cap * sizeof(float4)));
+        PRG_HIP(hipMalloc((void**)&h->pt1, cap * sizeof(float)));
+    }
+    h->N = n_local;
+    h->Nglobal = n_global;
+    h->D = dim;
+    h->Ncap = cap;
+    PRG_TRY(prg::ensure_stage(h, (size_t)n_local * dim * sizeof(float)));
+    PRG_HIP(hipMemcpyAsync(h->stage, target_hd, (size_t)n_local * dim * sizeof(float), hipMemcpyDefault, h->stream));
+    k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, n_local, dim, h->tgt4, cap,
+                                                       prg::kTgtPad, 0.f);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    h->have_target = true;
+    h->have_estep = false;
+    return PRG_OK;
+}
+
+int prg_cpd_bind_moments(prg_cpd* h, double* moments_dev) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_bind_moments: NULL handle");
+    h->moments = moments_dev ? moments_dev : h->state;
+    return PRG_OK;
+}
+
+int prg_cpd_moments_ptr(prg_cpd* h, double** moments_dev) {
+    PRG_REQUIRE(h && moments_dev, PRG_ERR_INVALID, "prg_cpd_moments_ptr: NULL argument");
+    *moments_dev = h->moments;
+    return PRG_OK;
+}
+
+int prg_cpd_params_ptr(prg_cpd* h, double** params_dev) {
+    PRG_REQUIRE(h && params_dev, PRG_ERR_INVALID, "prg_cpd_params_ptr: NULL argument");
+    *params_dev = h->params;
+    return PRG_OK;
+}
+
+int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_row) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_tuning: NULL handle");
+    auto ok_r = [](int r) { return r == 0 || r == 2 || r == 4 || r == -2 || r == -4; };
+    PRG_REQUIRE(ok_r(r_col) && ok_r(r_row), PRG_ERR_INVALID,
+                "prg_cpd_set_tuning: points per lane must be 0 (auto), 2, 4 (packed) or -2, -4 (scalar form)");
+    PRG_REQUIRE(seg_col >= 0 && seg_col <= 256 && seg_row >= 0 && seg_row <= 256, PRG_ERR_INVALID,
+                "prg_cpd_set_tuning: segment counts must be in [0, 256]");
+    h->r_col = r_col;
+    h->seg_col = seg_col;
+    h->r_row = r_row;
+    h->seg_row = seg_row;
+    return PRG_OK;
+}
+
+int prg_cpd_init_sums(prg_cpd* h) {
+    PRG_REQUIRE(h && h->have_target, PRG_ERR_STATE, "prg_cpd_init_sums: target not set");
+    prg::DeviceGuard g(h->device);
+    PRG_TRY(ensure_mompart(h));
+    const int nblk = (int)prg::ceil_div(h->N, kBlock);
+    k_zero_doubles<<<1, 64, 0, h->stream>>>(h->moments, PRG_NMOMENTS);
+    k_cloud_sums<<<nblk, kBlock, 0, h->stream>>>(h->tgt4, h->N, h->mompart);
+    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, 4, h->moments, 24);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
+    PRG_REQUIRE(h && h->have_source && h->have_target, PRG_ERR_STATE, "prg_cpd_init_params: clouds not set");
+    prg::DeviceGuard g(h->device);
+    PRG_TRY(ensure_mompart(h));
+    const int nblk = (int)prg::ceil_div(h->M, kBlock);
+    double* srcsum = h->mompart + (h->mompart_elems - 64);
+    double* init_dev = nullptr;
+    if (init_params_host) {
+        init_dev = srcsum + 8;
+        PRG_HIP(hipMemcpyAsync(init_dev, init_params_host, 13 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    k_cloud_sums<<<nblk, kBlock, 0, h->stream>>>(h->src4, h->M, h->mompart);
+    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, 4, srcsum, 0);
+    k_init_params<<<1, 64, 0, h->stream>>>(h->moments, srcsum, h->params, (double)h->M, (double)h->Nglobal, h->D,
+                                           init_dev);
+    PRG_HIP(hipGetLastError());
+    if (init_params_host) PRG_HIP(hipStreamSynchronize(h->stream));  // host buffer may be reused by the caller
+    return PRG_OK;
+}
+
+int prg_cpd_estep(prg_cpd* h, double w) {
+    PRG_REQUIRE(h && h->have_source && h->have_target, PRG_ERR_STATE, "prg_cpd_estep: clouds not set");
+    PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_cpd_estep: w must be in [0, 1) (got %g)", w);
+    prg::DeviceGuard g(h->device);
+    const int ra = h->r_col ? h->r_col : 2, rb = h->r_row ? h->r_row : 2;
+    const int RA = ra < 0 ? -ra : ra, RB = rb < 0 ? -rb : rb;
+    const int64_t nblkA = prg::ceil_div(h->N, kBlock * RA), nblkB = prg::ceil_div(h->M, kBlock * RB);
+    int SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M);
+    int SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N);
+    // segment lengths are multiples of the loop trip (8 points); the pads absorb the overshoot and the
+    // prefetch over-read of the last segment
+    auto seg_of = [](int64_t len, int s) { return (int)prg::round_up(prg::ceil_div(len, s), 8); };
+    int segA = seg_of(h->M, SA), segB = seg_of(h->N, SB);
+    while (SA > 1 && (int64_t)SA * segA + prg::kOverRead > h->Mcap) --SA, segA = seg_of(h->M, SA);
+    while (SB > 1 && (int64_t)SB * segB + prg::kOverRead > h->Ncap) --SB, segB = seg_of(h->N, SB);
+    PRG_REQUIRE((int64_t)SA * segA + prg::kOverRead <= h->Mcap && (int64_t)SB * segB + prg::kOverRead <= h->Ncap,
+                PRG_ERR_STATE, "prg_cpd_estep: internal segmenting failure");
+    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)SA * h->Ncap));
+    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)SB * 5 * h->Mcap));
+    PRG_TRY(ensure_mompart(h));
+
+    if (h->nonrigid)
+        PRG_TRY(prg::nonrigid_transform(h));
+    else
+        k_transform_linear<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->Mcap, h->params);
+    if (ra < 0) prg::launch_colpass_scalar(h, RA, SA, segA); else prg::launch_colpass_packed(h, RA, SA, segA);
+    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
+                                                      (double)h->M / (double)h->Nglobal, h->D);
+    if (rb < 0) prg::launch_rowpass_scalar(h, RB, SB, segB); else prg::launch_rowpass_packed(h, RB, SB, segB);
+    const int nblk = (int)prg::ceil_div(h->M, kBlock);
+    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
+                                                  h->mompart);
+    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
+    PRG_HIP(hipGetLastError());
+    h->have_estep = true;
+    h->last_w = w;
+    return PRG_OK;
+}
+
+int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {
+    PRG_REQUIRE(h && h->have_source, PRG_ERR_STATE, "prg_cpd_mstep: source not set");
+    PRG_REQUIRE(kind == PRG_TF_RIGID || kind == PRG_TF_AFFINE, PRG_ERR_INVALID,
+                "prg_cpd_mstep: kind must be PRG_TF_RIGID or PRG_TF_AFFINE (use prg_cpd_mstep_nonrigid)");
+    prg::DeviceGuard g(h->device);
+    k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int prg_cpd_get_params(prg_cpd* h, double* params_host) {
+    PRG_REQUIRE(h && params_host, PRG_ERR_INVALID, "prg_cpd_get_params: NULL argument");
+    prg::DeviceGuard g(h->device);
+    PRG_HIP(hipMemcpyAsync(params_host, h->params, PRG_NPARAMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}
+
+int prg_cpd_set_params(prg_cpd* h, const double* params_host) {
+    PRG_REQUIRE(h && params_host, PRG_ERR_INVALID, "prg_cpd_set_params: NULL argument");
+    prg::DeviceGuard g(h->device);
+    PRG_HIP(hipMemcpyAsync(h->params, params_host, PRG_NPARAMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}
+
+int prg_cpd_get_moments(prg_cpd* h, double* moments_host) {
+    PRG_REQUIRE(h && moments_host, PRG_ERR_INVALID, "prg_cpd_get_moments: NULL argument");
+    prg::DeviceGuard g(h->device);
+    PRG_HIP(hipMemcpyAsync(moments_host, h->moments, PRG_NMOMENTS * sizeof(double), hipMemcpyDeviceToHost,
+                           h->stream));
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}
+
+int prg_cpd_get_estep(prg_cpd* h, double* pt1_hd, double* p1_hd, double* px_hd) {
+    PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_cpd_get_estep: no E-step has been run");
+    prg::DeviceGuard g(h->device);
+    const size_t need = (size_t)(h->N > h->M * h->D ? h->N : h->M * h->D) * sizeof(double);
+    PRG_TRY(prg::ensure_stage(h, need));
+    if (pt1_hd) {
+        k_float_to_double<<<grid1(h->N), kBlock, 0, h->stream>>>(h->pt1, (double*)h->stage, h->N);
+        PRG_HIP(hipMemcpyAsync(pt1_hd, h->stage, h->N * sizeof(double), hipMemcpyDefault, h->stream));
+        PRG_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (p1_hd) {
+        PRG_HIP(hipMemcpyAsync(p1_hd, h->rowacc, h->M * sizeof(double), hipMemcpyDefault, h->stream));
+        PRG_HIP(hipStreamSynchronize(h->stream));
+    }
+    if (px_hd) {
+        k_pack_px<<<grid1(h->M), kBlock, 0, h->stream>>>(h->rowacc, h->Mcap, h->M, h->D, (double*)h->stage);
+        PRG_HIP(hipMemcpyAsync(px_hd, h->stage, h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
+        PRG_HIP(hipStreamSynchronize(h->stream));
+    }
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int prg_cpd_get_tsource(prg_cpd* h, float* tsource_hd) {
+    PRG_REQUIRE(h && h->have_source && tsource_hd, PRG_ERR_STATE, "prg_cpd_get_tsource: source not set");
+    prg::DeviceGuard g(h->device);
+    PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(float)));
+    k_unpack_points<<<grid1(h->M), kBlock, 0, h->stream>>>(h->z4, h->M, h->D, (float*)h->stage);
+    PRG_HIP(hipMemcpyAsync(tsource_hd, h->stage, h->M * h->D * sizeof(float), hipMemcpyDefault, h->stream));
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}
+
+int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p1_hd, const double* px_hd) {
+    PRG_REQUIRE(h && h->have_source && h->have_target, PRG_ERR_STATE, "prg_cpd_moments_from_estep: clouds not set");
+    PRG_REQUIRE(pt1_hd && p1_hd && px_hd, PRG_ERR_INVALID, "prg_cpd_moments_from_estep: NULL array");
+    prg::DeviceGuard g(h->device);
+    const size_t nb_pt1 = (size_t)h->N * sizeof(double), nb_p1 = (size_t)h->M * sizeof(double),
+                 nb_px = (size_t)h->M * h->D * sizeof(double);
+    PRG_TRY(prg::ensure_stage(h, nb_pt1 + nb_p1 + nb_px));
+    PRG_TRY(ensure_mompart(h));
+    double* d_pt1 = (double*)h->stage;
+    double* d_p1 = d_pt1 + h->N;
+    double* d_px = d_p1 + h->M;
+    PRG_HIP(hipMemcpyAsync(d_pt1, pt1_hd, nb_pt1, hipMemcpyDefault, h->stream));
+    PRG_HIP(hipMemcpyAsync(d_p1, p1_hd, nb_p1, hipMemcpyDefault, h->stream));
+    PRG_HIP(hipMemcpyAsync(d_px, px_hd, nb_px, hipMemcpyDefault, h->stream));
+    const int nblk = mom_blocks(h);
+    k_moments_from_arrays<<<nblk, kBlock, 0, h->stream>>>(d_pt1, d_p1, d_px, h->D, h->M, h->N, h->src4, h->tgt4,
+                                                          h->mompart);
+    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,60 @@
+// Internal definition of the CPD plan (opaque `prg_cpd` of include/probreg_hip.h).
+#pragma once
+#include "prg_common.h"
+
+// Row accumulator block: 4 fp64 planes of Mcap (p1, px0, px1, px2), written by the moment kernel.
+struct prg_cpd {
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    int64_t M = 0, N = 0, Nglobal = 0;
+    int D = 0;
+    int64_t Mcap = 0, Ncap = 0;  // padded capacities (multiples of 1024, + slack for segmenting)
+
+    // clouds in their kernel layout (float4 per point: x, y, z, aux)
+    float4* src4 = nullptr;   // original source y_m            (aux = 0)
+    float4* z4 = nullptr;     // transformed source z_m         (aux = 0), rewritten every E-step
+    float4* tgt4 = nullptr;   // local target x_n               (aux = b_n = -log2(den_n + c))
+    float* pt1 = nullptr;     // [Ncap] column sums of P
+
+    // column pass partials [SA][Ncap] (dmin, sum)
+    float2* colpart = nullptr;
+    int64_t colpart_elems = 0;
+    // row pass partials [SB][5][Mcap] (p1, ux, uy, uz, e)
+    float* rowpart = nullptr;
+    int64_t rowpart_elems = 0;
+    // fp64 per-row block [4][Mcap]
+    double* rowacc = nullptr;
+    // moment block partials [nblk][24]
+    double* mompart = nullptr;
+    int64_t mompart_elems = 0;
+
+    double* state = nullptr;    // owned: PRG_NMOMENTS + PRG_NPARAMS doubles
+    double* moments = nullptr;  // -> state or caller-bound memory
+    double* params = nullptr;   // -> state + PRG_NMOMENTS
+
+    // tuning (0 = auto)
+    int r_col = 0, seg_col = 0, r_row = 0, seg_row = 0;
+
+    // staging for uploads / moments_from_estep
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+
+    // non-rigid state
+    float* G = nullptr;        // [M][M] float32 (row-major)
+    double* W = nullptr;       // [M][3] float64 (row-major, 3 columns always)
+    double beta = 0.0;
+    bool nonrigid = false;
+    double* nr_work = nullptr;  // solver workspace (fp64)
+    size_t nr_work_bytes = 0;
+
+    bool have_source = false, have_target = false, have_estep = false;
+    double last_w = 0.0;
+};
+
+namespace prg {
+int ensure_stage(prg_cpd* h, size_t bytes);
+// non-rigid (cpd_nonrigid.hip)
+int nonrigid_transform(prg_cpd* h);          // z4 = y + G W
+int nonrigid_free(prg_cpd* h);
+}  // namespace prg

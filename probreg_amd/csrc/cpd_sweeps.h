@@ -1,0 +1,18 @@
+// Launchers of the two E-step pair sweeps (see cpd.hip header comment).
+//   packed : explicit float2 (v_pk_*_f32) arithmetic, R = 2 or 4 points per lane
+//   scalar : one fp32 op per pair (translation unit built with -fno-slp-vectorize), for A/B
+//            comparison on hardware; selected by negative R in prg_cpd_set_tuning.
+#pragma once
+#include "cpd_plan.h"
+
+namespace prg {
+constexpr int kSweepBlock = 256;
+constexpr int kColChunk = 8;   // source points consumed per column-pass loop trip
+constexpr int kRowChunk = 4;   // target points consumed per row-pass loop trip
+constexpr int kOverRead = 8;   // points read past the end of the last segment (software prefetch)
+
+void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len);
+void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len);
+void launch_colpass_scalar(prg_cpd* h, int R, int S, int seg_len);
+void launch_rowpass_scalar(prg_cpd* h, int R, int S, int seg_len);
+}  // namespace prg

@@ -1,0 +1,175 @@
+// E-step pair sweeps, packed-fp32 form (CDNA4 v_pk_add/mul/fma_f32), MI355X gfx950.
+//
+// Both kernels follow one pattern: a lane OWNS R points of one cloud (registers) and the other
+// cloud is streamed through SGPRs: the stream pointer is wave-uniform and read-only, so each
+// 64-byte struct load becomes one s_load_dwordx16 (4 points) that is prefetched one trip ahead,
+// and every VALU instruction takes the streamed coordinate as a scalar (broadcast) operand - no
+// LDS traffic, no VGPRs for the streamed tile.  The M x N matrix P (cpd.py:74-84) never exists.
+#include <math.h>
+
+#include "cpd_sweeps.h"
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct alignas(64) Quad { float4 q[4]; };
+
+constexpr double kLog2e = 1.4426950408889634;
+constexpr int kBlock = prg::kSweepBlock;
+
+__device__ __forceinline__ f2 splat(float a) { return (f2){a, a}; }
+__device__ __forceinline__ f2 exp2v(f2 a) { return (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+__device__ __forceinline__ f2 fmav(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 minv(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
+
+// ---- sweep 1: den_n of cpd.py:80 as an online (min d^2, sum exp2(kk (d^2 - min))) pair ---------
+// grid = (ceil(N / (256 R)), S); block b.y streams source points [b.y*seg_len, +seg_len).
+template <int RP>
+__global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
+                                                    int seg_len, const double* __restrict__ params,
+                                                    float2* __restrict__ colpart, int64_t ncap) {
+    constexpr int R = 2 * RP;
+    const float kk = (float)(-kLog2e / (2.0 * params[13]));
+    const int64_t n0 = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
+    f2 x[RP], y[RP], z[RP], run[RP], s[RP];
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        const float4 a = tgt4[n0 + (2 * p) * kBlock], b = tgt4[n0 + (2 * p + 1) * kBlock];
+        x[p] = (f2){a.x, b.x};
+        y[p] = (f2){a.y, b.y};
+        z[p] = (f2){a.z, b.z};
+        run[p] = splat(INFINITY);
+        s[p] = splat(0.f);
+    }
+    const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + (int64_t)blockIdx.y * seg_len);
+    const int nq = seg_len >> 2;
+    Quad cur = zp[0];
+    for (int m = 0; m < nq; m += 2) {
+        const Quad nx0 = zp[m + 1];
+        f2 d2[8][RP];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const f2 dx = x[p] - splat(cur.q[c].x), dy = y[p] - splat(cur.q[c].y), dz = z[p] - splat(cur.q[c].z);
+                d2[c][p] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+            }
+        const Quad nx1 = zp[m + 2];  // prefetch for the next trip (pads make the over-read safe)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const f2 dx = x[p] - splat(nx0.q[c].x), dy = y[p] - splat(nx0.q[c].y), dz = z[p] - splat(nx0.q[c].z);
+                d2[4 + c][p] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+            }
+        cur = nx1;
+        bool lower = false;
+        f2 cm[RP];
+#pragma unroll
+        for (int p = 0; p < RP; ++p) {
+            f2 v = d2[0][p];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) v = minv(v, d2[c][p]);
+            cm[p] = v;
+            lower |= (v.x < run[p].x) | (v.y < run[p].y);
+        }
+        if (lower) {  // rare after the first trips: move the running sums to the new minimum
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const f2 nm = minv(run[p], cm[p]);
+                // first use: run == inf -> kk * inf = -inf -> exp2 = 0, and s == 0 anyway
+                s[p] *= exp2v(splat(kk) * (run[p] - nm));
+                run[p] = nm;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int p = 0; p < RP; ++p) s[p] += exp2v(splat(kk) * (d2[c][p] - run[p]));
+    }
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        colpart[(int64_t)blockIdx.y * ncap + n0 + (2 * p) * kBlock] = make_float2(run[p].x, s[p].x);
+        colpart[(int64_t)blockIdx.y * ncap + n0 + (2 * p + 1) * kBlock] = make_float2(run[p].y, s[p].y);
+    }
+}
+
+// ---- sweep 2: p1, px, and the sigma2 residual of cpd.py:84-87 in residual form ------------------
+// grid = (ceil(M / (256 R)), S); block b.y streams target points [b.y*seg_len, +seg_len) as
+// (x, y, z, b_n) with b_n = -log2(den_n + c), so P_mn = exp2(kk d2 + b_n) costs one FMA + one exp.
+// Output planes: rowpart[(seg*5 + comp) * Mcap + m], comp = p1, ux, uy, uz, e with
+// u = sum_n P (x_n - z_m), e = sum_n P |x_n - z_m|^2.
+template <int RP>
+__global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
+                                                    int seg_len, const double* __restrict__ params,
+                                                    float* __restrict__ rowpart, int64_t mcap) {
+    constexpr int R = 2 * RP;
+    const float kk = (float)(-kLog2e / (2.0 * params[13]));
+    const int64_t m0 = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
+    f2 zx[RP], zy[RP], zz[RP], p1[RP], ux[RP], uy[RP], uz[RP], e[RP];
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+        const float4 a = z4[m0 + (2 * p) * kBlock], b = z4[m0 + (2 * p + 1) * kBlock];
+        zx[p] = (f2){a.x, b.x};
+        zy[p] = (f2){a.y, b.y};
+        zz[p] = (f2){a.z, b.z};
+        p1[p] = ux[p] = uy[p] = uz[p] = e[p] = splat(0.f);
+    }
+    const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + (int64_t)blockIdx.y * seg_len);
+    const int nq = seg_len >> 2;
+    Quad cur = tp[0];
+    for (int n = 0; n < nq; ++n) {
+        const Quad nxt = tp[n + 1];  // prefetch
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const f2 dx = zx[p] - splat(cur.q[c].x), dy = zy[p] - splat(cur.q[c].y),
+                         dz = zz[p] - splat(cur.q[c].z);
+                const f2 d = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                const f2 pr = exp2v(fmav(d, splat(kk), splat(cur.q[c].w)));
+                p1[p] += pr;
+                ux[p] = fmav(pr, dx, ux[p]);
+                uy[p] = fmav(pr, dy, uy[p]);
+                uz[p] = fmav(pr, dz, uz[p]);
+                e[p] = fmav(pr, d, e[p]);
+            }
+        }
+        cur = nxt;
+    }
+    float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap;
+#pragma unroll
+    for (int p = 0; p < RP; ++p) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int64_t m = m0 + (2 * p + hh) * kBlock;
+            o[m] = p1[p][hh];
+            o[mcap + m] = -ux[p][hh];  // u = sum P (x - z) = -sum P (z - x)
+            o[2 * mcap + m] = -uy[p][hh];
+            o[3 * mcap + m] = -uz[p][hh];
+            o[4 * mcap + m] = e[p][hh];
+        }
+    }
+}
+
+}  // namespace
+
+namespace prg {
+
+void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len) {
+    dim3 grid((unsigned)ceil_div(h->N, kBlock * R), (unsigned)S);
+    if (R == 2)
+        k_colpass<1><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, seg_len, h->params, h->colpart, h->Ncap);
+    else
+        k_colpass<2><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, seg_len, h->params, h->colpart, h->Ncap);
+}
+
+void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len) {
+    dim3 grid((unsigned)ceil_div(h->M, kBlock * R), (unsigned)S);
+    if (R == 2)
+        k_rowpass<1><<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, seg_len, h->params, h->rowpart, h->Mcap);
+    else
+        k_rowpass<2><<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, seg_len, h->params, h->rowpart, h->Mcap);
+}
+
+}  // namespace prg

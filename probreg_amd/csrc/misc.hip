@@ -1,0 +1,241 @@
+// Error plumbing and the small stand-alone kernels of libprobreg_hip.so:
+//   prg_squared_kernel_sum     (probreg/math_utils.py:28-29 -> cc/math_utils.cc:5-15)
+//   prg_rbf_kernel             (probreg/math_utils.py:36-37 -> cc/math_utils.cc:17-19)
+//   prg_gauss_transform_direct (probreg/gauss_transform.py:10-25, 46-60)
+#include <math.h>
+#include <stdarg.h>
+
+#include "prg_common.h"
+
+namespace prg {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace prg
+
+namespace {
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// partial sums (sum x, sum y, sum z, sum |p|^2) in fp64 over a row-major n x dim float cloud
+__global__ __launch_bounds__(kBlock) void k_sums_rowmajor(const float* __restrict__ p, int64_t n, int dim,
+                                                          double* __restrict__ part) {
+    __shared__ double sh[4][4];
+    double a[4] = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        double x = p[i * dim], y = p[i * dim + 1], z = dim > 2 ? p[i * dim + 2] : 0.0;
+        a[0] += x; a[1] += y; a[2] += z;
+        a[3] += x * x + y * y + z * z;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double s = wave_sum(a[c]);
+        if (lane == 0) sh[wv][c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        part[(int64_t)blockIdx.x * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
+                                                     sh[3][threadIdx.x];
+}
+
+__global__ void k_sks_final(const double* __restrict__ px, int nbx, const double* __restrict__ py, int nby, double m,
+                            double n, int dim, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sx[4] = {0, 0, 0, 0}, sy[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nbx; ++b)
+        for (int c = 0; c < 4; ++c) sx[c] += px[b * 4 + c];
+    for (int b = 0; b < nby; ++b)
+        for (int c = 0; c < 4; ++c) sy[c] += py[b * 4 + c];
+    const double cross = sx[0] * sy[0] + sx[1] * sy[1] + sx[2] * sy[2];
+    out[0] = (n * sx[3] + m * sy[3] - 2.0 * cross) / (m * dim * n);
+}
+
+// K[i][j] = exp(-|x_i - y_j|^2 / (2 beta)), float32.  The squared distance is evaluated in
+// float32 without fused multiply-add, like the reference's Eigen expression
+// (cc/math_utils.cc:9-10), and the exponential in fp64 rounded once to float32.
+__global__ __launch_bounds__(kBlock) void k_rbf(const float* __restrict__ x, int64_t m, const float* __restrict__ y,
+                                                int64_t n, int dim, float two_beta, float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * 16;
+    if (j >= n) return;
+    const float yx = y[j * dim], yy = y[j * dim + 1], yz = dim > 2 ? y[j * dim + 2] : 0.f;
+    for (int64_t i = i0; i < i0 + 16 && i < m; ++i) {
+        const float dx = __fsub_rn(x[i * dim], yx), dy = __fsub_rn(x[i * dim + 1], yy),
+                    dz = dim > 2 ? __fsub_rn(x[i * dim + 2], yz) : 0.f;
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        const float arg = __fdiv_rn(-d2, two_beta);
+        out[i * n + j] = (float)exp((double)arg);
+    }
+}
+
+// out[c][i] = sum_j w[c][j] exp2(kk |t_i - s_j|^2); lane owns a target point, source streamed
+// through SGPRs as (x, y, z, w_c) float4; fp32 pair arithmetic, fp64 accumulation per 256-chunk.
+__global__ __launch_bounds__(kBlock) void k_gauss_direct(const float4* __restrict__ src4, int64_t s_cap,
+                                                         const float* __restrict__ tgt, int64_t t, int dim, float kk,
+                                                         double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (i < t) {
+        tx = tgt[i * dim];
+        ty = tgt[i * dim + 1];
+        tz = dim > 2 ? tgt[i * dim + 2] : 0.f;
+    }
+    double acc = 0.0;
+    for (int64_t j0 = 0; j0 < s_cap; j0 += 256) {
+        float part = 0.f;
+        for (int j = 0; j < 256; j += 4) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 q = src4[j0 + j + c];
+                const float dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
+                float d = dx * dx;
+                d = fmaf(dy, dy, d);
+                d = fmaf(dz, dz, d);
+                part = fmaf(q.w, __builtin_amdgcn_exp2f(kk * d), part);
+            }
+        }
+        acc += (double)part;
+    }
+    if (i < t) out[i] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_pack_weighted(const float* __restrict__ s, const double* __restrict__ w,
+                                                          int64_t n, int dim, int64_t cap,
+                                                          float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap) return;
+    float4 v;
+    if (i < n) {
+        v.x = s[i * dim];
+        v.y = s[i * dim + 1];
+        v.z = dim > 2 ? s[i * dim + 2] : 0.f;
+        v.w = (float)w[i];
+    } else {
+        v.x = v.y = v.z = prg::kSrcPad;
+        v.w = 0.f;
+    }
+    out[i] = v;
+}
+
+struct TmpBuf {
+    void* p = nullptr;
+    ~TmpBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* prg_last_error(void) { return prg::g_err; }
+
+int prg_version(void) { return 100; }
+
+int prg_device_count(int* count) {
+    PRG_REQUIRE(count != nullptr, PRG_ERR_INVALID, "prg_device_count: NULL argument");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        prg::set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return PRG_ERR_HIP;
+    }
+    return PRG_OK;
+}
+
+int prg_squared_kernel_sum(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd, int64_t n,
+                           int dim, double* out_host) {
+    PRG_REQUIRE(x_hd && y_hd && out_host, PRG_ERR_INVALID, "prg_squared_kernel_sum: NULL argument");
+    PRG_REQUIRE(m > 0 && n > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID,
+                "prg_squared_kernel_sum: need m, n > 0 and dim in {2,3}");
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_squared_kernel_sum: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nbx = (int)(prg::ceil_div(m, kBlock) < 256 ? prg::ceil_div(m, kBlock) : 256);
+    const int nby = (int)(prg::ceil_div(n, kBlock) < 256 ? prg::ceil_div(n, kBlock) : 256);
+    TmpBuf bx, by, bp;
+    PRG_HIP(hipMalloc(&bx.p, (size_t)m * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&by.p, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bp.p, (size_t)(nbx + nby) * 4 * sizeof(double) + sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(bx.p, x_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(by.p, y_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+    double* px = (double*)bp.p;
+    double* py = px + (size_t)nbx * 4;
+    double* res = py + (size_t)nby * 4;
+    k_sums_rowmajor<<<nbx, kBlock, 0, st>>>((const float*)bx.p, m, dim, px);
+    k_sums_rowmajor<<<nby, kBlock, 0, st>>>((const float*)by.p, n, dim, py);
+    k_sks_final<<<1, 64, 0, st>>>(px, nbx, py, nby, (double)m, (double)n, dim, res);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_host, res, sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+int prg_rbf_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd, int64_t n, int dim,
+                   double beta, float* out_hd) {
+    PRG_REQUIRE(x_hd && y_hd && out_hd, PRG_ERR_INVALID, "prg_rbf_kernel: NULL argument");
+    PRG_REQUIRE(m > 0 && n > 0 && (dim == 2 || dim == 3) && beta > 0, PRG_ERR_INVALID,
+                "prg_rbf_kernel: need m, n > 0, dim in {2,3}, beta > 0");
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_rbf_kernel: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    TmpBuf bx, by, bo;
+    PRG_HIP(hipMalloc(&bx.p, (size_t)m * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&by.p, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bo.p, (size_t)m * n * sizeof(float)));
+    PRG_HIP(hipMemcpyAsync(bx.p, x_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(by.p, y_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+    dim3 grid((unsigned)prg::ceil_div(n, kBlock), (unsigned)prg::ceil_div(m, 16));
+    k_rbf<<<grid, kBlock, 0, st>>>((const float*)bx.p, m, (const float*)by.p, n, dim, (float)(2.0 * beta),
+                                   (float*)bo.p);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_hd, bo.p, (size_t)m * n * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+int prg_gauss_transform_direct(int device, void* hip_stream, const float* source_hd, int64_t s, const float* target_hd,
+                               int64_t t, int dim, const double* weights_hd, int n_weight_rows, double h,
+                               double* out_hd) {
+    PRG_REQUIRE(source_hd && target_hd && weights_hd && out_hd, PRG_ERR_INVALID,
+                "prg_gauss_transform_direct: NULL argument");
+    PRG_REQUIRE(s > 0 && t > 0 && (dim == 2 || dim == 3) && n_weight_rows > 0 && h > 0, PRG_ERR_INVALID,
+                "prg_gauss_transform_direct: need s, t, rows > 0, dim in {2,3}, h > 0");
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_gauss_transform_direct: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int64_t cap = prg::round_up(s, 256);
+    TmpBuf bs, bt, bw, b4, bo;
+    PRG_HIP(hipMalloc(&bs.p, (size_t)s * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bt.p, (size_t)t * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bw.p, (size_t)s * n_weight_rows * sizeof(double)));
+    PRG_HIP(hipMalloc(&b4.p, (size_t)cap * sizeof(float4)));
+    PRG_HIP(hipMalloc(&bo.p, (size_t)t * n_weight_rows * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(bs.p, source_hd, (size_t)s * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bt.p, target_hd, (size_t)t * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bw.p, weights_hd, (size_t)s * n_weight_rows * sizeof(double), hipMemcpyDefault, st));
+    const float kk = (float)(-1.4426950408889634 / (h * h));
+    for (int c = 0; c < n_weight_rows; ++c) {
+        k_pack_weighted<<<(unsigned)prg::ceil_div(cap, kBlock), kBlock, 0, st>>>(
+            (const float*)bs.p, (const double*)bw.p + (size_t)c * s, s, dim, cap, (float4*)b4.p);
+        k_gauss_direct<<<(unsigned)prg::ceil_div(t, kBlock), kBlock, 0, st>>>(
+            (const float4*)b4.p, cap, (const float*)bt.p, t, dim, kk, (double*)bo.p + (size_t)c * t);
+    }
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_hd, bo.p, (size_t)t * n_weight_rows * sizeof(double), hipMemcpyDefault, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""Thin object wrapper over the ``prg_cpd_*`` C ABI (one plan = one GPU = one HIP stream).
+
+Device memory for the clouds and workspaces is owned by the library; PyTorch is used only to
+pick the device / stream of the current process and to give ``torch.distributed`` (RCCL) a
+tensor view of the 32-double moment block that is all-reduced once per EM iteration.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, ptr
+
+
+def _current_device_and_stream(device=None):
+    """(device index, hipStream_t as int) of the calling process; torch is optional plumbing."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            dev = torch.cuda.current_device() if device is None else int(device)
+            return dev, int(torch.cuda.current_stream(dev).cuda_stream)
+    except ImportError:  # pragma: no cover
+        pass
+    return (0 if device is None else int(device)), 0
+
+
+class CpdPlan(object):
+    """Owns one ``prg_cpd`` handle."""
+
+    def __init__(self, device=None, stream=None):
+        _lib.require_gpu()
+        dev, st = _current_device_and_stream(device)
+        if stream is not None:
+            st = int(stream)
+        self.device = dev
+        self.stream = st
+        self._h = ctypes.c_void_p()
+        check(lib.prg_cpd_create(ctypes.byref(self._h), dev, ctypes.c_void_p(st)))
+        self._moments_tensor = None
+        self.m = self.n = self.dim = 0
+
+    # -- life cycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.prg_cpd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    # -- uploads ----------------------------------------------------------------------------
+    @staticmethod
+    def _f32(a):
+        if hasattr(a, "data_ptr"):  # torch tensor, host or device
+            import torch
+
+            assert a.dtype == torch.float32 and a.is_contiguous()
+            return a
+        return np.ascontiguousarray(a, dtype=np.float32)
+
+    def set_source(self, source):
+        a = self._f32(source)
+        self.m, self.dim = int(a.shape[0]), int(a.shape[1])
+        check(lib.prg_cpd_set_source(self._h, ptr(a), self.m, self.dim))
+
+    def set_target(self, target_local, n_global=None):
+        a = self._f32(target_local)
+        self.n = int(a.shape[0])
+        check(lib.prg_cpd_set_target(self._h, ptr(a), self.n, int(a.shape[1]), int(n_global or self.n)))
+
+    def set_tuning(self, r_col=0, seg_col=0, r_row=0, seg_row=0):
+        check(lib.prg_cpd_set_tuning(self._h, r_col, seg_col, r_row, seg_row))
+
+    # -- moment block as a torch tensor (for RCCL all-reduce) --------------------------------
+    def moments_tensor(self):
+        """Allocate (once) a torch fp64 tensor on the plan's device and bind it as MOMENTS."""
+        if self._moments_tensor is None:
+            import torch
+
+            t = torch.zeros(_lib.PRG_NMOMENTS, dtype=torch.float64, device="cuda:%d" % self.device)
+            check(lib.prg_cpd_bind_moments(self._h, ctypes.c_void_p(t.data_ptr())))
+            self._moments_tensor = t
+        return self._moments_tensor
+
+    def rowacc_tensor_view(self):
+        """(device pointer, count) of the per-point fp64 E-step block (non-rigid all-reduce payload)."""
+        p = ctypes.c_void_p()
+        cnt = ctypes.c_int64()
+        check(lib.prg_cpd_rowacc_ptr(self._h, ctypes.byref(p), ctypes.byref(cnt)))
+        return p.value, int(cnt.value)
+
+    # -- EM pieces ----------------------------------------------------------------------------
+    def init_sums(self):
+        check(lib.prg_cpd_init_sums(self._h))
+
+    def init_params(self, init13=None):
+        if init13 is None:
+            check(lib.prg_cpd_init_params(self._h, None))
+        else:
+            a = np.ascontiguousarray(init13, dtype=np.float64)
+            assert a.size == 13
+            check(lib.prg_cpd_init_params(self._h, ptr(a)))
+
+    def estep(self, w=0.0):
+        check(lib.prg_cpd_estep(self._h, float(w)))
+
+    def mstep(self, kind, update_scale=True):
+        check(lib.prg_cpd_mstep(self._h, int(kind), 1 if update_scale else 0))
+
+    def mstep_nonrigid(self, lmd):
+        check(lib.prg_cpd_mstep_nonrigid(self._h, float(lmd)))
+
+    def get_params(self):
+        out = np.empty(_lib.PRG_NPARAMS, dtype=np.float64)
+        check(lib.prg_cpd_get_params(self._h, ptr(out)))
+        return out
+
+    def set_params(self, params):
+        a = np.ascontiguousarray(params, dtype=np.float64)
+        assert a.size == _lib.PRG_NPARAMS
+        check(lib.prg_cpd_set_params(self._h, ptr(a)))
+
+    def get_moments(self):
+        out = np.empty(_lib.PRG_NMOMENTS, dtype=np.float64)
+        check(lib.prg_cpd_get_moments(self._h, ptr(out)))
+        return out
+
+    def get_estep(self):
+        pt1 = np.empty(self.n, dtype=np.float64)
+        p1 = np.empty(self.m, dtype=np.float64)
+        px = np.empty((self.m, self.dim), dtype=np.float64)
+        check(lib.prg_cpd_get_estep(self._h, ptr(pt1), ptr(p1), ptr(px)))
+        return pt1, p1, px
+
+    def get_tsource(self):
+        out = np.empty((self.m, self.dim), dtype=np.float32)
+        check(lib.prg_cpd_get_tsource(self._h, ptr(out)))
+        return out
+
+    def moments_from_estep(self, pt1, p1, px):
+        pt1 = np.ascontiguousarray(pt1, dtype=np.float64)
+        p1 = np.ascontiguousarray(p1, dtype=np.float64)
+        px = np.ascontiguousarray(px, dtype=np.float64)
+        assert pt1.shape == (self.n,) and p1.shape == (self.m,) and px.shape == (self.m, self.dim)
+        check(lib.prg_cpd_moments_from_estep(self._h, ptr(pt1), ptr(p1), ptr(px)))
+
+    # -- non-rigid ----------------------------------------------------------------------------
+    def build_g(self, beta):
+        check(lib.prg_cpd_nonrigid_build_g(self._h, float(beta)))
+
+    def get_g(self):
+        out = np.empty((self.m, self.m), dtype=np.float32)
+        check(lib.prg_cpd_nonrigid_get_g(self._h, ptr(out)))
+        return out
+
+    def set_w(self, w):
+        a = np.ascontiguousarray(w, dtype=np.float64)
+        assert a.shape == (self.m, self.dim)
+        check(lib.prg_cpd_nonrigid_set_w(self._h, ptr(a)))
+
+    def get_w(self):
+        out = np.empty((self.m, self.dim), dtype=np.float64)
+        check(lib.prg_cpd_nonrigid_get_w(self._h, ptr(out)))
+        return out
+
+    def synchronize(self):
+        # a host read-back of the parameter block synchronises the plan's stream
+        self.get_params()

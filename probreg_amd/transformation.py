@@ -1,0 +1,92 @@
+"""Transformation result types of the registration API (reference probreg/transformation.py:17-102).
+
+These are small host-side value objects (a 3x3 matrix, a vector, an M x D weight matrix); the
+per-iteration transform of the *source cloud* inside the EM loop runs fused on the GPU
+(``k_transform_linear`` / ``k_gw`` in csrc/), not through these classes.
+"""
+import abc
+
+import numpy as np
+
+
+def _is_vector3d(points):
+    # open3d is optional: duck-type o3.utility.Vector3dVector (reference transformation.py:23-26)
+    return type(points).__name__ == "Vector3dVector"
+
+
+class Transformation(abc.ABC):
+    def __init__(self, xp=np):
+        self.xp = xp
+
+    def transform(self, points, array_type=None):
+        if _is_vector3d(points) or (array_type is not None and isinstance(points, array_type)):
+            return type(points)(self._transform(np.asarray(points)))
+        return self._transform(points)
+
+    @abc.abstractmethod
+    def _transform(self, points):
+        return points
+
+
+class RigidTransformation(Transformation):
+    """x -> scale * rot @ x + t   (reference transformation.py:33-60)."""
+
+    def __init__(self, rot=np.identity(3), t=np.zeros(3), scale=1.0, xp=np):
+        super(RigidTransformation, self).__init__(xp)
+        self.rot = rot
+        self.t = t
+        self.scale = scale
+
+    def _transform(self, points):
+        return self.scale * np.dot(points, self.rot.T) + self.t
+
+    def inverse(self):
+        return RigidTransformation(self.rot.T, -np.dot(self.rot.T, self.t) / self.scale, 1.0 / self.scale)
+
+    def __mul__(self, other):
+        return RigidTransformation(
+            np.dot(self.rot, other.rot), self.t + self.scale * np.dot(self.rot, other.t), self.scale * other.scale
+        )
+
+
+class AffineTransformation(Transformation):
+    """x -> b @ x + t   (reference transformation.py:63-78)."""
+
+    def __init__(self, b=np.identity(3), t=np.zeros(3), xp=np):
+        super(AffineTransformation, self).__init__(xp)
+        self.b = b
+        self.t = t
+
+    def _transform(self, points):
+        return np.dot(points, self.b.T) + self.t
+
+
+class NonRigidTransformation(Transformation):
+    """y_m -> y_m + (G W)_m on the control points it was built with (reference transformation.py:81-102).
+
+    ``g`` is the float32 Gaussian kernel matrix of the control points.  When the object comes out
+    of ``NonRigidCPD`` the matrix lives on the GPU; ``.g`` downloads it on first access (M*M*4 bytes).
+    """
+
+    def __init__(self, w, points, beta=2.0, xp=np, _plan=None):
+        super(NonRigidTransformation, self).__init__(xp)
+        self._points = np.asarray(points)
+        self._beta = beta
+        self._plan = _plan
+        self._g = None
+        self.w = w
+
+    @property
+    def g(self):
+        if self._g is None:
+            if self._plan is not None:
+                self._g = self._plan.get_g()
+            else:
+                from . import math_utils as mu
+
+                self._g = mu.rbf_kernel(self._points, self._points, self._beta)
+        return self._g
+
+    def _transform(self, points):
+        # same contract as the reference: ``points`` must be the control points the kernel was built on
+        return points + np.dot(self.g, self.w)

@@ -1,0 +1,146 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in this directory by running the REFERENCE's own code.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The unmodified reference modules are imported through ``oracle/ref_import.py`` (stub modules
+for open3d / the pybind extensions - see its docstring) and executed on deterministic inputs.
+Inputs and outputs are stored together so the tests never need the reference tree.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from probreg_amd import synthetic  # noqa: E402
+
+
+def rot_z(deg):
+    a = np.deg2rad(deg)
+    return np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+
+
+def load_pcd_ascii(path):
+    with open(path) as f:
+        lines = f.read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("DATA")) + 1
+    return np.array([[float(v) for v in l.split()[:3]] for l in lines[start:] if l.strip()])
+
+
+def run_cpd(ref, kind, src, tgt, w=0.0, maxiter=50, tol=0.001, **kw):
+    if kind == "rigid":
+        reg = ref.cpd.RigidCPD(src.copy(), **kw)
+    elif kind == "affine":
+        reg = ref.cpd.AffineCPD(src.copy(), **kw)
+    else:
+        reg = ref.cpd.NonRigidCPD(src.copy(), **kw)
+    niter = [0]
+    reg.set_callbacks([lambda t: niter.__setitem__(0, niter[0] + 1)])
+    res = reg.registration(tgt.copy(), w=w, maxiter=maxiter, tol=tol)
+    out = {"sigma2": res.sigma2, "q": res.q, "niter": niter[0]}
+    tr = res.transformation
+    if kind == "rigid":
+        out.update(rot=tr.rot, t=tr.t, scale=tr.scale)
+    elif kind == "affine":
+        out.update(b=tr.b, t=tr.t)
+    else:
+        out.update(w=tr.w, tsource=tr.transform(src))
+    return out
+
+
+def main():
+    ref = ref_import.load(with_filterreg=False)
+    cases = {}
+
+    def add(name, kind, src, tgt, **kw):
+        out = run_cpd(ref, kind, src, tgt, **kw)
+        entry = {"source": src, "target": tgt}
+        entry.update({"out_" + k: np.asarray(v) for k, v in out.items()})
+        for k, v in kw.items():
+            if isinstance(v, (int, float, bool)):
+                entry["arg_" + k] = np.asarray(v)
+        cases[name] = entry
+        print("%-32s niter=%3d sigma2=%.10e q=%.10e" % (name, out["niter"], out["sigma2"], out["q"]))
+
+    bunny = load_pcd_ascii(os.path.join(ref_import.REFERENCE_ROOT, "examples", "bunny.pcd"))
+    bunny_t = bunny @ rot_z(30.0).T
+    fish_s = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_source.txt"))
+    fish_t = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_target.txt"))
+
+    # C0 and friends: the reference's own fixtures, default arguments
+    add("bunny_rigid_default", "rigid", bunny, bunny_t)
+    add("bunny_affine_default", "affine", bunny, bunny_t)
+    add("bunny_nonrigid_default", "nonrigid", bunny, bunny_t)
+    add("bunny_nonrigid_k5", "nonrigid", bunny, bunny_t, maxiter=5, tol=-1.0)
+    add("bunny_rigid_noscale_w01_k10", "rigid", bunny, bunny_t, w=0.1, maxiter=10, tol=-1.0, update_scale=False)
+    add("fish_rigid_default", "rigid", fish_s, fish_t)
+    add("fish_affine_default", "affine", fish_s, fish_t)
+    add("fish_nonrigid_default", "nonrigid", fish_s, fish_t)
+
+    # synthetic C1 / C2 / C3 generators at oracle-sized N = M, fixed iteration counts (tol < 0)
+    s, t, _ = synthetic.rigid_pair(2000, seed=0)
+    for k in (1, 3, 10):
+        add("synth_rigid_2k_k%d" % k, "rigid", s, t, maxiter=k, tol=-1.0)
+    add("synth_rigid_2k_w02_k5", "rigid", s, t, w=0.2, maxiter=5, tol=-1.0)
+    s, t, _ = synthetic.affine_pair(2000, seed=3)
+    for k in (1, 10):
+        add("synth_affine_2k_k%d" % k, "affine", s, t, maxiter=k, tol=-1.0)
+    s, t = synthetic.nonrigid_pair(1000, seed=5)
+    for k in (1, 5):
+        add("synth_nonrigid_1k_k%d" % k, "nonrigid", s, t, maxiter=k, tol=-1.0)
+    s, t, _ = synthetic.rigid_pair(1500, m=700, seed=7)  # N != M
+    add("synth_rigid_ragged_k6", "rigid", s, t, maxiter=6, tol=-1.0)
+
+    # single E-step calls (cpd.py:71-88), incl. a dead column: one target point so far away that every
+    # fp64 exp() underflows, which exercises the den == 0 -> eps32 rule (cpd.py:81)
+    cpd_obj = ref.cpd.RigidCPD(bunny.copy())
+    est = {}
+    tsrc = bunny @ rot_z(5.0).T
+    far = bunny_t.copy()
+    far[17] = far[17] + np.array([3.0, -2.0, 1.0])
+    for name, (a, b, s2, w) in {
+        "bunny_s2_1e-3_w0": (tsrc, bunny_t, 1.0e-3, 0.0),
+        "bunny_s2_1e-4_w03": (tsrc, bunny_t, 1.0e-4, 0.3),
+        "bunny_dead_column_w0": (tsrc, far, 2.0e-3, 0.0),
+        "bunny_dead_column_w01": (tsrc, far, 2.0e-3, 0.1),
+        "fish2d_s2_5e-2_w0": (fish_s, fish_t, 5.0e-2, 0.0),
+    }.items():
+        r = cpd_obj.expectation_step(a, b, s2, w)
+        est[name] = dict(t_source=a, target=b, sigma2=np.asarray(s2), w=np.asarray(w), pt1=r.pt1, p1=r.p1, px=r.px,
+                         n_p=np.asarray(r.n_p))
+        print("estep %-28s n_p=%.12e min(pt1)=%.3e" % (name, r.n_p, r.pt1.min()))
+
+    # the reference's unit-test vectors (tests/test_math_utils.py:7-16) + sigma2 initialiser on bunny
+    x15 = np.arange(15, dtype=np.float64).reshape(5, 3)
+    misc = {
+        "x15": x15,
+        "sks_x15": np.asarray(ref.math_utils.squared_kernel_sum(x15, x15)),
+        "rbf_x15_beta1": ref.math_utils.rbf_kernel(x15 * 0.1, x15 * 0.1, 1.0),
+        "sks_bunny": np.asarray(ref.math_utils.squared_kernel_sum(bunny, bunny_t)),
+        "rbf_fish_beta2": ref.math_utils.rbf_kernel(fish_s, fish_s, 2.0),
+    }
+    print("sks_x15 = %.10e   sks_bunny = %.10e" % (misc["sks_x15"], misc["sks_bunny"]))
+
+    flat = {}
+    for cname, entry in cases.items():
+        for k, v in entry.items():
+            flat["reg/%s/%s" % (cname, k)] = v
+    for cname, entry in est.items():
+        for k, v in entry.items():
+            flat["estep/%s/%s" % (cname, k)] = v
+    for k, v in misc.items():
+        flat["misc/%s" % k] = v
+    out = os.path.join(HERE, "cpd_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
+if __name__ == "__main__":
+    main()

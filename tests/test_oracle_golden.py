@@ -1,0 +1,93 @@
+"""The numpy oracle (oracle/cpd_numpy.py) against fixtures produced by the reference's own code
+(tests/golden/make_golden.py).  CPU only.  This is what pins the oracle."""
+import numpy as np
+import pytest
+
+from oracle import cpd_numpy as co
+from conftest import rel_err
+
+REG_CASES = [
+    "bunny_rigid_default", "bunny_affine_default", "bunny_nonrigid_default", "bunny_nonrigid_k5",
+    "bunny_rigid_noscale_w01_k10", "fish_rigid_default", "fish_affine_default", "fish_nonrigid_default",
+    "synth_rigid_2k_k1", "synth_rigid_2k_k3", "synth_rigid_2k_k10", "synth_rigid_2k_w02_k5",
+    "synth_affine_2k_k1", "synth_affine_2k_k10", "synth_nonrigid_1k_k1", "synth_nonrigid_1k_k5",
+    "synth_rigid_ragged_k6",
+]
+
+
+def _kind(name):
+    return "nonrigid" if "nonrigid" in name else ("affine" if "affine" in name else "rigid")
+
+
+@pytest.mark.parametrize("name", REG_CASES)
+def test_registration_matches_reference(cpd_golden, name):
+    c = cpd_golden.case("reg/" + name)
+    kind = _kind(name)
+    kw = {}
+    for k in ("w", "maxiter", "tol", "update_scale"):
+        if "arg_" + k in c:
+            kw[k] = c["arg_" + k]
+    if "maxiter" in kw:
+        kw["maxiter"] = int(kw["maxiter"])
+    params, sigma2, q, niter = co.registration(kind, c["source"], c["target"], **kw)
+    assert niter == c["out_niter"]
+    # sigma2: the only difference is the fp32 summation order inside the sigma2 initialiser (~1e-8)
+    assert abs(sigma2 - c["out_sigma2"]) <= 2e-7 * abs(c["out_sigma2"])
+    if kind == "rigid":
+        assert rel_err(params["rot"], c["out_rot"]) < 1e-7
+        assert np.max(np.abs(params["t"] - c["out_t"])) < 1e-7
+        assert abs(params["scale"] - c["out_scale"]) < 1e-7
+    elif kind == "affine":
+        assert rel_err(params["b"], c["out_b"]) < 1e-7
+        assert np.max(np.abs(params["t"] - c["out_t"])) < 1e-7
+    else:
+        g = co.rbf_kernel(c["source"], c["source"], 2.0)
+        ts = co.transform("nonrigid", params, c["source"], g)
+        assert rel_err(ts, c["out_tsource"]) < 1e-6
+    if c["out_sigma2"] > 2e-7:  # q is ill-conditioned once sigma2 sits on the eps32 clamp
+        assert abs(q - c["out_q"]) <= 1e-6 * abs(c["out_q"])
+
+
+@pytest.mark.parametrize("chunk", [64, 1024])
+def test_estep_matches_reference(cpd_golden, chunk):
+    for name in cpd_golden.group("estep"):
+        c = cpd_golden.case("estep/" + name)
+        es = co.expectation_step(c["t_source"], c["target"], c["sigma2"], c["w"], chunk=chunk)
+        assert np.max(np.abs(es.pt1 - c["pt1"])) < 1e-12, name
+        assert rel_err(es.p1, c["p1"]) < 1e-12, name
+        assert rel_err(es.px, c["px"]) < 1e-12, name
+        assert abs(es.n_p - c["n_p"]) < 1e-9, name
+
+
+def test_dead_column_rule(cpd_golden):
+    # cpd.py:81: a column whose every fp64 exp() underflowed gets den = eps32 -> P column == 0
+    c = cpd_golden.case("estep/bunny_dead_column_w0")
+    assert c["pt1"].min() == 0.0
+    assert abs(c["n_p"] - (c["target"].shape[0] - 1)) < 1e-9
+
+
+def test_math_utils_vectors(cpd_golden):
+    m = cpd_golden.case("misc")
+    x = m["x15"]
+    # reference tests/test_math_utils.py:7-11
+    brute = sum(np.sum((x[i] - x[j]) ** 2) for i in range(5) for j in range(5)) / (5 * 3 * 5)
+    assert abs(m["sks_x15"] - brute) < 1e-6
+    assert abs(co.squared_kernel_sum(x, x) - m["sks_x15"]) < 1e-6
+    assert abs(co.squared_kernel_sum_closed_form(x, x) - m["sks_x15"]) < 1e-6
+    g = co.rbf_kernel(x * 0.1, x * 0.1, 1.0)
+    assert np.allclose(g, g.T)  # tests/test_math_utils.py:13-16
+    assert np.max(np.abs(g - m["rbf_x15_beta1"])) < 1e-7
+
+
+def test_moment_form_equals_direct_mstep(cpd_golden):
+    c = cpd_golden.case("reg/synth_rigid_2k_k1")
+    src, tgt = c["source"], c["target"]
+    s2 = co.squared_kernel_sum(src, tgt)
+    es = co.expectation_step(src, tgt, s2, 0.0)
+    mom = co.moments_from_estep(src, tgt, es)
+    for kind, direct in (("rigid", co.mstep_rigid(src, tgt, es)), ("affine", co.mstep_affine(src, tgt, es))):
+        via = co.mstep_from_moments(kind, mom, 3)
+        assert abs(via.sigma2 - direct.sigma2) < 1e-12 * abs(direct.sigma2) + 1e-15
+        assert abs(via.q - direct.q) < 1e-9 * abs(direct.q)
+        for k in direct.params:
+            assert np.max(np.abs(np.asarray(via.params[k]) - np.asarray(direct.params[k]))) < 1e-10
