@@ -106,6 +106,11 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host);
  * Replaces: CoherentPointDrift.expectation_step, cpd.py:71-88. */
 int prg_cpd_estep(prg_cpd* h, double w);
 
+/* Same E-step with HIP events recorded on the plan's stream between its kernels.
+ * ms_out[0..4] = transform, column pass, column finalise, row pass, moment reduction; ms_out[5] = total.
+ * (measurement hook for bench.py's `roofline` object; synchronises the stream) */
+int prg_cpd_estep_timed(prg_cpd* h, double w, float* ms_out);
+
 /* M-step from (all-reduced) MOMENTS into PARAMS; identical on every rank.
  * Replaces: RigidCPD._maximization_step cpd.py:160-192 (update_scale as there) and
  * AffineCPD._maximization_step cpd.py:219-244. */
@@ -142,6 +147,9 @@ int prg_cpd_nonrigid_get_g(prg_cpd* h, float* g_hd);
 /* Set / get W (m x dim float64).  W = 0 after build_g (cpd.py:281). */
 int prg_cpd_nonrigid_set_w(prg_cpd* h, const double* w_hd);
 int prg_cpd_nonrigid_get_w(prg_cpd* h, double* w_hd);
+/* T = Y + G W for the current W (m x dim float64): NonRigidTransformation._transform on the control
+ * points, transformation.py:101-102. */
+int prg_cpd_nonrigid_apply(prg_cpd* h, double* t_hd);
 /* Device address of the per-point E-step block (4*m doubles: p1[m], px0[m], px1[m], px2[m])
  * followed by MOMENTS-style scalars; this is the non-rigid all-reduce payload. */
 int prg_cpd_rowacc_ptr(prg_cpd* h, double** rowacc_dev, int64_t* count);

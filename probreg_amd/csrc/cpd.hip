@@ -744,7 +744,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     return PRG_OK;
 }
 
-int prg_cpd_estep(prg_cpd* h, double w) {
+static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_REQUIRE(h && h->have_source && h->have_target, PRG_ERR_STATE, "prg_cpd_estep: clouds not set");
     PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_cpd_estep: w must be in [0, 1) (got %g)", w);
     prg::DeviceGuard g(h->device);
@@ -765,22 +765,52 @@ int prg_cpd_estep(prg_cpd* h, double w) {
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)SB * 5 * h->Mcap));
     PRG_TRY(ensure_mompart(h));
 
+    if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
     if (h->nonrigid)
         PRG_TRY(prg::nonrigid_transform(h));
     else
         k_transform_linear<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->Mcap, h->params);
+    if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (ra < 0) prg::launch_colpass_scalar(h, RA, SA, segA); else prg::launch_colpass_packed(h, RA, SA, segA);
+    if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       (double)h->M / (double)h->Nglobal, h->D);
+    if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (rb < 0) prg::launch_rowpass_scalar(h, RB, SB, segB); else prg::launch_rowpass_packed(h, RB, SB, segB);
+    if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
     const int nblk = (int)prg::ceil_div(h->M, kBlock);
     k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart);
     k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
+    if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());
     h->have_estep = true;
     h->last_w = w;
     return PRG_OK;
+}
+
+
+int prg_cpd_estep(prg_cpd* h, double w) { return estep_impl(h, w, nullptr); }
+
+int prg_cpd_estep_timed(prg_cpd* h, double w, float* ms_out) {
+    PRG_REQUIRE(h && ms_out, PRG_ERR_INVALID, "prg_cpd_estep_timed: NULL argument");
+    prg::DeviceGuard g(h->device);
+    hipEvent_t ev[6];
+    for (int i = 0; i < 6; ++i) PRG_HIP(hipEventCreate(&ev[i]));
+    int st = estep_impl(h, w, ev);
+    if (st == PRG_OK) {
+        hipError_t e = hipEventSynchronize(ev[5]);
+        if (e != hipSuccess) {
+            prg::set_error("prg_cpd_estep_timed: hipEventSynchronize failed: %s", hipGetErrorString(e));
+            st = PRG_ERR_HIP;
+        }
+    }
+    if (st == PRG_OK) {
+        for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&ms_out[i], ev[i], ev[i + 1]);
+        (void)hipEventElapsedTime(&ms_out[5], ev[0], ev[5]);
+    }
+    for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
+    return st;
 }
 
 int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {

@@ -208,3 +208,27 @@ int prg_cpd_rowacc_ptr(prg_cpd* h, double** rowacc_dev, int64_t* count) {
 }
 
 }  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(kBlock) void k_apply_out(const float4* __restrict__ src4, const double* __restrict__ gw,
+                                                      int64_t m, int dim, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const float4 y = src4[i];
+    const double yy[3] = {y.x, y.y, y.z};
+    for (int k = 0; k < dim; ++k) out[i * dim + k] = yy[k] + gw[i * 3 + k];
+}
+}  // namespace
+
+extern "C" int prg_cpd_nonrigid_apply(prg_cpd* h, double* t_hd) {
+    PRG_REQUIRE(h && h->G && h->W && t_hd, PRG_ERR_STATE, "prg_cpd_nonrigid_apply: G has not been built");
+    prg::DeviceGuard g(h->device);
+    double* gw = h->nr_work;
+    k_gw<<<(unsigned)prg::ceil_div(h->M, kGwRows), kBlock, 0, h->stream>>>(h->G, h->M, h->W, gw);
+    PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(double)));
+    k_apply_out<<<grid1(h->M), kBlock, 0, h->stream>>>(h->src4, gw, h->M, h->D, (double*)h->stage);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(t_hd, h->stage, (size_t)h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}

@@ -108,6 +108,13 @@ class CpdPlan(object):
     def estep(self, w=0.0):
         check(lib.prg_cpd_estep(self._h, float(w)))
 
+    def estep_timed(self, w=0.0):
+        """E-step with per-kernel HIP-event timing: dict of milliseconds (see prg_cpd_estep_timed)."""
+        ms = np.zeros(6, dtype=np.float32)
+        check(lib.prg_cpd_estep_timed(self._h, float(w), ptr(ms)))
+        names = ("transform", "colpass", "colfinal", "rowpass", "moments", "total")
+        return dict(zip(names, [float(v) for v in ms]))
+
     def mstep(self, kind, update_scale=True):
         check(lib.prg_cpd_mstep(self._h, int(kind), 1 if update_scale else 0))
 
@@ -165,6 +172,11 @@ class CpdPlan(object):
     def get_w(self):
         out = np.empty((self.m, self.dim), dtype=np.float64)
         check(lib.prg_cpd_nonrigid_get_w(self._h, ptr(out)))
+        return out
+
+    def nonrigid_apply(self):
+        out = np.empty((self.m, self.dim), dtype=np.float64)
+        check(lib.prg_cpd_nonrigid_apply(self._h, ptr(out)))
         return out
 
     def synchronize(self):

@@ -1,0 +1,83 @@
+"""Host-side logic that needs no GPU: sharding, parameter-block algebra, API surface."""
+import inspect
+
+import numpy as np
+import pytest
+
+from probreg_amd import cpd, dist, synthetic, transformation as tf
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (1, 7, 8, 100000, 200001):
+        for world in (1, 2, 3, 8):
+            if n < world:
+                continue
+            spans = [dist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans[:-1], spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        dist.shard_bounds(10, 3, 2)
+
+
+def test_world_without_init():
+    assert dist.world() == (0, 1)
+
+
+def test_params_block_and_centring_roundtrip():
+    rng = np.random.default_rng(1)
+    rot = synthetic.rot_zx(25.0, -10.0)
+    t = rng.normal(size=3)
+    s = 1.3
+    cy, cx = rng.normal(size=3), rng.normal(size=3)
+    y = rng.normal(size=(50, 3))
+    # the centred-frame translation used by RigidCPD._initialize / _result_from_params
+    t_c = t + s * rot @ cy - cx
+    z_centred = s * (y - cy) @ rot.T + t_c
+    z = s * y @ rot.T + t
+    assert np.allclose(z_centred + cx, z)
+    blk = cpd._params_block(rot[:2, :2], t[:2], s, 2)
+    assert blk.shape == (13,) and blk[8] == 1.0 and blk[12] == s and blk[11] == 0.0
+
+
+def test_api_surface_matches_reference_names():
+    sig = inspect.signature(cpd.registration_cpd)
+    assert list(sig.parameters)[:8] == ["source", "target", "tf_type_name", "w", "maxiter", "tol", "callbacks",
+                                        "use_cuda"]
+    assert sig.parameters["maxiter"].default == 50 and sig.parameters["tol"].default == 0.001
+    assert cpd.EstepResult._fields == ("pt1", "p1", "px", "n_p")
+    assert cpd.MstepResult._fields == ("transformation", "sigma2", "q")
+    for cls in (cpd.RigidCPD, cpd.AffineCPD, cpd.NonRigidCPD):
+        for meth in ("set_source", "set_callbacks", "expectation_step", "maximization_step", "registration"):
+            assert hasattr(cls, meth)
+    assert list(inspect.signature(cpd.RigidCPD.__init__).parameters)[1:5] == ["source", "update_scale",
+                                                                             "tf_init_params", "use_cuda"]
+    assert list(inspect.signature(cpd.NonRigidCPD.__init__).parameters)[1:5] == ["source", "beta", "lmd", "use_cuda"]
+
+
+def test_unknown_type_raises_value_error():
+    x = np.zeros((4, 3))
+    with pytest.raises(ValueError):
+        cpd.registration_cpd(x, x, "projective")
+
+
+def test_transformations_are_plain_value_objects():
+    rot = synthetic.rot_zx(30.0, 0.0)
+    r = tf.RigidTransformation(rot, np.array([1.0, 2.0, 3.0]), 2.0)
+    p = np.array([[1.0, 0.0, 0.0]])
+    assert np.allclose(r.transform(p), 2.0 * p @ rot.T + [1.0, 2.0, 3.0])
+    inv = r.inverse()
+    assert np.allclose(inv.transform(r.transform(p)), p)
+    a = tf.AffineTransformation(np.diag([1.0, 2.0, 3.0]), np.ones(3))
+    assert np.allclose(a.transform(p), [[2.0, 1.0, 1.0]])
+
+
+def test_synthetic_generators_are_seeded():
+    a, b, _ = synthetic.rigid_pair(100, seed=3)
+    a2, b2, _ = synthetic.rigid_pair(100, seed=3)
+    assert np.array_equal(a, a2) and np.array_equal(b, b2)
+    assert a.shape == (100, 3) and np.array_equal(a, a.astype(np.float32).astype(np.float64))
+    s, t, _ = synthetic.filterreg_pair(1000, seed=1)
+    assert t.shape == (1000, 3)
