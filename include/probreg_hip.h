@@ -93,8 +93,10 @@ int prg_cpd_params_ptr(prg_cpd* h, double** params_dev);
  * Replaces: mu.squared_kernel_sum, math_utils.py:28-29 -> cc/math_utils.cc:5-15
  * (closed form, never materialises M x N). All-reduce MOMENTS between step 1 and 2. */
 int prg_cpd_init_sums(prg_cpd* h);
-/* step 2: sigma2_0 and q0 = 1 + N*D/2*log(sigma2_0) into PARAMS, linear part and t from
- * `init_params_host` (12 doubles + scale, NULL = identity / zero / 1).
+/* step 2: sigma2_0 and q0 = 1 + N*D/2*log(sigma2_0) into PARAMS.  `init_params_host` (NULL = identity,
+ * zero, 1, zero) holds 16 doubles: [0..8] linear part, [9..11] t, [12] scale, [13..15] delta =
+ * origin_target - origin_source when the caller subtracted different origins from the two uploaded
+ * clouds (sigma2_0 is a mean squared source-target distance and is not invariant to that).
  * Replaces: RigidCPD._initialize cpd.py:145-153, AffineCPD._initialize :209-217,
  * NonRigidCPD._initialize :277-282. */
 int prg_cpd_init_params(prg_cpd* h, const double* init_params_host);

@@ -40,13 +40,15 @@ def _as_points(x):
     return np.asarray(x, dtype=np.float64)
 
 
-def _params_block(linear, t, scale, dim):
-    p = np.zeros(13)
+def _params_block(linear, t, scale, dim, delta=None):
+    p = np.zeros(16)
     lin = np.identity(3)
     lin[:dim, :dim] = np.asarray(linear, dtype=np.float64)
     p[:9] = lin.ravel()
     p[9:9 + dim] = np.asarray(t, dtype=np.float64)
     p[12] = scale
+    if delta is not None:
+        p[13:13 + dim] = np.asarray(delta, dtype=np.float64)
     return p
 
 
@@ -93,7 +95,7 @@ class CoherentPointDrift(abc.ABC):
             plan.set_target(target - c)
             p = np.zeros(_lib.PRG_NPARAMS)
             p[:13] = _params_block(np.identity(t_source.shape[1]), np.zeros(t_source.shape[1]), 1.0,
-                                   t_source.shape[1])
+                                   t_source.shape[1])[:13]
             p[13] = sigma2
             plan.set_params(p)
             plan.estep(w)
@@ -210,7 +212,7 @@ class RigidCPD(CoherentPointDrift):
         scale = float(ip.get("scale", 1.0))
         # centred frame: z - cx = s R (y - cy) + t'  with  t' = t + s R cy - cx
         t_c = t + scale * rot @ self._cy - self._cx
-        plan.init_params(_params_block(rot, t_c, scale, dim))
+        plan.init_params(_params_block(rot, t_c, scale, dim, self._cx - self._cy))
         return self._result_from_params(plan.get_params())
 
     def _device_mstep(self, plan):
@@ -249,7 +251,7 @@ class AffineCPD(CoherentPointDrift):
         b = np.asarray(ip.get("b", np.identity(dim)), dtype=np.float64)
         t = np.asarray(ip.get("t", np.zeros(dim)), dtype=np.float64)
         t_c = t + b @ self._cy - self._cx
-        plan.init_params(_params_block(b, t_c, 1.0, dim))
+        plan.init_params(_params_block(b, t_c, 1.0, dim, self._cx - self._cy))
         return self._result_from_params(plan.get_params())
 
     def _device_mstep(self, plan):

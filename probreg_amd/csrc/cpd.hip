@@ -101,11 +101,23 @@ __global__ void k_zero_doubles(double* p, int n) {
 // q0 = 1 + N D / 2 log(sigma2_0)                                           (cpd.py:148)
 __global__ void k_init_params(const double* __restrict__ moments, const double* __restrict__ srcsum,
                               double* __restrict__ params, double m, double nglobal, int dim,
-                              const double* __restrict__ init /* 13 doubles or null */) {
+                              const double* __restrict__ init /* 16 doubles or null */) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double* ts = moments + 24;
     double cross = ts[0] * srcsum[0] + ts[1] * srcsum[1] + ts[2] * srcsum[2];
-    double sigma2 = (m * ts[3] + nglobal * srcsum[3] - 2.0 * cross) / (dim * m * nglobal);
+    double total = m * ts[3] + nglobal * srcsum[3] - 2.0 * cross;
+    if (init) {
+        // the caller subtracted different origins from the two clouds (delta = origin_target - origin_source):
+        // sum |x' - y' + delta|^2 = sum |x' - y'|^2 + 2 delta.(M sum x' - N sum y') + M N |delta|^2
+        const double* dl = init + 13;
+        double lin = 0.0, d2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            lin += dl[k] * (m * ts[k] - nglobal * srcsum[k]);
+            d2 += dl[k] * dl[k];
+        }
+        total += 2.0 * lin + m * nglobal * d2;
+    }
+    double sigma2 = total / (dim * m * nglobal);
     for (int i = 0; i < PRG_NPARAMS; ++i) params[i] = 0.0;
     if (init) {
         for (int i = 0; i < 13; ++i) params[i] = init[i];
@@ -733,7 +745,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     double* init_dev = nullptr;
     if (init_params_host) {
         init_dev = srcsum + 8;
-        PRG_HIP(hipMemcpyAsync(init_dev, init_params_host, 13 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        PRG_HIP(hipMemcpyAsync(init_dev, init_params_host, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     k_cloud_sums<<<nblk, kBlock, 0, h->stream>>>(h->src4, h->M, h->mompart);
     k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, 4, srcsum, 0);

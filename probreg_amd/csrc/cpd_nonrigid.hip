@@ -135,7 +135,17 @@ int nonrigid_transform(prg_cpd* h) {
     return PRG_OK;
 }
 
+int nonrigid_gw(prg_cpd* h, const double* w3, double* out3) {
+    PRG_REQUIRE(h->G, PRG_ERR_STATE, "non-rigid: G has not been built");
+    k_gw<<<(unsigned)prg::ceil_div(h->M, kGwRows), kBlock, 0, h->stream>>>(h->G, h->M, w3, out3);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
 int nonrigid_free(prg_cpd* h) {
+    if (h->nr_solve) (void)hipFree(h->nr_solve);
+    h->nr_solve = nullptr;
+    h->nr_solve_bytes = 0;
     if (h->G) (void)hipFree(h->G);
     if (h->W) (void)hipFree(h->W);
     if (h->nr_work) (void)hipFree(h->nr_work);

@@ -1,7 +1,405 @@
-// placeholder, replaced below
+// Non-rigid CPD M-step on MI355X (gfx950): dense fp64 solve on the f64 matrix cores.
+//
+// Reference (neka-nat/probreg v0.3.7, probreg/cpd.py:284-303):
+//     W = solve(diag(p1) G + lmd*sigma2_prev*I,  px - diag(p1) Y)        (LAPACK gesv, float64)
+//     T = Y + G W ;  sigma2 = (tr(X^T diag(pt1) X) - 2 tr(px^T T) + tr(T^T diag(p1) T)) / (n_p D)
+//
+// The system matrix A = D G + c I (D = diag(p1), c = lmd*sigma2_prev) is not symmetric, but with
+// U = D^1/2 and V = D^1/2 G the push-through identity
+//     (c I + U V)^-1 = (1/c) (I - U (c I + V U)^-1 V)
+// turns it into one SPD system in S = c I + D^1/2 G D^1/2 (eigenvalues >= c > 0, legal for p1 >= 0):
+//     W = (B - D^1/2 S^-1 D^1/2 (G B)) / c ,   B = px - D Y.
+// S is factored by a right-looking blocked Cholesky (NB = 128) whose trailing update and panel
+// solve are NT-GEMMs on v_mfma_f64_16x16x4_f64; everything is fp64 because cond(S) reaches 1e7-1e8
+// (c ~ 1e-3, lambda_max(G) ~ M) which rules out an fp32 factorisation at the 1e-4 parity target.
+#include <math.h>
+
 #include "cpd_plan.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int NB = 128;          // Cholesky block size == GEMM tile edge
+constexpr int LDP = NB + 1;      // padded LDS row stride (doubles)
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---- right-hand side and S --------------------------------------------------------------------
+// B = px - p1 * y   (cpd.py:296, right-hand side), rows >= m zero.  sp = sqrt(p1).
+__global__ __launch_bounds__(kBlock) void k_rhs(const double* __restrict__ rowacc, int64_t mcap,
+                                                const float4* __restrict__ src4, int64_t m, int64_t mp,
+                                                double* __restrict__ b3, double* __restrict__ sp) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= mp) return;
+    if (i < m) {
+        const double p1 = rowacc[i];
+        const float4 y = src4[i];
+        b3[i * 3 + 0] = rowacc[mcap + i] - p1 * (double)y.x;
+        b3[i * 3 + 1] = rowacc[2 * mcap + i] - p1 * (double)y.y;
+        b3[i * 3 + 2] = rowacc[3 * mcap + i] - p1 * (double)y.z;
+        sp[i] = sqrt(fmax(p1, 0.0));
+    } else {
+        b3[i * 3] = b3[i * 3 + 1] = b3[i * 3 + 2] = 0.0;
+        sp[i] = 0.0;
+    }
+}
+
+// S = c I + diag(sp) G diag(sp) on the lower 128-tiles (diagonal tiles full); identity in the pad.
+__global__ __launch_bounds__(kBlock) void k_build_s(const float* __restrict__ g, int64_t m, int64_t mp,
+                                                    const double* __restrict__ sp, const double* __restrict__ params,
+                                                    double lmd, double* __restrict__ s) {
+    const int by = blockIdx.y, bx = blockIdx.x;
+    if (bx > by) return;
+    const double c = lmd * params[13];
+    const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;  // 128 columns x 2 rows per pass
+    const int64_t j = (int64_t)bx * NB + tx;
+    const double spj = j < m ? sp[j] : 0.0;
+    for (int r = ty; r < NB; r += 2) {
+        const int64_t i = (int64_t)by * NB + r;
+        double v;
+        if (i < m && j < m)
+            v = sp[i] * (double)g[i * m + j] * spj + (i == j ? c : 0.0);
+        else
+            v = (i == j) ? 1.0 : 0.0;
+        s[i * mp + j] = v;
+    }
+}
+
+// ---- diagonal block: Cholesky + triangular inverse in LDS ---------------------------------------
+// One workgroup.  a = S[k0:k0+128, k0:k0+128] -> L (written back, lower) and L^-1 (to linv, full 128x128
+// with an explicit zero upper triangle, row-major).
+__global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, int64_t ld, int64_t k0,
+                                                      double* __restrict__ linv, int* __restrict__ info) {
+    extern __shared__ double a[];  // [NB][LDP]
+    const int tid = threadIdx.x;
+    double* sblk = s + k0 * ld + k0;
+    for (int idx = tid; idx < NB * NB; idx += kBlock) {
+        const int i = idx >> 7, j = idx & 127;
+        a[i * LDP + j] = sblk[(int64_t)i * ld + j];
+    }
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int j = 0; j < NB; ++j) {
+        __syncthreads();
+        const double ajj = a[j * LDP + j];
+        if (!(ajj > 0.0) && tid == 0) atomicMax(info, (int)(k0 + j + 1));
+        const double d = sqrt(fabs(ajj) > 0.0 ? fabs(ajj) : 1.0);
+        const double rd = 1.0 / d;
+        __syncthreads();
+        if (tid == 0) a[j * LDP + j] = d;
+        for (int i = j + 1 + tid; i < NB; i += kBlock) a[i * LDP + j] *= rd;
+        __syncthreads();
+        for (int i = j + 1 + ty; i < NB; i += 16) {
+            const double aij = a[i * LDP + j];
+            for (int k = j + 1 + tx; k <= i; k += 16) a[i * LDP + k] -= aij * a[k * LDP + j];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NB * NB; idx += kBlock) {
+        const int i = idx >> 7, j = idx & 127;
+        if (j <= i) sblk[(int64_t)i * ld + j] = a[i * LDP + j];
+    }
+    // in-place inverse of the lower triangle (column j uses the already inverted trailing block)
+    for (int j = NB - 1; j >= 0; --j) {
+        __syncthreads();
+        const double ajj = 1.0 / a[j * LDP + j];
+        double t = 0.0;
+        const int i = tid;
+        if (i > j && i < NB)
+            for (int k = j + 1; k <= i; ++k) t += a[i * LDP + k] * a[k * LDP + j];
+        __syncthreads();
+        if (i > j && i < NB) a[i * LDP + j] = -t * ajj;
+        if (tid == 0) a[j * LDP + j] = ajj;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NB * NB; idx += kBlock) {
+        const int i = idx >> 7, j = idx & 127;
+        linv[idx] = (j <= i) ? a[i * LDP + j] : 0.0;
+    }
+}
+
+// ---- NT GEMM on the f64 matrix cores ---------------------------------------------------------------
+// C[i][j] (op)= sum_k A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K = 128.
+//   MODE 0 (panel solve, X = A21 * Linv^T): C = A B^T, C aliases A (all loads finish before any store).
+//   MODE 1 (trailing update, A22 -= L21 L21^T): C -= A B^T on the lower tiles, 1-D triangular grid.
+// Wave w owns the 64 x 64 quadrant (w>>1, w&1) as 4 x 4 MFMA tiles of 16 x 16 (64 accumulator f64
+// per lane).  v_mfma_f64_16x16x4_f64 operand map: lane l supplies A[i = l&15][k = l>>4] and
+// B[k = l>>4][j = l&15]; the k index inside a 16-chunk is permuted (lane group kq holds
+// k = 4 kq + s at step s) identically for A and B, so every lane fetches 4 consecutive doubles
+// (two 16-byte loads) per 16-row strip.  C/D map: col = l&15, row = (l>>4) + 4 reg.
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, const double* bbase,
+                                                        int64_t lda, int64_t ldb, double* cbase, int64_t ldc) {
+    int by, bx;
+    if (MODE == 1) {
+        const int t = blockIdx.x;
+        by = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((int64_t)(by + 1) * (by + 2) / 2 <= t) ++by;
+        while ((int64_t)by * (by + 1) / 2 > t) --by;
+        bx = t - (int)((int64_t)by * (by + 1) / 2);
+    } else {
+        by = blockIdx.x;
+        bx = 0;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int li = lane & 15, kq = lane >> 4;
+    const double* ap = abase + ((int64_t)by * NB + wr * 64 + li) * lda + 4 * kq;
+    const double* bp = bbase + ((int64_t)bx * NB + wc * 64 + li) * ldb + 4 * kq;
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int kc = 0; kc < NB; kc += 16) {
+        d4 af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            af[t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda + kc);
+            bf[t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb + kc);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (MODE == 0) __syncthreads();  // C aliases A: every wave's loads are done before anyone stores
+    double* cp = cbase + ((int64_t)by * NB + wr * 64 + kq) * ldc + (int64_t)bx * NB + wc * 64 + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* q = cp + (int64_t)(16 * i + 4 * r) * ldc + 16 * j;
+                if (MODE == 1)
+                    *q -= acc[i][j][r];
+                else
+                    *q = acc[i][j][r];
+            }
+}
+
+// ---- block triangular solves with 3 right-hand sides ----------------------------------------------
+// x_k = Linv_k * v_k (TRANS = 0) or Linv_k^T * v_k (TRANS = 1); v, x are [mp][3] row-major.
+template <int TRANS>
+__global__ __launch_bounds__(384) void k_diag_solve(const double* __restrict__ linv, double* __restrict__ v,
+                                                    int64_t k0) {
+    __shared__ double vin[NB][3];
+    const int r = threadIdx.x / 3, c = threadIdx.x % 3;
+    vin[r][c] = v[(k0 + r) * 3 + c];
+    __syncthreads();
+    double s = 0.0;
+    if (TRANS == 0) {
+        for (int k = 0; k <= r; ++k) s += linv[r * NB + k] * vin[k][c];
+    } else {
+        for (int k = r; k < NB; ++k) s += linv[k * NB + r] * vin[k][c];
+    }
+    v[(k0 + r) * 3 + c] = s;
+}
+
+// forward (right-looking): v[i] -= sum_c L[i][k0 + c] * x_k[c] for rows i >= k0 + 128.
+// 4 threads per row, each covering 32 of the 128 columns in 16-byte pieces; x_k in LDS.
+__global__ __launch_bounds__(kBlock) void k_fwd_update(const double* __restrict__ s, int64_t ld, int64_t k0,
+                                                       int64_t mp, double* __restrict__ v) {
+    __shared__ double xk[NB][3];
+    for (int idx = threadIdx.x; idx < NB * 3; idx += kBlock) xk[idx / 3][idx % 3] = v[k0 * 3 + idx];
+    __syncthreads();
+    const int part = threadIdx.x & 3;
+    const int64_t i = k0 + NB + (int64_t)blockIdx.x * 64 + (threadIdx.x >> 2);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (i < mp) {
+        const double* row = s + i * ld + k0;
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            const int c = q * 8 + part * 2;
+            const double2 l2 = *reinterpret_cast<const double2*>(row + c);
+            a0 += l2.x * xk[c][0] + l2.y * xk[c + 1][0];
+            a1 += l2.x * xk[c][1] + l2.y * xk[c + 1][1];
+            a2 += l2.x * xk[c][2] + l2.y * xk[c + 1][2];
+        }
+    }
+    a0 += __shfl_xor(a0, 1, 64); a0 += __shfl_xor(a0, 2, 64);
+    a1 += __shfl_xor(a1, 1, 64); a1 += __shfl_xor(a1, 2, 64);
+    a2 += __shfl_xor(a2, 1, 64); a2 += __shfl_xor(a2, 2, 64);
+    if (i < mp && part == 0) {
+        v[i * 3] -= a0;
+        v[i * 3 + 1] -= a1;
+        v[i * 3 + 2] -= a2;
+    }
+}
+
+// backward (right-looking): v[c] -= sum_r L[k0 + r][c] * x_k[r] for columns c < k0 (coalesced along c).
+__global__ __launch_bounds__(kBlock) void k_bwd_update(const double* __restrict__ s, int64_t ld, int64_t k0,
+                                                       double* __restrict__ v) {
+    __shared__ double xk[NB][3];
+    for (int idx = threadIdx.x; idx < NB * 3; idx += kBlock) xk[idx / 3][idx % 3] = v[k0 * 3 + idx];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= k0) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const double* col = s + k0 * ld + c;
+#pragma unroll 8
+    for (int r = 0; r < NB; ++r) {
+        const double l = col[(int64_t)r * ld];
+        a0 += l * xk[r][0];
+        a1 += l * xk[r][1];
+        a2 += l * xk[r][2];
+    }
+    v[c * 3] -= a0;
+    v[c * 3 + 1] -= a1;
+    v[c * 3 + 2] -= a2;
+}
+
+// v = sp .* gb     |   w = (b - sp .* u) / c
+__global__ __launch_bounds__(kBlock) void k_scale_rows(const double* __restrict__ sp, const double* __restrict__ in,
+                                                       int64_t mp, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= mp) return;
+    const double f = sp[i];
+    out[i * 3] = f * in[i * 3];
+    out[i * 3 + 1] = f * in[i * 3 + 1];
+    out[i * 3 + 2] = f * in[i * 3 + 2];
+}
+__global__ __launch_bounds__(kBlock) void k_form_w(const double* __restrict__ b3, const double* __restrict__ sp,
+                                                   const double* __restrict__ u, int64_t m,
+                                                   const double* __restrict__ params, double lmd,
+                                                   double* __restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const double rc = 1.0 / (lmd * params[13]);
+    const double f = sp[i];
+    w[i * 3] = (b3[i * 3] - f * u[i * 3]) * rc;
+    w[i * 3 + 1] = (b3[i * 3 + 1] - f * u[i * 3 + 1]) * rc;
+    w[i * 3 + 2] = (b3[i * 3 + 2] - f * u[i * 3 + 2]) * rc;
+}
+
+// partial sums of tr(px^T T) and tr(T^T diag(p1) T), T = y + gw   (cpd.py:298-300)
+__global__ __launch_bounds__(kBlock) void k_traces(const double* __restrict__ rowacc, int64_t mcap,
+                                                   const float4* __restrict__ src4, const double* __restrict__ gw,
+                                                   int64_t m, double* __restrict__ part) {
+    __shared__ double sh[4][2];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a = 0.0, b = 0.0;
+    if (i < m) {
+        const float4 y = src4[i];
+        const double t0 = (double)y.x + gw[i * 3], t1 = (double)y.y + gw[i * 3 + 1], t2 = (double)y.z + gw[i * 3 + 2];
+        a = rowacc[mcap + i] * t0 + rowacc[2 * mcap + i] * t1 + rowacc[3 * mcap + i] * t2;
+        b = rowacc[i] * (t0 * t0 + t1 * t1 + t2 * t2);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (lane == 0) { sh[wv][0] = a; sh[wv][1] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        part[(int64_t)blockIdx.x * 2 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
+                                                     sh[3][threadIdx.x];
+}
+
+__global__ void k_nonrigid_finish(const double* __restrict__ part, int nblk, const double* __restrict__ mom,
+                                  double* __restrict__ params, int dim) {
+    __shared__ double sh[2][64];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 64) {
+        a += part[2 * i];
+        b += part[2 * i + 1];
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tr_pxt = 0.0, tr_tpt = 0.0;
+        for (int i = 0; i < 64; ++i) { tr_pxt += sh[0][i]; tr_tpt += sh[1][i]; }
+        const double n_p = mom[0], tr_xp1x = mom[22];
+        const double sigma2 = (tr_xp1x - 2.0 * tr_pxt + tr_tpt) / (n_p * dim);  // cpd.py:301 (no eps clamp)
+        params[13] = sigma2;
+        params[14] = sigma2;  // q := sigma2, cpd.py:303
+        params[15] = n_p;
+        params[16] += 1.0;
+    }
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
+
+}  // namespace
+
 extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
-    (void)h; (void)lmd;
-    prg::set_error("prg_cpd_mstep_nonrigid: not built yet");
-    return PRG_ERR_STATE;
+    PRG_REQUIRE(h && h->G && h->W && h->have_estep, PRG_ERR_STATE,
+                "prg_cpd_mstep_nonrigid: needs build_g and an E-step first");
+    PRG_REQUIRE(lmd > 0.0, PRG_ERR_INVALID, "prg_cpd_mstep_nonrigid: lmd must be > 0 (got %g)", lmd);
+    prg::DeviceGuard g(h->device);
+    const int64_t m = h->M, mp = prg::round_up(m, NB), nblk = mp / NB;
+    // workspace: S [mp*mp] | Linv [nblk*128*128] | b3, gb, v, sp (each <= 3 mp) | trace partials | info
+    const size_t n_s = (size_t)mp * mp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)mp * 3;
+    const int tr_blk = (int)prg::ceil_div(m, kBlock);
+    const size_t need = (n_s + n_linv + 4 * n_vec + 2 * (size_t)tr_blk + 16) * sizeof(double);
+    if (h->nr_solve_bytes < need) {
+        if (h->nr_solve) (void)hipFree(h->nr_solve);
+        h->nr_solve = nullptr;
+        h->nr_solve_bytes = 0;
+        PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
+        h->nr_solve_bytes = need;
+        PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, NB * LDP * (int)sizeof(double)));
+    }
+    double* S = h->nr_solve;
+    double* linv = S + n_s;
+    double* b3 = linv + n_linv;
+    double* gb = b3 + n_vec;
+    double* v = gb + n_vec;
+    double* sp = v + n_vec;
+    double* trpart = sp + n_vec;
+    int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
+    hipStream_t st = h->stream;
+
+    PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    k_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, mp, b3, sp);
+    PRG_TRY(prg::nonrigid_gw(h, b3, gb));                       // G B
+    k_scale_rows<<<grid1(m), kBlock, 0, st>>>(sp, gb, m, v);    // v = D^1/2 G B (pad rows of v stay 0 below)
+    if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));
+    k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
+
+    // blocked Cholesky S = L L^T (lower, in place)
+    const size_t lds = (size_t)NB * LDP * sizeof(double);
+    for (int64_t kb = 0; kb < nblk; ++kb) {
+        const int64_t k0 = kb * NB;
+        k_potrf_inv<<<1, kBlock, lds, st>>>(S, mp, k0, linv + (size_t)kb * NB * NB, info);
+        const int64_t below = nblk - kb - 1;
+        if (below > 0) {
+            double* a21 = S + (k0 + NB) * mp + k0;
+            k_gemm_nt_f64<0><<<(unsigned)below, kBlock, 0, st>>>(a21, linv + (size_t)kb * NB * NB, mp, NB, a21, mp);
+            const int64_t ntri = below * (below + 1) / 2;
+            k_gemm_nt_f64<1><<<(unsigned)ntri, kBlock, 0, st>>>(a21, a21, mp, mp, S + (k0 + NB) * mp + (k0 + NB), mp);
+        }
+    }
+    // L L^T u = v
+    for (int64_t kb = 0; kb < nblk; ++kb) {
+        const int64_t k0 = kb * NB;
+        k_diag_solve<0><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+        const int64_t rows = mp - k0 - NB;
+        if (rows > 0) k_fwd_update<<<(unsigned)prg::ceil_div(rows, 64), kBlock, 0, st>>>(S, mp, k0, mp, v);
+    }
+    for (int64_t kb = nblk - 1; kb >= 0; --kb) {
+        const int64_t k0 = kb * NB;
+        k_diag_solve<1><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+        if (k0 > 0) k_bwd_update<<<grid1(k0), kBlock, 0, st>>>(S, mp, k0, v);
+    }
+    k_form_w<<<grid1(m), kBlock, 0, st>>>(b3, sp, v, m, h->params, lmd, h->W);
+    PRG_TRY(prg::nonrigid_gw(h, h->W, gb));                     // G W
+    k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, gb, m, trpart);
+    k_nonrigid_finish<<<1, 64, 0, st>>>(trpart, tr_blk, h->moments, h->params, h->D);
+    PRG_HIP(hipGetLastError());
+    int host_info = 0;
+    PRG_HIP(hipMemcpyAsync(&host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    PRG_REQUIRE(host_info == 0, PRG_ERR_STATE,
+                "prg_cpd_mstep_nonrigid: S is not positive definite at pivot %d (sigma2 or lmd <= 0?)", host_info - 1);
+    return PRG_OK;
 }

@@ -45,8 +45,10 @@ struct prg_cpd {
     double* W = nullptr;       // [M][3] float64 (row-major, 3 columns always)
     double beta = 0.0;
     bool nonrigid = false;
-    double* nr_work = nullptr;  // solver workspace (fp64)
+    double* nr_work = nullptr;  // [16 M] doubles: G.W product and scratch
     size_t nr_work_bytes = 0;
+    double* nr_solve = nullptr;  // M-step workspace: S (fp64 M x M), block inverses, vectors
+    size_t nr_solve_bytes = 0;
 
     bool have_source = false, have_target = false, have_estep = false;
     double last_w = 0.0;
@@ -56,5 +58,6 @@ namespace prg {
 int ensure_stage(prg_cpd* h, size_t bytes);
 // non-rigid (cpd_nonrigid.hip)
 int nonrigid_transform(prg_cpd* h);          // z4 = y + G W
+int nonrigid_gw(prg_cpd* h, const double* w3, double* out3);  // out3[m][3] = G * w3[m][3] (fp64)
 int nonrigid_free(prg_cpd* h);
 }  // namespace prg

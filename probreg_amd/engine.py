@@ -97,12 +97,13 @@ class CpdPlan(object):
     def init_sums(self):
         check(lib.prg_cpd_init_sums(self._h))
 
-    def init_params(self, init13=None):
-        if init13 is None:
+    def init_params(self, init16=None):
+        """``init16``: linear part (9), t (3), scale, delta = origin_target - origin_source (3)."""
+        if init16 is None:
             check(lib.prg_cpd_init_params(self._h, None))
         else:
-            a = np.ascontiguousarray(init13, dtype=np.float64)
-            assert a.size == 13
+            a = np.ascontiguousarray(init16, dtype=np.float64)
+            assert a.size == 16
             check(lib.prg_cpd_init_params(self._h, ptr(a)))
 
     def estep(self, w=0.0):

@@ -89,4 +89,9 @@ class NonRigidTransformation(Transformation):
 
     def _transform(self, points):
         # same contract as the reference: ``points`` must be the control points the kernel was built on
+        if self._plan is not None:
+            # G W on the GPU (fp64 accumulation over the float32 G), never through a host copy of G
+            self._plan.set_w(np.asarray(self.w, dtype=np.float64))
+            disp = self._plan.nonrigid_apply() - self._points.astype(np.float32).astype(np.float64)
+            return np.asarray(points) + disp
         return points + np.dot(self.g, self.w)

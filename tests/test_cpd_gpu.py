@@ -119,14 +119,15 @@ def test_maximization_step_from_arrays(cpd_golden):
         ("affine", cpd.AffineCPD(src), co.mstep_affine(src, tgt, es)),
     ):
         res = obj.maximization_step(tgt, cpd.EstepResult(*es))
-        assert abs(res.sigma2 - direct.sigma2) < 1e-9 * direct.sigma2, kind
-        assert abs(res.q - direct.q) < 1e-8 * abs(direct.q), kind
+        # the clouds are rounded to float32 on upload (after fp64 centring): ~1e-8 relative on the moments
+        assert abs(res.sigma2 - direct.sigma2) < 1e-6 * direct.sigma2, kind
+        assert abs(res.q - direct.q) < 1e-6 * abs(direct.q), kind
         if kind.startswith("rigid"):
-            assert rel_err(res.transformation.rot, direct.params["rot"]) < 1e-9
-            assert abs(res.transformation.scale - direct.params["scale"]) < 1e-9
+            assert rel_err(res.transformation.rot, direct.params["rot"]) < 1e-6
+            assert abs(res.transformation.scale - direct.params["scale"]) < 1e-6
         else:
-            assert rel_err(res.transformation.b, direct.params["b"]) < 1e-9
-        assert np.max(np.abs(res.transformation.t - direct.params["t"])) < 1e-9
+            assert rel_err(res.transformation.b, direct.params["b"]) < 1e-6
+        assert np.max(np.abs(res.transformation.t - direct.params["t"])) < 1e-6
 
 
 def test_sigma2_init_vs_reference(cpd_golden):
@@ -323,3 +324,63 @@ def test_gauss_transform_direct():
     got = gt.GaussTransform(src, 0.3).compute(tgt, w2)
     want = np.array([[np.dot(wr, np.exp(-np.sum((t - src) ** 2, axis=1) / 0.09)) for t in tgt] for wr in w2])
     assert got.shape == (2, 170) and np.allclose(got, want, atol=1e-4, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# non-rigid CPD (reference cpd.py:247-303)
+# ---------------------------------------------------------------------------------------------
+NONRIGID_CASES = ["bunny_nonrigid_default", "bunny_nonrigid_k5", "fish_nonrigid_default", "synth_nonrigid_1k_k1",
+                  "synth_nonrigid_1k_k5"]
+
+
+@pytest.mark.parametrize("name", NONRIGID_CASES)
+def test_nonrigid_vs_reference(cpd_golden, name):
+    """The recovered non-rigid transform is compared as T(Y) = Y + G W (what the reference's
+    ``transformation.transform(source)`` returns).  W itself solves a system whose condition number is
+    ~lambda_max(G)/(lmd sigma2) ~ 1e6..1e8, so 1-ulp differences in the float32 G (Eigen's vectorised
+    expf in the reference vs a correctly rounded exp here) move W by up to ~1e-3 relative while T,
+    sigma2 and q stay inside the north-star tolerance; W is checked at that looser level."""
+    from probreg_amd import cpd
+
+    c = cpd_golden.case("reg/" + name)
+    niter = [0]
+    res = cpd.registration_cpd(c["source"], c["target"], "nonrigid",
+                               callbacks=[lambda t: niter.__setitem__(0, niter[0] + 1)], **_kwargs(c))
+    if "default" in name:
+        assert abs(niter[0] - c["out_niter"]) <= 2
+        if niter[0] != c["out_niter"]:
+            pytest.skip("stopped %d iteration(s) apart from the fp64 reference (absolute tol on q)" %
+                        abs(niter[0] - c["out_niter"]))
+    assert abs(res.sigma2 - c["out_sigma2"]) <= TOL_SIGMA2 * c["out_sigma2"]
+    ts = res.transformation.transform(c["source"])
+    extent = np.max(np.abs(c["out_tsource"] - c["out_tsource"].mean(0)))
+    assert np.max(np.abs(ts - c["out_tsource"])) < TOL_TF * extent
+    wmax = np.max(np.abs(c["out_w"]))
+    assert np.max(np.abs(res.transformation.w - c["out_w"])) < 2e-2 * wmax
+
+
+def test_nonrigid_g_matches_oracle(cpd_golden):
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd
+
+    c = cpd_golden.case("reg/fish_nonrigid_default")
+    reg = cpd.NonRigidCPD(c["source"], beta=2.0)
+    g = reg._tf_obj.g
+    want = co.rbf_kernel(c["source"], c["source"], 2.0)
+    assert g.dtype == np.float32 and np.array_equal(g, g.T)
+    assert np.max(np.abs(g - want)) <= 1.2e-7
+
+
+def test_nonrigid_vs_oracle_medium():
+    """M = 3000 (not a multiple of the 128 Cholesky block): seeded C3-style clouds, 4 fixed iterations."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(3500, m=3000, seed=61)
+    p, s2, q, _ = co.registration("nonrigid", src, tgt, maxiter=4, tol=-1.0, closed_form_init=True)
+    g = co.rbf_kernel(src, src, 2.0)
+    want = co.transform("nonrigid", p, src, g)
+    res = cpd.registration_cpd(src, tgt, "nonrigid", maxiter=4, tol=-1.0)
+    assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
+    got = res.transformation.transform(src)
+    assert np.max(np.abs(got - want)) < TOL_TF * np.max(np.abs(want - want.mean(0)))

@@ -39,7 +39,7 @@ def test_params_block_and_centring_roundtrip():
     z = s * y @ rot.T + t
     assert np.allclose(z_centred + cx, z)
     blk = cpd._params_block(rot[:2, :2], t[:2], s, 2)
-    assert blk.shape == (13,) and blk[8] == 1.0 and blk[12] == s and blk[11] == 0.0
+    assert blk.shape == (16,) and blk[8] == 1.0 and blk[12] == s and blk[11] == 0.0
 
 
 def test_api_surface_matches_reference_names():
