@@ -142,5 +142,67 @@ def main():
     print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
 
 
+def main_filterreg():
+    """FilterReg fixtures: the reference's filterreg.py driving the vendored lattice (oracle/_ref)."""
+    from oracle import permutohedral as ph
+
+    assert ph.ref_available(), "build oracle/_ref first: make -C oracle ref"
+    ref = ref_import.load(with_filterreg=True)
+    bunny = load_pcd_ascii(os.path.join(ref_import.REFERENCE_ROOT, "examples", "bunny.pcd"))
+    bunny_t = bunny @ rot_z(30.0).T
+    fish_s = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_source.txt"))
+    fish_t = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_target.txt"))
+    flat = {}
+
+    def add(name, src, tgt, **kw):
+        niter = [0]
+        res = ref.filterreg.registration_filterreg(src.copy(), tgt.copy(),
+                                                   callbacks=[lambda t: niter.__setitem__(0, niter[0] + 1)], **kw)
+        pre = "reg/%s/" % name
+        flat[pre + "source"], flat[pre + "target"] = src, tgt
+        flat[pre + "out_rot"] = np.asarray(res.transformation.rot)
+        flat[pre + "out_t"] = np.asarray(res.transformation.t)
+        flat[pre + "out_sigma2"] = np.asarray(float(res.sigma2))
+        flat[pre + "out_q"] = np.asarray(float(res.q))
+        flat[pre + "out_niter"] = np.asarray(niter[0])
+        for k, v in kw.items():
+            if isinstance(v, (int, float, bool)):
+                flat[pre + "arg_" + k] = np.asarray(v)
+        print("filterreg %-30s niter=%3d sigma2=%.9e q=%.9e" % (name, niter[0], res.sigma2, res.q))
+
+    add("bunny_default", bunny, bunny_t)
+    add("bunny_update_sigma2", bunny, bunny_t, update_sigma2=True)
+    add("bunny_update_sigma2_w005_k8", bunny, bunny_t, update_sigma2=True, w=0.05, maxiter=8, tol=-1.0)
+    add("bunny_fixed_sigma2_k5", bunny, bunny_t, sigma2=1.0e-3, maxiter=5, tol=-1.0)
+    s, t, _ = synthetic.filterreg_pair(5000, seed=2)
+    add("synth_5k_outliers_k6", s, t, update_sigma2=True, w=0.05, maxiter=6, tol=-1.0)
+    s, t, _ = synthetic.filterreg_pair(4000, m=2500, seed=4)
+    add("synth_ragged_k4", s, t, update_sigma2=True, w=0.05, maxiter=4, tol=-1.0)
+    add("fish2d_k10", fish_s, fish_t, update_sigma2=True, maxiter=10, tol=-1.0,
+        tf_init_params={"rot": np.identity(2), "t": np.zeros(2)})
+
+    # lattice unit vectors straight from the vendored permutohedral.cpp (init + compute)
+    rng = np.random.default_rng(11)
+    for d in (1, 2, 3):
+        for blur in (True, False):
+            pts = (rng.normal(size=(3000, d)) * 2.5).astype(np.float32)
+            lat = ph.Lattice(pts, blur, prefer_ref=True)
+            assert lat.is_ref
+            pre = "lattice/d%d_blur%d/" % (d, int(blur))
+            flat[pre + "points"] = pts
+            flat[pre + "size"] = np.asarray(lat.lattice_size)
+            for ch in (1, 3, 5):
+                v = rng.normal(size=(3000, ch)).astype(np.float32)
+                flat[pre + "values_ch%d" % ch] = v
+                flat[pre + "out_ch%d" % ch] = lat.filter(v)
+            print("lattice d=%d blur=%d size=%d" % (d, blur, lat.lattice_size))
+    out = os.path.join(HERE, "filterreg_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) < 2 or sys.argv[1] == "cpd":
+        main()
+    if len(sys.argv) < 2 or sys.argv[1] == "filterreg":
+        main_filterreg()
