@@ -176,6 +176,48 @@ int prg_squared_kernel_sum(int device, void* hip_stream, const float* x_hd, int6
 int prg_rbf_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd,
                    int64_t n, int dim, double beta, float* out_hd);
 
+/* ---- permutohedral lattice (Gaussian filtering) --------------------------------------------- */
+/* Replaces the pybind class probreg._permutohedral_lattice.Permutohedral
+ * (cc/permutohedral_lattice_py.cc:13-21 over third_party/permutohedral/permutohedral.cpp) behind
+ * probreg.gaussian_filtering.Permutohedral (gaussian_filtering.py:8-17). */
+typedef struct prg_ph prg_ph;
+int prg_ph_create(prg_ph** out, int device, void* hip_stream);
+int prg_ph_destroy(prg_ph* h);
+/* init(features, with_blur): points is n x d row-major float32 (the reference passes the transpose). */
+int prg_ph_init(prg_ph* h, const float* points_hd, int64_t n, int dim, int with_blur);
+/* get_lattice_size() */
+int prg_ph_lattice_size(prg_ph* h, int* size);
+/* filter(v, start): values n x channels row-major float32 -> out, same shape.  `start` does not exist
+ * here because the reference drops it (permutohedral.cpp:608-616). */
+int prg_ph_filter(prg_ph* h, const float* values_hd, int channels, float* out_hd);
+
+/* ---- FilterReg rigid point-to-point ------------------------------------------------------------ */
+typedef struct prg_filterreg prg_filterreg;
+int prg_fr_create(prg_filterreg** out, int device, void* hip_stream);
+int prg_fr_destroy(prg_filterreg* h);
+/* Clouds as float64 (the reference transforms / scales in float64 before the float32 lattice cast).
+ * Replaces: RigidFilterReg(source=...) filterreg.py:150-156 and the `target` of registration, :120. */
+int prg_fr_set_source(prg_filterreg* h, const double* source_hd, int64_t m, int dim);
+int prg_fr_set_target(prg_filterreg* h, const double* target_hd, int64_t n, int dim);
+/* Current rigid transform (rot: row-major 3x3 with the dim x dim block filled, t: 3) and sigma2. */
+int prg_fr_set_state(prg_filterreg* h, const double* rot9, const double* t3, double sigma2);
+/* E-step: transform the source, build the lattice over [t_source; target] / sigma (rebuilt without blur
+ * when it has more than n*alpha vertices), filter (1 | target | |target|^2) and keep the first m rows.
+ * Replaces: FilterReg.expectation_step, filterreg.py:78-108 (pt2pt). */
+int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_blur);
+/* m0 [m], m1 [m x dim], m2 [m] of the last E-step (float32; any pointer may be NULL). */
+int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd);
+/* M-step (weighted Kabsch + composition + optional sigma2 update).  out_host[17]: [0..8] rot, [9..11] t,
+ * [12] sigma2 used, [13] q, [14] number of points with m0 != 0, [15] new sigma2, [16] 1 if a transform
+ * was estimated (0 = every m0 was zero: the reference returns q = None, filterreg.py:167-168).
+ * Replaces: RigidFilterReg._maximization_step filterreg.py:158-196 + cc/kabsch.cc:6-109. */
+int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host);
+
+/* Weighted Kabsch on float32 clouds: centroids weighted by w, covariance by w^2; rot_host dim x dim
+ * row-major, t_host dim.  Replaces: _kabsch.kabsch / kabsch2d (cc/kabsch_py.cc, cc/kabsch.cc:6-109). */
+int prg_kabsch_weighted(int device, void* hip_stream, const float* model_hd, const float* target_hd,
+                        const float* weight_hd, int64_t n, int dim, double* rot_host, double* t_host);
+
 #ifdef __cplusplus
 }
 #endif

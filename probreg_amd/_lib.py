@@ -80,6 +80,20 @@ SIGNATURES = {
     "prg_gauss_transform_direct": [_i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _d, _vp],
     "prg_squared_kernel_sum": [_i, _vp, _vp, _i64, _vp, _i64, _i, _c.POINTER(_d)],
     "prg_rbf_kernel": [_i, _vp, _vp, _i64, _vp, _i64, _i, _d, _vp],
+    "prg_ph_create": [_pp, _i, _vp],
+    "prg_ph_destroy": [_vp],
+    "prg_ph_init": [_vp, _vp, _i64, _i, _i],
+    "prg_ph_lattice_size": [_vp, _c.POINTER(_i)],
+    "prg_ph_filter": [_vp, _vp, _i, _vp],
+    "prg_fr_create": [_pp, _i, _vp],
+    "prg_fr_destroy": [_vp],
+    "prg_fr_set_source": [_vp, _vp, _i64, _i],
+    "prg_fr_set_target": [_vp, _vp, _i64, _i],
+    "prg_fr_set_state": [_vp, _vp, _vp, _d],
+    "prg_fr_estep": [_vp, _d, _c.POINTER(_i), _c.POINTER(_i)],
+    "prg_fr_get_estep": [_vp, _vp, _vp, _vp],
+    "prg_fr_mstep": [_vp, _d, _i, _vp],
+    "prg_kabsch_weighted": [_i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
 }
 
 for _name, _args in SIGNATURES.items():

@@ -1,0 +1,926 @@
+// FilterReg rigid point-to-point EM iteration on MI355X (gfx950): GPU permutohedral lattice
+// (parallel hash build, atomic splat, blur, slice) + weighted Kabsch reduction.
+//
+// Reference behaviour (neka-nat/probreg v0.3.7):
+//   lattice   third_party/permutohedral/permutohedral.cpp:140-325 (init, SSE build) and :482-616 (compute)
+//             behind probreg/gaussian_filtering.py:8-17 / probreg/cc/permutohedral_lattice_py.cc:13-21
+//   E-step    probreg/filterreg.py:78-108        M-step  probreg/filterreg.py:158-196 (pt2pt)
+//   Kabsch    probreg/cc/kabsch.cc:6-109
+//
+// The embedding arithmetic (elevate, round-half-even, rank, barycentric) is evaluated in float32 with
+// explicitly un-fused operations so that every point lands in the same simplex with the same weights as
+// in the reference's SSE build; vertex ids are arbitrary labels (hash order), which no output depends on.
+// The splat is a float atomic add, i.e. the summation ORDER differs from the reference's sequential loop
+// (float32 round-off only).  Everything here is HBM-latency / atomic bound integer and scatter work.
+#include <math.h>
+
+#include "prg_common.h"
+#include "small_linalg.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr unsigned long long kEmpty = 0xFFFFFFFFFFFFFFFFull;
+constexpr int kMaxD = 3;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long pack_key(const short* k, int d) {
+    unsigned long long r = 0;
+    for (int i = 0; i < d; ++i) r |= (unsigned long long)(unsigned short)k[i] << (16 * i);
+    return r;
+}
+__device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+struct Lattice {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t n = 0;   // embedded points
+    int d = 0;
+    int with_blur = 1;
+    int size = 0;    // number of lattice vertices (host copy)
+    // device
+    float* feat = nullptr;              // [n][d]
+    unsigned long long* tkeys = nullptr;  // hash table [cap]
+    int* slot_id = nullptr;             // [cap] dense id of an occupied slot
+    int64_t cap = 0;
+    int* pslot = nullptr;               // [n][d+1] slot, later overwritten by dense id (= offset_)
+    float* bary = nullptr;              // [n][d+1]
+    unsigned long long* dkeys = nullptr;  // [n*(d+1)] dense keys
+    int* nb = nullptr;                  // [2][d+1][size] blur neighbours (dense id or -1)
+    int* count = nullptr;               // device counter
+    float* vals = nullptr;              // [2][(size+1)][C] ping-pong value buffers
+    int64_t vals_elems = 0;
+    int64_t n_alloc = 0, nb_alloc = 0;
+    float* io = nullptr;                // staging for values / outputs
+    size_t io_bytes = 0;
+};
+
+// ---- embedding (permutohedral.cpp:186-276, SSE build) -------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, int64_t n, float s0, float s1,
+                                                  float s2, unsigned long long* __restrict__ tkeys,
+                                                  unsigned long long mask, int* __restrict__ pslot,
+                                                  float* __restrict__ bary) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    constexpr int D1 = D + 1;
+    const float scale[3] = {s0, s1, s2};
+    float f[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) f[k] = feat[i * D + k];
+    float elevated[D1], rem0[D1], rank[D1], bar[D1 + 1];
+    float sm = 0.f;
+#pragma unroll
+    for (int j = D; j > 0; --j) {
+        const float cf = __fmul_rn(f[j - 1], scale[j - 1]);
+        elevated[j] = __fsub_rn(sm, __fmul_rn((float)j, cf));
+        sm = __fadd_rn(sm, cf);
+    }
+    elevated[0] = sm;
+    const float invd1 = 1.0f / (float)D1, fd1 = (float)D1;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < D1; ++k) {
+        float v = __fmul_rn(invd1, elevated[k]);
+        v = rintf(v);  // round half to even (_mm_cvtps_epi32 under the default MXCSR, :214-218)
+        rem0[k] = __fmul_rn(v, fd1);
+        sum = __fadd_rn(sum, v);
+    }
+#pragma unroll
+    for (int k = 0; k < D1; ++k) rank[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        const float da = __fsub_rn(elevated[a], rem0[a]);
+#pragma unroll
+        for (int b = a + 1; b < D1; ++b) {
+            const float db = __fsub_rn(elevated[b], rem0[b]);
+            if (da < db) rank[a] += 1.f; else rank[b] += 1.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < D1; ++k) {
+        rank[k] += sum;
+        if (rank[k] < 0.f) { rank[k] += fd1; rem0[k] += fd1; }
+        else if (rank[k] >= fd1) { rank[k] -= fd1; rem0[k] -= fd1; }
+    }
+#pragma unroll
+    for (int k = 0; k <= D1; ++k) bar[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < D1; ++k) {
+        const float v = __fmul_rn(__fsub_rn(elevated[k], rem0[k]), invd1);
+        const int p = D - (int)rank[k];
+#pragma unroll
+        for (int q = 0; q <= D1; ++q) {  // static indexing keeps bar[] in registers
+            if (q == p) bar[q] = __fadd_rn(bar[q], v);
+            if (q == p + 1) bar[q] = __fsub_rn(bar[q], v);
+        }
+    }
+    bar[0] = __fadd_rn(bar[0], __fadd_rn(1.0f, bar[D1]));
+#pragma unroll
+    for (int r = 0; r < D1; ++r) {
+        short key[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            // canonical[r][rank] = r if rank <= D - r else r - (D+1)   (:166-171)
+            const int rk = (int)rank[k];
+            const int can = (rk <= D - r) ? r : r - D1;
+            key[k] = (short)(rem0[k] + (float)can);
+        }
+        const unsigned long long pk = pack_key(key, D);
+        unsigned long long slot = mix64(pk) & mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS(&tkeys[slot], kEmpty, pk);
+            if (prev == kEmpty || prev == pk) break;
+            slot = (slot + 1) & mask;
+        }
+        pslot[i * D1 + r] = (int)slot;
+        bary[i * D1 + r] = bar[r];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_compact(const unsigned long long* __restrict__ tkeys, int64_t cap,
+                                                    int* __restrict__ slot_id, unsigned long long* __restrict__ dkeys,
+                                                    int* __restrict__ count) {
+    const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (s >= cap) return;
+    const unsigned long long k = tkeys[s];
+    if (k == kEmpty) return;
+    const int id = atomicAdd(count, 1);
+    slot_id[s] = id;
+    dkeys[id] = k;
+}
+
+__global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int64_t total,
+                                                    const int* __restrict__ slot_id) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < total) pslot[i] = slot_id[pslot[i]];
+}
+
+__device__ __forceinline__ int lookup(const unsigned long long* __restrict__ tkeys, unsigned long long mask,
+                                      const int* __restrict__ slot_id, unsigned long long pk) {
+    unsigned long long slot = mix64(pk) & mask;
+    for (;;) {
+        const unsigned long long k = tkeys[slot];
+        if (k == pk) return slot_id[slot];
+        if (k == kEmpty) return -1;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// blur neighbours (permutohedral.cpp:300-324): along axis j, n1 = key - 1 (all coords) with n1[j] = key[j] + d,
+// n2 = key + 1 with n2[j] = key[j] - d; axis j == d only touches the implicit last coordinate.
+template <int D>
+__global__ __launch_bounds__(kBlock) void k_neighbours(const unsigned long long* __restrict__ dkeys, int size,
+                                                       const unsigned long long* __restrict__ tkeys,
+                                                       unsigned long long mask, const int* __restrict__ slot_id,
+                                                       int* __restrict__ nb1, int* __restrict__ nb2) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)size * (D + 1)) return;
+    const int j = (int)(t / size), v = (int)(t % size);
+    const unsigned long long pk = dkeys[v];
+    short key[D], n1[D], n2[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        key[k] = (short)(unsigned short)(pk >> (16 * k));
+        n1[k] = (short)(key[k] - 1);
+        n2[k] = (short)(key[k] + 1);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        if (k == j) { n1[k] = (short)(key[k] + D); n2[k] = (short)(key[k] - D); }
+    nb1[(int64_t)j * size + v] = lookup(tkeys, mask, slot_id, pack_key(n1, D));
+    nb2[(int64_t)j * size + v] = lookup(tkeys, mask, slot_id, pack_key(n2, D));
+}
+
+// ---- filtering (permutohedral.cpp:482-616) --------------------------------------------------------------
+// vals layout: [(size + 1)][C], row 0 is the all-zero row that the missing-neighbour id -1 maps to.
+__global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset, const float* __restrict__ bary,
+                                                  const float* __restrict__ in, int64_t first, int64_t n, int d1,
+                                                  int ch, float* __restrict__ vals) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (n - first) * d1) return;
+    const int64_t i = first + t / d1;
+    const int r = (int)(t % d1);
+    const int o = offset[i * d1 + r] + 1;
+    const float w = bary[i * d1 + r];
+    for (int k = 0; k < ch; ++k) {
+        const float p = __fmul_rn(w, in[i * ch + k]);
+        if (p != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], p);
+    }
+}
+
+// seq_mask bit k set: channel k follows seqCompute (0.5*(n1+n2) evaluated in double, :510), else sseCompute.
+__global__ __launch_bounds__(kBlock) void k_blur(const float* __restrict__ old, float* __restrict__ nw,
+                                                 const int* __restrict__ nb1, const int* __restrict__ nb2, int size,
+                                                 int ch, unsigned seq_mask) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)size * ch) return;
+    const int v = (int)(t / ch), k = (int)(t % ch);
+    const float a = old[(int64_t)(nb1[v] + 1) * ch + k], b = old[(int64_t)(nb2[v] + 1) * ch + k];
+    const float o = old[(int64_t)(v + 1) * ch + k];
+    const float s = __fadd_rn(a, b);
+    float r;
+    if ((seq_mask >> k) & 1u)
+        r = (float)((double)o + 0.5 * (double)s);
+    else
+        r = __fadd_rn(o, __fmul_rn(0.5f, s));
+    nw[(int64_t)(v + 1) * ch + k] = r;
+}
+
+__global__ __launch_bounds__(kBlock) void k_slice(const int* __restrict__ offset, const float* __restrict__ bary,
+                                                  const float* __restrict__ vals, int64_t n_out, int d1, int ch,
+                                                  float alpha, unsigned seq_mask, float* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_out * ch) return;
+    const int64_t i = t / ch;
+    const int k = (int)(t % ch);
+    float acc = 0.f;
+    for (int r = 0; r < d1; ++r) {
+        const int o = offset[i * d1 + r] + 1;
+        const float w = bary[i * d1 + r];
+        const float v = vals[(int64_t)o * ch + k];
+        if ((seq_mask >> k) & 1u)
+            acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(w, v), alpha));   // (:526) w * value * alpha
+        else
+            acc = __fadd_rn(acc, __fmul_rn(__fmul_rn(w, alpha), v));   // (:588-590) (w*alpha) * value
+    }
+    out[t] = acc;
+}
+
+int lat_free(Lattice* L) {
+    void* ptrs[] = {L->feat, L->tkeys, L->slot_id, L->pslot, L->bary, L->dkeys, L->nb, L->count, L->vals, L->io};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    L->feat = nullptr; L->tkeys = nullptr; L->slot_id = nullptr; L->pslot = nullptr; L->bary = nullptr;
+    L->dkeys = nullptr; L->nb = nullptr; L->count = nullptr; L->vals = nullptr; L->io = nullptr;
+    L->n_alloc = L->nb_alloc = L->vals_elems = 0;
+    L->io_bytes = 0;
+    L->cap = 0;
+    return PRG_OK;
+}
+
+int lat_ensure_io(Lattice* L, size_t bytes) {
+    if (L->io && L->io_bytes >= bytes) return PRG_OK;
+    if (L->io) (void)hipFree(L->io);
+    L->io = nullptr;
+    L->io_bytes = 0;
+    PRG_HIP(hipMalloc((void**)&L->io, bytes));
+    L->io_bytes = bytes;
+    return PRG_OK;
+}
+
+// Build the lattice over L->feat (device, n x d float32).  Synchronises (the vertex count is needed on the host,
+// as in the reference where get_lattice_size() drives the with_blur decision, filterreg.py:90-91).
+int lat_build(Lattice* L, int64_t n, int d, int with_blur) {
+    PRG_REQUIRE(d >= 1 && d <= kMaxD, PRG_ERR_INVALID, "permutohedral lattice: feature dimension %d not in [1, 3]", d);
+    const int d1 = d + 1;
+    hipStream_t st = L->stream;
+    if (n > L->n_alloc || d != L->d) {
+        const int64_t na = n;
+        for (void* p : {(void*)L->tkeys, (void*)L->slot_id, (void*)L->pslot, (void*)L->bary, (void*)L->dkeys})
+            if (p) (void)hipFree(p);
+        int64_t cap = 1;
+        while (cap < 2 * na * d1) cap <<= 1;
+        L->cap = cap;
+        PRG_HIP(hipMalloc((void**)&L->tkeys, cap * sizeof(unsigned long long)));
+        PRG_HIP(hipMalloc((void**)&L->slot_id, cap * sizeof(int)));
+        PRG_HIP(hipMalloc((void**)&L->pslot, na * d1 * sizeof(int)));
+        PRG_HIP(hipMalloc((void**)&L->bary, na * d1 * sizeof(float)));
+        PRG_HIP(hipMalloc((void**)&L->dkeys, na * d1 * sizeof(unsigned long long)));
+        if (!L->count) PRG_HIP(hipMalloc((void**)&L->count, sizeof(int)));
+        L->n_alloc = na;
+    }
+    L->n = n;
+    L->d = d;
+    L->with_blur = with_blur;
+    PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, L->cap * sizeof(unsigned long long), st));
+    PRG_HIP(hipMemsetAsync(L->count, 0, sizeof(int), st));
+    // scale_factor[i] = float(1/sqrt((i+2)(i+1)) * inv_std_dev), inv_std_dev a float (:180-183)
+    const float inv_std = with_blur ? (float)(sqrt(2.0 / 3.0) * d1) : (float)(sqrt(1.0 / 6.0) * d1);
+    float sc[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < d; ++i) sc[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std);
+    const unsigned long long mask = (unsigned long long)L->cap - 1;
+    const unsigned nb = (unsigned)prg::ceil_div(n, kBlock);
+    if (d == 1) k_embed<1><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary);
+    else if (d == 2) k_embed<2><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary);
+    else k_embed<3><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary);
+    k_compact<<<(unsigned)prg::ceil_div(L->cap, kBlock), kBlock, 0, st>>>(L->tkeys, L->cap, L->slot_id, L->dkeys,
+                                                                         L->count);
+    k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(&L->size, L->count, sizeof(int), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    if (with_blur) {
+        const int64_t need = 2 * (int64_t)d1 * L->size;
+        if (need > L->nb_alloc) {
+            if (L->nb) (void)hipFree(L->nb);
+            L->nb = nullptr;
+            PRG_HIP(hipMalloc((void**)&L->nb, need * sizeof(int)));
+            L->nb_alloc = need;
+        }
+        int* nb1 = L->nb;
+        int* nb2 = L->nb + (int64_t)d1 * L->size;
+        const unsigned g = (unsigned)prg::ceil_div((int64_t)L->size * d1, kBlock);
+        if (d == 1) k_neighbours<1><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
+        else if (d == 2) k_neighbours<2><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
+        else k_neighbours<3><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
+        PRG_HIP(hipGetLastError());
+    }
+    return PRG_OK;
+}
+
+// Filter `ch` channels: in [n][ch] (device) -> out [n_out][ch] (device); only points >= first are splatted
+// (callers pass first > 0 only when the skipped rows are known to be zero).
+int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out, unsigned seq_mask, float* out) {
+    const int d1 = L->d + 1;
+    hipStream_t st = L->stream;
+    const int64_t plane = (int64_t)(L->size + 1) * ch;
+    if (2 * plane > L->vals_elems) {
+        if (L->vals) (void)hipFree(L->vals);
+        L->vals = nullptr;
+        PRG_HIP(hipMalloc((void**)&L->vals, 2 * plane * sizeof(float)));
+        L->vals_elems = 2 * plane;
+    }
+    float* a = L->vals;
+    float* b = L->vals + plane;
+    PRG_HIP(hipMemsetAsync(a, 0, 2 * plane * sizeof(float), st));
+    k_splat<<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, in, first,
+                                                                                    L->n, d1, ch, a);
+    if (L->with_blur) {
+        const int* nb1 = L->nb;
+        const int* nb2 = L->nb + (int64_t)d1 * L->size;
+        for (int j = 0; j < d1; ++j) {
+            k_blur<<<(unsigned)prg::ceil_div((int64_t)L->size * ch, kBlock), kBlock, 0, st>>>(
+                a, b, nb1 + (int64_t)j * L->size, nb2 + (int64_t)j * L->size, L->size, ch, seq_mask);
+            float* t = a; a = b; b = t;
+        }
+    }
+    const float alpha = 1.0f / (1.0f + powf(2.0f, (float)-L->d));
+    k_slice<<<(unsigned)prg::ceil_div(n_out * ch, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, a, n_out, d1, ch,
+                                                                           alpha, seq_mask, out);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+}  // namespace
+
+struct prg_ph {
+    Lattice L;
+};
+
+// =============================================================================================
+// FilterReg plan
+// =============================================================================================
+struct prg_filterreg {
+    Lattice L;
+    int64_t M = 0, N = 0;
+    int D = 0;
+    double* src = nullptr;   // [M][D] fp64 source
+    double* tgt = nullptr;   // [N][D] fp64 target
+    double* ts = nullptr;    // [M][3] fp64 transformed source
+    float* vin = nullptr;    // [M+N][5] values (source rows zero)
+    float* vout = nullptr;   // [M][5] filtered m0, m1(3), m2
+    double* state = nullptr; // [64]: 0..8 rot, 9..11 t, 12 sigma2, 13 q, 14 nonzero count, 15 sigma2_new
+    double* part = nullptr;  // block partials
+    int64_t part_blocks = 0;
+    bool have_src = false, have_tgt = false, have_estep = false;
+};
+
+namespace {
+
+constexpr int kFrComp = 28;  // 0 sw,1-3 sw*m,4-6 sw*t,7 sw2,8-10 sw2*m,11-13 sw2*t,14-22 sw2*m*t^T,23 q,24 s2num,25 m0m0,26 cnt
+
+__global__ __launch_bounds__(kBlock) void k_fr_transform(const double* __restrict__ src, int64_t m, int dim,
+                                                         const double* __restrict__ state, double* __restrict__ ts,
+                                                         float* __restrict__ feat) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const double sigma = sqrt(state[12]);
+    double y[3] = {0, 0, 0}, z[3] = {0, 0, 0};
+    for (int k = 0; k < dim; ++k) y[k] = src[i * dim + k];
+    for (int r = 0; r < dim; ++r) {
+        double acc = 0.0;
+        for (int k = 0; k < dim; ++k) acc += y[k] * state[3 * r + k];  // dot(points, rot.T), transformation.py:49-50
+        z[r] = acc + state[9 + r];
+    }
+    for (int k = 0; k < 3; ++k) ts[i * 3 + k] = z[k];
+    for (int k = 0; k < dim; ++k) feat[i * dim + k] = (float)(z[k] / sigma);  // fx = t_source / sigma, :84
+}
+
+__global__ __launch_bounds__(kBlock) void k_fr_target_features(const double* __restrict__ tgt, int64_t n, int dim,
+                                                               const double* __restrict__ state,
+                                                               float* __restrict__ feat /* at row M */) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double sigma = sqrt(state[12]);
+    for (int k = 0; k < dim; ++k) feat[i * dim + k] = (float)(tgt[i * dim + k] / sigma);  // fy = target / sigma, :85
+}
+
+// values [M+N][5]: source rows 0; target rows (1, y, |y|^2)   (filterreg.py:92-99)
+__global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__ tgt, int64_t m, int64_t n, int dim,
+                                                      float* __restrict__ vin) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m + n) return;
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (i >= m) {
+        const double* y = tgt + (i - m) * dim;
+        double s = 0.0;
+        v[0] = 1.0f;
+        for (int k = 0; k < dim; ++k) {
+            v[1 + k] = (float)y[k];
+            s += y[k] * y[k];
+        }
+        v[4] = (float)s;
+    }
+    for (int k = 0; k < 5; ++k) vin[i * 5 + k] = v[k];
+}
+
+// per-point M-step terms (filterreg.py:163-182, 190-195) -> block partials [nblk][kFrComp]
+__global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout, const double* __restrict__ ts,
+                                                     int64_t m, int dim, double c, const double* __restrict__ state,
+                                                     double* __restrict__ part) {
+    __shared__ double sh[4][kFrComp];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a[kFrComp];
+#pragma unroll
+    for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
+    const double sigma2 = state[12];
+    if (i < m) {
+        const float m0 = vout[i * 5];
+        if (m0 != 0.f) {
+            const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
+            const float m1[3] = {vout[i * 5 + 1], vout[i * 5 + 2], vout[i * 5 + 3]};
+            const float m2 = vout[i * 5 + 4];
+            float tg[3];  // m1m0 = m1 / m0 in float32 (:172)
+            for (int k = 0; k < 3; ++k) tg[k] = k < dim ? __fdiv_rn(m1[k], m0) : 0.f;
+            const double m0m0 = (double)m0 / ((double)m0 + c);       // :173
+            const double dr = sqrt(m0m0 / sigma2);                    // :174
+            const double w = (double)(float)dr;                        // the Kabsch binding casts to float32
+            const double w2 = w * w;
+            double mod[3];
+            for (int k = 0; k < 3; ++k) mod[k] = k < dim ? (double)(float)z[k] : 0.0;
+            a[0] = w;
+            a[7] = w2;
+            double r2 = 0.0, zz = 0.0, zm1 = 0.0;
+            for (int k = 0; k < 3; ++k) {
+                a[1 + k] = w * mod[k];
+                a[4 + k] = w * (double)tg[k];
+                a[8 + k] = w2 * mod[k];
+                a[11 + k] = w2 * (double)tg[k];
+                for (int j = 0; j < 3; ++j) a[14 + 3 * k + j] = w2 * mod[k] * (double)tg[j];
+                if (k < dim) {
+                    const double rx = dr * (z[k] - (double)tg[k]);
+                    r2 += rx * rx;
+                    zz += z[k] * z[k];
+                    zm1 += z[k] * (double)m1[k];
+                }
+            }
+            a[23] = sqrt(r2);                                                          // q term, :181-182
+            a[24] = ((double)m0 * zz - 2.0 * zm1 + (double)m2) / ((double)m0 + c);    // :192-194
+            a[25] = m0m0;
+            a[26] = 1.0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kFrComp; ++k) {
+        const double s = wave_sum(a[k]);
+        if (lane == 0) sh[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kFrComp)
+        part[(int64_t)blockIdx.x * kFrComp + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// weighted Kabsch from moments (cc/kabsch.cc:6-109): mom[0] sw, [1..3] sw*model, [4..6] sw*target, [7] sw2,
+// [8..10] sw2*model, [11..13] sw2*target, [14..22] sw2*model*target^T.  Centroids use w, the covariance w^2.
+__device__ void kabsch_from_moments(const double* mom, int dim, double (&dr)[3][3], double (&dt)[3]) {
+    for (int i = 0; i < 3; ++i) {
+        dt[i] = 0.0;
+        for (int j = 0; j < 3; ++j) dr[i][j] = (i == j) ? 1.0 : 0.0;
+    }
+    const double sw = mom[0];
+    if (sw != 0.0) {
+        double mc[3], tc[3], H[3][3];
+        for (int k = 0; k < 3; ++k) { mc[k] = mom[1 + k] / sw; tc[k] = mom[4 + k] / sw; }
+        const double sw2 = mom[7];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                H[i][j] = (mom[14 + 3 * i + j] - mc[i] * mom[11 + j] - mom[8 + i] * tc[j] + sw2 * mc[i] * tc[j]) / sw2;
+        if (dim == 3) {
+            double U[3][3], V[3][3], sv[3];
+            prg::jacobi_svd(H, 3, U, V, sv);
+            int jmin = 0;
+            for (int j = 1; j < 3; ++j)
+                if (sv[j] < sv[jmin]) jmin = j;
+            const double dd = prg::det3(U, 3) * prg::det3(V, 3);  // det(U V), kabsch.cc:48
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double r = 0.0;
+                    for (int k = 0; k < 3; ++k) r += (k == jmin ? dd : 1.0) * V[i][k] * U[j][k];  // V diag U^T
+                    dr[i][j] = r;
+                }
+        } else {
+            const double ang = atan2(H[0][1] - H[1][0], H[0][0] + H[1][1]);  // kabsch.cc:98
+            dr[0][0] = dr[1][1] = cos(ang);
+            dr[0][1] = -sin(ang);
+            dr[1][0] = sin(ang);
+        }
+        for (int i = 0; i < 3; ++i) {
+            double r = 0.0;
+            for (int k = 0; k < 3; ++k) r += dr[i][k] * mc[k];
+            dt[i] = tc[i] - r;
+        }
+    }
+}
+
+// weighted Kabsch from the moments (cc/kabsch.cc:6-109) + composition (filterreg.py:180) - one workgroup
+__global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__ part, int nblk, int dim,
+                                                      int update_sigma2, double* __restrict__ state) {
+    __shared__ double sh[8][32];
+    __shared__ double mom[32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double s = 0.0;
+    if (c < kFrComp)
+        for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * kFrComp + c];
+    sh[slice][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x];
+        mom[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    state[14] = mom[26];
+    if (mom[26] == 0.0) {  // every m0 == 0: keep the previous transform, q = None (:167-168)
+        state[13] = nan("");
+        state[16] = 0.0;
+        return;
+    }
+    state[16] = 1.0;
+    double dr[3][3], dt[3];
+    kabsch_from_moments(mom, dim, dr, dt);
+    // rot = dr @ rot_p ; t = t_p @ dr^T + dt   (filterreg.py:180)
+    double rp[3][3], tp[3], rn[3][3], tn[3];
+    for (int i = 0; i < 3; ++i) {
+        tp[i] = state[9 + i];
+        for (int j = 0; j < 3; ++j) rp[i][j] = state[3 * i + j];
+    }
+    for (int i = 0; i < 3; ++i) {
+        double tt = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            double r = 0.0;
+            for (int k = 0; k < 3; ++k) r += dr[i][k] * rp[k][j];
+            rn[i][j] = r;
+            tt += dr[i][j] * tp[j];
+        }
+        tn[i] = tt + dt[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        state[9 + i] = tn[i];
+        for (int j = 0; j < 3; ++j) state[3 * i + j] = rn[i][j];
+    }
+    state[13] = mom[23];
+    state[15] = update_sigma2 ? mom[24] / (3.0 * mom[25]) : state[12];  // :192-195 (3.0 hard-coded there)
+}
+
+// stand-alone Kabsch: moments of (model, target, weight) float32 clouds -> partials [nblk][kFrComp]
+__global__ __launch_bounds__(kBlock) void k_kabsch_terms(const float* __restrict__ model,
+                                                         const float* __restrict__ target,
+                                                         const float* __restrict__ weight, int64_t n, int dim,
+                                                         double* __restrict__ part) {
+    __shared__ double sh[4][kFrComp];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a[kFrComp];
+#pragma unroll
+    for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
+    if (i < n) {
+        const double w = weight[i], w2 = w * w;
+        double mod[3] = {0, 0, 0}, tg[3] = {0, 0, 0};
+        for (int k = 0; k < dim; ++k) { mod[k] = model[i * dim + k]; tg[k] = target[i * dim + k]; }
+        a[0] = w;
+        a[7] = w2;
+        for (int k = 0; k < 3; ++k) {
+            a[1 + k] = w * mod[k];
+            a[4 + k] = w * tg[k];
+            a[8 + k] = w2 * mod[k];
+            a[11 + k] = w2 * tg[k];
+            for (int j = 0; j < 3; ++j) a[14 + 3 * k + j] = w2 * mod[k] * tg[j];
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kFrComp; ++k) {
+        const double s = wave_sum(a[k]);
+        if (lane == 0) sh[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kFrComp)
+        part[(int64_t)blockIdx.x * kFrComp + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(kBlock) void k_kabsch_finish(const double* __restrict__ part, int nblk, int dim,
+                                                          double* __restrict__ out) {
+    __shared__ double sh[8][32];
+    __shared__ double mom[32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double s = 0.0;
+    if (c < kFrComp)
+        for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * kFrComp + c];
+    sh[slice][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x];
+        mom[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double dr[3][3], dt[3];
+    kabsch_from_moments(mom, dim, dr, dt);
+    for (int i = 0; i < 3; ++i) {
+        out[9 + i] = dt[i];
+        for (int j = 0; j < 3; ++j) out[3 * i + j] = dr[i][j];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// stand-alone lattice (gaussian_filtering.Permutohedral)
+// ---------------------------------------------------------------------------------------------
+int prg_ph_create(prg_ph** out, int device, void* hip_stream) {
+    PRG_REQUIRE(out != nullptr, PRG_ERR_INVALID, "prg_ph_create: out is NULL");
+    int count = 0;
+    PRG_HIP(hipGetDeviceCount(&count));
+    PRG_REQUIRE(device >= 0 && device < count, PRG_ERR_INVALID, "prg_ph_create: device %d out of range", device);
+    prg_ph* h = new (std::nothrow) prg_ph();
+    PRG_REQUIRE(h != nullptr, PRG_ERR_NOMEM, "prg_ph_create: out of host memory");
+    h->L.device = device;
+    h->L.stream = (hipStream_t)hip_stream;
+    *out = h;
+    return PRG_OK;
+}
+
+int prg_ph_destroy(prg_ph* h) {
+    if (!h) return PRG_OK;
+    prg::DeviceGuard g(h->L.device);
+    (void)hipStreamSynchronize(h->L.stream);
+    lat_free(&h->L);
+    delete h;
+    return PRG_OK;
+}
+
+int prg_ph_init(prg_ph* h, const float* points_hd, int64_t n, int dim, int with_blur) {
+    PRG_REQUIRE(h && points_hd, PRG_ERR_INVALID, "prg_ph_init: NULL argument");
+    PRG_REQUIRE(n > 0 && dim >= 1 && dim <= kMaxD, PRG_ERR_INVALID,
+                "prg_ph_init: need n > 0 and feature dimension in [1, 3] (got n=%lld d=%d)", (long long)n, dim);
+    prg::DeviceGuard g(h->L.device);
+    Lattice* L = &h->L;
+    if (L->feat) (void)hipFree(L->feat);
+    L->feat = nullptr;
+    PRG_HIP(hipMalloc((void**)&L->feat, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMemcpyAsync(L->feat, points_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, L->stream));
+    return lat_build(L, n, dim, with_blur ? 1 : 0);
+}
+
+int prg_ph_lattice_size(prg_ph* h, int* size) {
+    PRG_REQUIRE(h && size, PRG_ERR_INVALID, "prg_ph_lattice_size: NULL argument");
+    PRG_REQUIRE(h->L.n > 0, PRG_ERR_STATE, "prg_ph_lattice_size: lattice not initialised");
+    *size = h->L.size;
+    return PRG_OK;
+}
+
+int prg_ph_filter(prg_ph* h, const float* values_hd, int channels, float* out_hd) {
+    PRG_REQUIRE(h && values_hd && out_hd, PRG_ERR_INVALID, "prg_ph_filter: NULL argument");
+    PRG_REQUIRE(h->L.n > 0, PRG_ERR_STATE, "prg_ph_filter: lattice not initialised");
+    PRG_REQUIRE(channels >= 1 && channels <= 32, PRG_ERR_INVALID, "prg_ph_filter: channels must be in [1, 32]");
+    prg::DeviceGuard g(h->L.device);
+    Lattice* L = &h->L;
+    const size_t nb = (size_t)L->n * channels * sizeof(float);
+    PRG_TRY(lat_ensure_io(L, 2 * nb));
+    float* din = L->io;
+    float* dout = L->io + (size_t)L->n * channels;
+    PRG_HIP(hipMemcpyAsync(din, values_hd, nb, hipMemcpyDefault, L->stream));
+    // <= 2 channels take the reference's seqCompute arithmetic, more take sseCompute (permutohedral.cpp:612-615)
+    const unsigned seq_mask = channels <= 2 ? 0xFFFFFFFFu : 0u;
+    PRG_TRY(lat_filter(L, din, channels, 0, L->n, seq_mask, dout));
+    PRG_HIP(hipMemcpyAsync(out_hd, dout, nb, hipMemcpyDefault, L->stream));
+    PRG_HIP(hipStreamSynchronize(L->stream));
+    return PRG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FilterReg plan
+// ---------------------------------------------------------------------------------------------
+int prg_fr_create(prg_filterreg** out, int device, void* hip_stream) {
+    PRG_REQUIRE(out != nullptr, PRG_ERR_INVALID, "prg_fr_create: out is NULL");
+    int count = 0;
+    PRG_HIP(hipGetDeviceCount(&count));
+    PRG_REQUIRE(device >= 0 && device < count, PRG_ERR_INVALID, "prg_fr_create: device %d out of range", device);
+    prg::DeviceGuard g(device);
+    prg_filterreg* h = new (std::nothrow) prg_filterreg();
+    PRG_REQUIRE(h != nullptr, PRG_ERR_NOMEM, "prg_fr_create: out of host memory");
+    h->L.device = device;
+    h->L.stream = (hipStream_t)hip_stream;
+    hipError_t e = hipMalloc((void**)&h->state, 64 * sizeof(double));
+    if (e != hipSuccess) {
+        delete h;
+        prg::set_error("prg_fr_create: hipMalloc failed: %s", hipGetErrorString(e));
+        return PRG_ERR_HIP;
+    }
+    (void)hipMemsetAsync(h->state, 0, 64 * sizeof(double), h->L.stream);
+    *out = h;
+    return PRG_OK;
+}
+
+int prg_fr_destroy(prg_filterreg* h) {
+    if (!h) return PRG_OK;
+    prg::DeviceGuard g(h->L.device);
+    (void)hipStreamSynchronize(h->L.stream);
+    lat_free(&h->L);
+    for (void* p : {(void*)h->src, (void*)h->tgt, (void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->state,
+                    (void*)h->part})
+        if (p) (void)hipFree(p);
+    delete h;
+    return PRG_OK;
+}
+
+static int fr_alloc(prg_filterreg* h) {
+    if (!(h->have_src && h->have_tgt)) return PRG_OK;
+    const int64_t tot = h->M + h->N;
+    for (void* p : {(void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->part, (void*)h->L.feat})
+        if (p) (void)hipFree(p);
+    h->ts = nullptr; h->vin = nullptr; h->vout = nullptr; h->part = nullptr; h->L.feat = nullptr;
+    PRG_HIP(hipMalloc((void**)&h->ts, (size_t)h->M * 3 * sizeof(double)));
+    PRG_HIP(hipMalloc((void**)&h->vin, (size_t)tot * 5 * sizeof(float)));
+    PRG_HIP(hipMalloc((void**)&h->vout, (size_t)h->M * 5 * sizeof(float)));
+    h->part_blocks = prg::ceil_div(h->M, kBlock);
+    PRG_HIP(hipMalloc((void**)&h->part, (size_t)h->part_blocks * kFrComp * sizeof(double)));
+    PRG_HIP(hipMalloc((void**)&h->L.feat, (size_t)tot * h->D * sizeof(float)));
+    k_fr_values<<<(unsigned)prg::ceil_div(tot, kBlock), kBlock, 0, h->L.stream>>>(h->tgt, h->M, h->N, h->D, h->vin);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int prg_fr_set_source(prg_filterreg* h, const double* source_hd, int64_t m, int dim) {
+    PRG_REQUIRE(h && source_hd, PRG_ERR_INVALID, "prg_fr_set_source: NULL argument");
+    PRG_REQUIRE(m > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID, "prg_fr_set_source: need m > 0, dim in {2,3}");
+    PRG_REQUIRE(!h->have_tgt || h->D == dim, PRG_ERR_INVALID, "prg_fr_set_source: dim mismatch with target");
+    prg::DeviceGuard g(h->L.device);
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    if (h->src) (void)hipFree(h->src);
+    h->src = nullptr;
+    PRG_HIP(hipMalloc((void**)&h->src, (size_t)m * dim * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(h->src, source_hd, (size_t)m * dim * sizeof(double), hipMemcpyDefault, h->L.stream));
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    h->M = m;
+    h->D = dim;
+    h->have_src = true;
+    h->have_estep = false;
+    return fr_alloc(h);
+}
+
+int prg_fr_set_target(prg_filterreg* h, const double* target_hd, int64_t n, int dim) {
+    PRG_REQUIRE(h && target_hd, PRG_ERR_INVALID, "prg_fr_set_target: NULL argument");
+    PRG_REQUIRE(n > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID, "prg_fr_set_target: need n > 0, dim in {2,3}");
+    PRG_REQUIRE(!h->have_src || h->D == dim, PRG_ERR_INVALID, "prg_fr_set_target: dim mismatch with source");
+    prg::DeviceGuard g(h->L.device);
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    if (h->tgt) (void)hipFree(h->tgt);
+    h->tgt = nullptr;
+    PRG_HIP(hipMalloc((void**)&h->tgt, (size_t)n * dim * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(h->tgt, target_hd, (size_t)n * dim * sizeof(double), hipMemcpyDefault, h->L.stream));
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    h->N = n;
+    h->D = dim;
+    h->have_tgt = true;
+    h->have_estep = false;
+    return fr_alloc(h);
+}
+
+int prg_fr_set_state(prg_filterreg* h, const double* rot9, const double* t3, double sigma2) {
+    PRG_REQUIRE(h && rot9 && t3, PRG_ERR_INVALID, "prg_fr_set_state: NULL argument");
+    PRG_REQUIRE(sigma2 > 0.0, PRG_ERR_INVALID, "prg_fr_set_state: sigma2 must be > 0 (got %g)", sigma2);
+    prg::DeviceGuard g(h->L.device);
+    double buf[13];
+    for (int i = 0; i < 9; ++i) buf[i] = rot9[i];
+    for (int i = 0; i < 3; ++i) buf[9 + i] = t3[i];
+    buf[12] = sigma2;
+    PRG_HIP(hipMemcpyAsync(h->state, buf, sizeof(buf), hipMemcpyHostToDevice, h->L.stream));
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    return PRG_OK;
+}
+
+int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_blur) {
+    PRG_REQUIRE(h && h->have_src && h->have_tgt, PRG_ERR_STATE, "prg_fr_estep: clouds not set");
+    prg::DeviceGuard g(h->L.device);
+    hipStream_t st = h->L.stream;
+    const int64_t tot = h->M + h->N;
+    k_fr_transform<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, st>>>(h->src, h->M, h->D, h->state, h->ts,
+                                                                            h->L.feat);
+    k_fr_target_features<<<(unsigned)prg::ceil_div(h->N, kBlock), kBlock, 0, st>>>(h->tgt, h->N, h->D, h->state,
+                                                                                  h->L.feat + h->M * h->D);
+    PRG_HIP(hipGetLastError());
+    int blur = 1;
+    PRG_TRY(lat_build(&h->L, tot, h->D, 1));
+    if ((double)h->L.size > (double)h->N * alpha) {  // filterreg.py:90-91
+        blur = 0;
+        PRG_TRY(lat_build(&h->L, tot, h->D, 0));
+    }
+    // one fused 5-channel pass: channels 0 (m0) and 4 (m2) are single-channel filters in the reference
+    // (seqCompute arithmetic), channels 1..3 (m1) its 3-channel filter (sseCompute arithmetic)
+    PRG_TRY(lat_filter(&h->L, h->vin, 5, h->M, h->M, 0x11u, h->vout));
+    if (lattice_size) *lattice_size = h->L.size;
+    if (with_blur) *with_blur = blur;
+    h->have_estep = true;
+    return PRG_OK;
+}
+
+int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd) {
+    PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_fr_get_estep: no E-step has been run");
+    prg::DeviceGuard g(h->L.device);
+    hipStream_t st = h->L.stream;
+    const size_t pitch = 5 * sizeof(float);
+    if (m0_hd) PRG_HIP(hipMemcpy2DAsync(m0_hd, sizeof(float), h->vout, pitch, sizeof(float), h->M, hipMemcpyDefault, st));
+    if (m1_hd)
+        PRG_HIP(hipMemcpy2DAsync(m1_hd, h->D * sizeof(float), h->vout + 1, pitch, h->D * sizeof(float), h->M,
+                                 hipMemcpyDefault, st));
+    if (m2_hd) PRG_HIP(hipMemcpy2DAsync(m2_hd, sizeof(float), h->vout + 4, pitch, sizeof(float), h->M, hipMemcpyDefault, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host) {
+    PRG_REQUIRE(h && h->have_estep && out_host, PRG_ERR_STATE, "prg_fr_mstep: run prg_fr_estep first");
+    PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep: w must be in [0, 1) (got %g)", w);
+    prg::DeviceGuard g(h->L.device);
+    hipStream_t st = h->L.stream;
+    double sigma2 = 0.0;
+    PRG_HIP(hipMemcpyAsync(&sigma2, h->state + 12, sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    // c = w/(1-w) * n/m * (2 sigma2 pi)^(dim/2)   (filterreg.py:164)
+    const double c = w / (1.0 - w) * (double)h->N / (double)h->M * pow(2.0 * sigma2 * M_PI, h->D / 2.0);
+    const int nblk = (int)h->part_blocks;
+    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, h->D, c, h->state, h->part);
+    k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, h->state);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_host, h->state, 17 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+// stand-alone weighted Kabsch (probreg/cc/kabsch.cc:6-109 behind _kabsch.kabsch / kabsch2d)
+int prg_kabsch_weighted(int device, void* hip_stream, const float* model_hd, const float* target_hd,
+                        const float* weight_hd, int64_t n, int dim, double* rot_host, double* t_host) {
+    PRG_REQUIRE(model_hd && target_hd && weight_hd && rot_host && t_host, PRG_ERR_INVALID,
+                "prg_kabsch_weighted: NULL argument");
+    PRG_REQUIRE(n > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID, "prg_kabsch_weighted: need n > 0, dim in {2,3}");
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_kabsch_weighted: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int nblk = (int)prg::ceil_div(n, kBlock);
+    struct Tmp {
+        void* p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } bm, bt, bw, bp, bo;
+    PRG_HIP(hipMalloc(&bm.p, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bt.p, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bw.p, (size_t)n * sizeof(float)));
+    PRG_HIP(hipMalloc(&bp.p, (size_t)nblk * kFrComp * sizeof(double)));
+    PRG_HIP(hipMalloc(&bo.p, 12 * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(bm.p, model_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bt.p, target_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bw.p, weight_hd, (size_t)n * sizeof(float), hipMemcpyDefault, st));
+    k_kabsch_terms<<<nblk, kBlock, 0, st>>>((const float*)bm.p, (const float*)bt.p, (const float*)bw.p, n, dim,
+                                            (double*)bp.p);
+    k_kabsch_finish<<<1, kBlock, 0, st>>>((const double*)bp.p, nblk, dim, (double*)bo.p);
+    PRG_HIP(hipGetLastError());
+    double out[12];
+    PRG_HIP(hipMemcpyAsync(out, bo.p, sizeof(out), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < dim; ++i) {
+        t_host[i] = out[9 + i];
+        for (int j = 0; j < dim; ++j) rot_host[i * dim + j] = out[3 * i + j];
+    }
+    return PRG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,264 @@
+"""FilterReg (rigid, point-to-point) on MI355X - drop-in for ``probreg.filterreg`` on that path
+(reference probreg/filterreg.py:27-196, 269-317).
+
+The E-step (lattice build over [t_source; target]/sigma, the three Gaussian filters) and the M-step
+(weighted Kabsch, composition, sigma2 update) run in ``libprobreg_hip.so``; the Python loop mirrors
+``FilterReg.registration`` (filterreg.py:120-147) line by line, including its quirks: with the defaults
+sigma2 is never updated, the returned ``sigma2`` is the un-clamped one, and the driver stops with the
+previous ``q`` when every ``m0`` is zero.
+Out of scope here: ``objective_type='pt2pl'``, ``feature_fn`` other than identity,
+``DeformableKinematicFilterReg``.
+"""
+import abc
+import ctypes
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from . import math_utils as mu
+from . import transformation as tf
+from ._lib import check, lib, ptr
+from .engine import _current_device_and_stream
+from .log import log
+
+EstepResult = namedtuple("EstepResult", ["m0", "m1", "m2", "nx"])
+MstepResult = namedtuple("MstepResult", ["transformation", "sigma2", "q"])
+MstepResult.__doc__ = """Result of Maximization step.
+
+    Attributes:
+        transformation (tf.Transformation): Transformation from source to target.
+        sigma2 (float): Variance of Gaussian distribution.
+        q (float): Result of likelihood.
+"""
+
+
+def _as_points(x):
+    if x is None:
+        return None
+    if hasattr(x, "points") and not isinstance(x, np.ndarray):
+        x = x.points
+    return np.asarray(x, dtype=np.float64)
+
+
+def _identity(x):
+    return x
+
+
+class _Plan(object):
+    """One ``prg_filterreg`` handle."""
+
+    def __init__(self, device=None):
+        _lib.require_gpu()
+        dev, st = _current_device_and_stream(device)
+        self._h = ctypes.c_void_p()
+        check(lib.prg_fr_create(ctypes.byref(self._h), dev, ctypes.c_void_p(st)))
+        self.m = self.n = self.dim = 0
+
+    def set_source(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.m, self.dim = a.shape
+        check(lib.prg_fr_set_source(self._h, ptr(a), a.shape[0], a.shape[1]))
+
+    def set_target(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self.n = a.shape[0]
+        check(lib.prg_fr_set_target(self._h, ptr(a), a.shape[0], a.shape[1]))
+
+    def set_state(self, rot, t, sigma2):
+        r = np.identity(3)
+        d = np.asarray(rot).shape[0]
+        r[:d, :d] = rot
+        tt = np.zeros(3)
+        tt[:d] = t
+        check(lib.prg_fr_set_state(self._h, ptr(np.ascontiguousarray(r)), ptr(tt), float(sigma2)))
+
+    def estep(self, alpha=0.015):
+        size, blur = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib.prg_fr_estep(self._h, float(alpha), ctypes.byref(size), ctypes.byref(blur)))
+        return int(size.value), bool(blur.value)
+
+    def get_estep(self, want_m2):
+        m0 = np.empty(self.m, dtype=np.float32)
+        m1 = np.empty((self.m, self.dim), dtype=np.float32)
+        m2 = np.empty(self.m, dtype=np.float32) if want_m2 else None
+        check(lib.prg_fr_get_estep(self._h, ptr(m0), ptr(m1), ptr(m2) if want_m2 else None))
+        return m0, m1, m2
+
+    def mstep(self, w, update_sigma2):
+        out = np.zeros(17)
+        check(lib.prg_fr_mstep(self._h, float(w), 1 if update_sigma2 else 0, ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.prg_fr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+
+class FilterReg(abc.ABC):
+    """FilterReg (reference filterreg.py:45-147).
+
+    Args:
+        source (numpy.ndarray, optional): Source point cloud data.
+        target_normals (numpy.ndarray, optional): Normals of target points (pt2pl only - not built).
+        sigma2 (Float, optional): Variance parameter. If this variable is None,
+            the variance is initialised from the mean squared distance.
+        update_sigma2 (bool, optional): If this variable is True, Update sigma2 in the registration iteration.
+    """
+
+    def __init__(self, source=None, target_normals=None, sigma2=None, update_sigma2=False):
+        self._source = _as_points(source)
+        self._target_normals = target_normals
+        self._sigma2 = sigma2
+        self._update_sigma2 = update_sigma2
+        self._tf_type = None
+        self._tf_result = None
+        self._callbacks = []
+        self._plan = None
+
+    def set_source(self, source):
+        self._source = _as_points(source)
+
+    def set_target_normals(self, target_normals):
+        self._target_normals = target_normals
+
+    def set_callbacks(self, callbacks):
+        self._callbacks = callbacks
+
+    def _ensure_plan(self, target):
+        if self._plan is None:
+            self._plan = _Plan()
+        self._plan.set_source(self._source)
+        self._plan.set_target(target)
+        return self._plan
+
+    def expectation_step(self, t_source, target, y, sigma2, update_sigma2, objective_type="pt2pt", alpha=0.015):
+        """Expectation step (reference filterreg.py:78-108) on explicit arrays; returns float32 m0, m1, m2."""
+        assert t_source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
+        if objective_type != "pt2pt":
+            if objective_type == "pt2pl":
+                raise NotImplementedError("objective_type 'pt2pl' is a next-row (SURVEY.md 8f), not built yet.")
+            raise ValueError("Unknown objective_type: %s." % objective_type)
+        if y is not target and not np.array_equal(np.asarray(y), np.asarray(target)):
+            raise NotImplementedError("feature-space lattices (y != target) are a next-row (SURVEY.md 8f).")
+        plan = _Plan()
+        try:
+            plan.set_source(t_source)
+            plan.set_target(target)
+            plan.set_state(np.identity(t_source.shape[1]), np.zeros(t_source.shape[1]), sigma2)
+            plan.estep(alpha)
+            m0, m1, m2 = plan.get_estep(update_sigma2)
+        finally:
+            plan.close()
+        return EstepResult(m0, m1, m2, None)
+
+    def registration(self, target, w=0.0, objective_type="pt2pt", maxiter=50, tol=0.001, min_sigma2=1.0e-4,
+                     feature_fn=_identity):
+        """EM driver (reference filterreg.py:120-147)."""
+        assert self._tf_type is not None, "transformation type is None."
+        if objective_type != "pt2pt":
+            if objective_type == "pt2pl":
+                raise NotImplementedError("objective_type 'pt2pl' is a next-row (SURVEY.md 8f), not built yet.")
+            raise ValueError("Unknown objective_type: %s." % objective_type)
+        if feature_fn is not _identity:
+            probe = np.asarray(feature_fn(self._source[:2]))
+            if probe.shape != self._source[:2].shape or not np.array_equal(probe, self._source[:2]):
+                raise NotImplementedError("feature_fn other than identity is a next-row (SURVEY.md 8f).")
+        target = _as_points(target)
+        if self._source.shape[1] != target.shape[1] or target.shape[1] not in (2, 3):
+            raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
+        q = None
+        if self._sigma2 is None:
+            self._sigma2 = max(mu.squared_kernel_sum(self._source, target), min_sigma2)
+        plan = self._ensure_plan(target)
+        dim = target.shape[1]
+        res = MstepResult(self._tf_result, self._sigma2, None)
+        for i in range(maxiter):
+            plan.set_state(self._tf_result.rot, self._tf_result.t, self._sigma2)
+            plan.estep()
+            out = plan.mstep(w, self._update_sigma2)
+            if out[16] == 0.0:  # every m0 == 0 (filterreg.py:167-168, :136-138)
+                res = MstepResult(self._tf_result, self._sigma2, q)
+                break
+            rot = out[:9].reshape(3, 3)[:dim, :dim].copy()
+            t = out[9:9 + dim].copy()
+            res = MstepResult(tf.RigidTransformation(rot, t), float(out[15]), float(out[13]))
+            self._tf_result = res.transformation
+            self._sigma2 = max(res.sigma2, min_sigma2)
+            for c in self._callbacks:
+                c(self._tf_result)
+            log.debug("Iteration: {}, Criteria: {}".format(i, res.q))
+            if q is not None and abs(res.q - q) < tol:
+                break
+            q = res.q
+        return res
+
+
+class RigidFilterReg(FilterReg):
+    """Rigid FilterReg (reference filterreg.py:150-196)."""
+
+    def __init__(self, source=None, target_normals=None, sigma2=None, update_sigma2=False, tf_init_params={}):
+        super(RigidFilterReg, self).__init__(
+            source=source, target_normals=target_normals, sigma2=sigma2, update_sigma2=update_sigma2
+        )
+        self._tf_type = tf.RigidTransformation
+        self._tf_result = self._tf_type(**tf_init_params)
+        if self._source is not None and "rot" not in tf_init_params and self._source.shape[1] == 2:
+            # the reference needs explicit 2-D tf_init_params for 2-D data (examples/filterreg_rigid2d.py);
+            # default to the 2-D identity instead of failing with a shape error
+            self._tf_result = self._tf_type(np.identity(2), np.zeros(2))
+
+
+def registration_filterreg(source, target, target_normals=None, sigma2=None, update_sigma2=False, w=0,
+                           objective_type="pt2pt", maxiter=50, tol=0.001, min_sigma2=1.0e-4, feature_fn=_identity,
+                           callbacks=[], **kwargs):
+    """FilterReg registration (reference filterreg.py:269-317).
+
+    Args:
+        source (numpy.ndarray): Source point cloud data.
+        target (numpy.ndarray): Target point cloud data.
+        target_normals (numpy.ndarray, optional): Normal vectors of target point cloud (pt2pl: not built).
+        sigma2 (float, optional): Variance of GMM. If `sigma2` is `None`, it is initialised automatically.
+        update_sigma2 (bool, optional): update sigma2 every iteration.
+        w (float, optional): Weight of the uniform distribution, 0 < `w` < 1.
+        objective_type (str, optional): only 'pt2pt' is built.
+        maxitr (int, optional): Maximum number of iterations to EM algorithm.
+        tol (float, optional): Tolerance for termination.
+        min_sigma2 (float, optional): Minimum variance of GMM.
+        feature_fn (function, optional): Feature function (identity only).
+        callback (:obj:`list` of :obj:`function`, optional): Called after each iteration.
+
+    Keyword Args:
+        tf_init_params (dict, optional): Parameters to initialize transformation (for rigid).
+
+    Returns:
+        MstepResult: Result of the registration (transformation, sigma2, q)
+    """
+    frg = RigidFilterReg(_as_points(source), _as_points(target_normals), sigma2, update_sigma2, **kwargs)
+    frg.set_callbacks(callbacks)
+    return frg.registration(
+        _as_points(target), w=w, objective_type=objective_type, maxiter=maxiter, tol=tol, min_sigma2=min_sigma2,
+        feature_fn=feature_fn,
+    )
+
+
+def kabsch(model, target, weight):
+    """Weighted Kabsch on the GPU (reference ``_kabsch.kabsch`` / ``kabsch2d``, cc/kabsch.cc:6-109)."""
+    _lib.require_gpu()
+    model = np.ascontiguousarray(model, dtype=np.float32)
+    target = np.ascontiguousarray(target, dtype=np.float32)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    dim = model.shape[1]
+    dev, st = _current_device_and_stream()
+    rot = np.empty((dim, dim))
+    t = np.empty(dim)
+    check(lib.prg_kabsch_weighted(dev, ctypes.c_void_p(st), ptr(model), ptr(target), ptr(weight), model.shape[0], dim,
+                                  ptr(rot), ptr(t)))
+    return rot, t

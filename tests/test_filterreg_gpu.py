@@ -1,0 +1,161 @@
+"""Parity of the HIP FilterReg path (lattice, Kabsch, EM loop) with fixtures produced by the reference's
+filterreg.py + vendored permutohedral.cpp, and with the oracle on seeded inputs."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, Golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_TF = 1e-4
+TOL_SIGMA2 = 1e-5
+
+
+@pytest.fixture(scope="module")
+def fr_golden():
+    return Golden(os.path.join(GOLDEN_DIR, "filterreg_golden.npz"))
+
+
+def test_lattice_vs_reference_vectors(fr_golden):
+    """Same simplices and weights as the vendored lattice: vertex count identical, filter outputs equal up to
+    the float32 summation order of the splat (atomics)."""
+    from probreg_amd import gaussian_filtering as gf
+
+    for name in fr_golden.group("lattice"):
+        c = fr_golden.case("lattice/" + name)
+        lat = gf.Permutohedral(c["points"], "blur1" in name)
+        assert lat.get_lattice_size() == c["size"], name
+        for ch in (1, 3, 5):
+            got = lat.filter(c["values_ch%d" % ch])
+            want = c["out_ch%d" % ch]
+            assert got.shape == want.shape
+            assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)), (name, ch)
+
+
+def test_reference_unit_test_gaussian_filtering():
+    """Port of the reference's tests/test_gaussian_filtering.py:7-18 (rtol 0.3 against the direct transform)."""
+    from probreg_amd import gaussian_filtering as gf
+
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0.0, 10.0, (100, 1))
+    v0 = np.ones((100, 1))
+    v1 = rng.uniform(0.0, 1.0, (100, 1))
+    lat = gf.Permutohedral(pts)
+    out0, out1 = lat.filter(v0), lat.filter(v1)
+    k = np.exp(-((pts - pts.T) ** 2) / 2.0)
+    assert np.allclose(out1 / out0, (k @ v1) / (k @ v0), rtol=0.3)
+
+
+def test_estep_vs_oracle():
+    from oracle import filterreg_numpy as fo
+    from probreg_amd import filterreg, synthetic
+
+    src, tgt, _ = synthetic.filterreg_pair(6000, m=5000, seed=8)
+    for sigma2 in (0.05, 0.002):
+        info = []
+        want = fo.expectation_step(src, tgt, tgt, sigma2, True, info=info)
+        got = filterreg.RigidFilterReg(src).expectation_step(src, tgt, tgt, sigma2, True)
+        for a, b in ((got.m0, want.m0), (got.m1, want.m1), (got.m2, want.m2)):
+            assert a.dtype == np.float32
+            assert np.max(np.abs(a - b)) <= 3e-5 * np.max(np.abs(b)), sigma2
+
+
+def _kwargs(c):
+    kw = {}
+    for k in ("sigma2", "update_sigma2", "w", "maxiter", "tol"):
+        if "arg_" + k in c:
+            kw[k] = c["arg_" + k]
+    if "maxiter" in kw:
+        kw["maxiter"] = int(kw["maxiter"])
+    if "update_sigma2" in kw:
+        kw["update_sigma2"] = bool(kw["update_sigma2"])
+    return kw
+
+
+FIXED = ["bunny_update_sigma2_w005_k8", "bunny_fixed_sigma2_k5", "synth_5k_outliers_k6", "synth_ragged_k4",
+         "fish2d_k10"]
+
+
+@pytest.mark.parametrize("name", FIXED)
+def test_registration_fixed_iterations_vs_reference(fr_golden, name):
+    from probreg_amd import filterreg
+
+    c = fr_golden.case("reg/" + name)
+    kw = _kwargs(c)
+    if name.startswith("fish2d"):
+        kw["tf_init_params"] = {"rot": np.identity(2), "t": np.zeros(2)}
+    res = filterreg.registration_filterreg(c["source"], c["target"], **kw)
+    assert rel_err(res.transformation.rot, c["out_rot"]) < TOL_TF
+    assert np.max(np.abs(res.transformation.t - c["out_t"])) < TOL_TF * max(1.0, np.max(np.abs(c["out_t"])))
+    assert abs(res.sigma2 - c["out_sigma2"]) <= TOL_SIGMA2 * c["out_sigma2"] + 1e-12
+    assert abs(res.q - c["out_q"]) <= 1e-4 * abs(c["out_q"])
+
+
+@pytest.mark.parametrize("name", ["bunny_default", "bunny_update_sigma2"])
+def test_registration_defaults_vs_reference(fr_golden, name):
+    from probreg_amd import filterreg
+
+    c = fr_golden.case("reg/" + name)
+    niter = [0]
+    res = filterreg.registration_filterreg(c["source"], c["target"],
+                                           callbacks=[lambda t: niter.__setitem__(0, niter[0] + 1)], **_kwargs(c))
+    assert abs(niter[0] - c["out_niter"]) <= 2
+    # converged answers: the reference's own test tolerance is atol 0.2 on angles (tests/test_filterreg.py:27-29);
+    # we hold the converged transform to 1e-3 when the iteration counts differ, 1e-4 when they agree
+    tol = TOL_TF if niter[0] == c["out_niter"] else 1e-3
+    assert rel_err(res.transformation.rot, c["out_rot"]) < tol
+    assert np.max(np.abs(res.transformation.t - c["out_t"])) < tol
+
+
+def test_kabsch_vs_oracle():
+    from oracle import filterreg_numpy as fo
+    from probreg_amd import filterreg
+
+    rng = np.random.default_rng(12)
+    a = rng.normal(size=(5000, 3))
+    th = 0.3
+    r = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    b = a @ r.T + np.array([0.2, -0.1, 0.3]) + rng.normal(scale=0.01, size=a.shape)
+    w = rng.uniform(0.1, 2.0, 5000)
+    rr, tt = filterreg.kabsch(a, b, w)
+    ro, to = fo.kabsch_f32(a, b, w)  # float32 sequential sums in the reference -> 1e-5 agreement
+    assert np.max(np.abs(rr - ro)) < 2e-5 and np.max(np.abs(tt - to)) < 2e-5
+    r2, t2 = filterreg.kabsch(a[:, :2], b[:, :2], w)
+    ro2, to2 = fo.kabsch2d_f32(a[:, :2], b[:, :2], w)
+    assert np.max(np.abs(r2 - ro2)) < 2e-5 and np.max(np.abs(t2 - to2)) < 2e-5
+
+
+def test_all_m0_zero_keeps_previous_transform():
+    """filterreg.py:167-168 / 136-138: if no source point sees any target mass the driver stops and returns
+    the previous transformation with the previous q (None on the first iteration)."""
+    from probreg_amd import filterreg
+
+    src = np.random.default_rng(0).uniform(size=(200, 3))
+    tgt = src + 1000.0  # far away: with a tiny fixed sigma2 no lattice vertex is shared
+    res = filterreg.registration_filterreg(src, tgt, sigma2=1e-4, maxiter=3)
+    assert res.q is None
+    assert np.allclose(res.transformation.rot, np.identity(3)) and np.allclose(res.transformation.t, 0.0)
+
+
+def test_config_c4_size_smoke_properties():
+    """BASELINE config C4 (N = M = 500k, 5 % outliers): a few iterations run, the rotation stays orthonormal,
+    the lattice shrinks the error of the recovered rotation."""
+    from probreg_amd import filterreg, synthetic
+
+    src, tgt, (r, t) = synthetic.filterreg_pair(500000, seed=0)
+    res = filterreg.registration_filterreg(src, tgt, update_sigma2=True, w=0.05, maxiter=10, tol=-1.0)
+    rot = res.transformation.rot
+    assert np.allclose(rot @ rot.T, np.eye(3), atol=1e-9) and abs(np.linalg.det(rot) - 1.0) < 1e-9
+    assert np.max(np.abs(rot - r)) < 0.05
+
+
+def test_unsupported_paths_raise():
+    from probreg_amd import filterreg
+
+    x = np.random.default_rng(1).uniform(size=(50, 3))
+    with pytest.raises(ValueError):
+        filterreg.registration_filterreg(x, x, objective_type="point_to_line")
+    with pytest.raises(NotImplementedError):
+        filterreg.registration_filterreg(x, x, objective_type="pt2pl")
