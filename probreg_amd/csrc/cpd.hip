@@ -100,7 +100,7 @@ __global__ void k_zero_doubles(double* p, int n) {
 
 // sigma2_0 = [M sum|x|^2 + N sum|y|^2 - 2 (sum x).(sum y)] / (D M N)   (math_utils.py:28-29 in closed form)
 // q0 = 1 + N D / 2 log(sigma2_0)                                           (cpd.py:148)
-__global__ void k_init_params(const double* __restrict__ moments, const double* __restrict__ srcsum,
+__global__ void k_init_params(double* __restrict__ moments, const double* __restrict__ srcsum,
                               double* __restrict__ params, double m, double nglobal, int dim,
                               const double* __restrict__ init /* 16 doubles or null */) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -128,6 +128,8 @@ __global__ void k_init_params(const double* __restrict__ moments, const double* 
     }
     params[13] = sigma2;
     params[14] = 1.0 + nglobal * dim * 0.5 * log(sigma2);
+    // the target sums have served their purpose: keep the all-reduced block bounded over the EM iterations
+    for (int i = 24; i < PRG_NMOMENTS; ++i) moments[i] = 0.0;
 }
 
 // z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).
