@@ -29,8 +29,11 @@ WORKLOADS = {
     # name: (kind, N = M, description)
     "rigid_100k": ("rigid", 100000, "C1 RigidCPD fp32 synthetic N=M=100000 D=3 w=0"),
     "affine_200k": ("affine", 200000, "C2 AffineCPD fp32 synthetic N=M=200000 D=3 w=0"),
+    "nonrigid_50k": ("nonrigid", 50000, "C3 NonRigidCPD fp32 E-step / fp64 M-step synthetic N=M=50000 beta=2 lmd=2"),
+    "filterreg_500k": ("filterreg", 500000, "C4 FilterReg rigid pt2pt synthetic N=M=500000, 5% outliers, w=0.05"),
     "rigid_20k": ("rigid", 20000, "reduced RigidCPD fp32 synthetic N=M=20000 (debug only)"),
 }
+F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X f64 matrix peak (v_mfma_f64_16x16x4_f64, 32 FLOP/clk/SIMD at 2.4 GHz)
 
 
 def cpu_baseline(n_full):
@@ -62,6 +65,92 @@ def cpu_baseline(n_full):
     }
 
 
+def _base(args, metric, value, elapsed, desc, dtype):
+    return {"metric": metric, "value": value, "unit": "EM iterations/s", "n_gpus": 1, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": desc}}
+
+
+def bench_nonrigid(args, n, desc):
+    """C3: one step = E-step (fp32 sweeps) + fp64 Cholesky M-step (cpd.py:284-303)."""
+    import torch
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(n, seed=0)
+    reg = cpd.NonRigidCPD(src)
+    reg._initialize(tgt)
+    plan = reg._plan
+
+    def step():
+        plan.estep(0.0)
+        plan.mstep_nonrigid(2.0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # M-step alone (dominant): HIP-synchronised wall time around prg_cpd_mstep_nonrigid
+    plan.estep(0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.mstep_nonrigid(2.0)
+    torch.cuda.synchronize()
+    t_m = time.perf_counter() - t0
+    flops = n ** 3 / 3.0 + 3 * 2.0 * n * n * 3   # Cholesky + three G-times-(M x 3) products
+    out = _base(args, "EM iterations/sec (%s)" % desc, args.steps / elapsed, elapsed, desc, "f32 E-step / f64 M-step")
+    out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_nt_f64 (blocked Cholesky of S = cI + D^1/2 G D^1/2)",
+                       "achieved": flops / t_m / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops / t_m / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                       "algorithmic_flops_per_mstep": flops, "mstep_ms": 1e3 * t_m}
+    out["result"] = {"sigma2": float(plan.get_params()[13])}
+    return out
+
+
+def bench_filterreg(args, n, desc):
+    """C4: one step = lattice E-step + Kabsch M-step (filterreg.py:129-146), sigma2 updated every step."""
+    import torch
+    from probreg_amd import filterreg, math_utils as mu, synthetic
+
+    src, tgt, (r_true, _) = synthetic.filterreg_pair(n, seed=0)
+    reg = filterreg.RigidFilterReg(src, update_sigma2=True)
+    plan = reg._ensure_plan(tgt)
+    state = {"rot": np.identity(3), "t": np.zeros(3), "sigma2": max(mu.squared_kernel_sum(src, tgt), 1e-4)}
+    sizes = []
+
+    def step():
+        plan.set_state(state["rot"], state["t"], state["sigma2"])
+        size, _blur = plan.estep()
+        out = plan.mstep(0.05, True)
+        state["rot"], state["t"] = out[:9].reshape(3, 3).copy(), out[9:12].copy()
+        state["sigma2"] = max(out[15], 1e-4)
+        sizes.append(size)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    d, c = 3, 5
+    lat = float(np.mean(sizes[args.warmup:]))
+    alg = (2 * n) * (4 * d + 8 * (d + 1)) + n * (4 * c + 8 * (d + 1) + 8 * c * (d + 1)) \
+        + n * (8 * (d + 1) + 4 * c * (d + 1) + 4 * c) + (d + 1) * lat * c * 16
+    out = _base(args, "EM iterations/sec (%s)" % desc, args.steps / elapsed, elapsed, desc, "f32 lattice / f64 M-step")
+    out["roofline"] = {"bound": "hbm", "kernel": "whole lattice E-step (embed, hash, splat, blur, slice)",
+                       "achieved": alg / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_iteration": alg, "mean_lattice_vertices": lat}
+    out["result"] = {"sigma2": state["sigma2"], "rot_err_vs_truth": float(np.max(np.abs(state["rot"] - r_true)))}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +178,12 @@ def main():
     from probreg_amd import _lib, cpd, synthetic
 
     kind, n, desc = WORKLOADS[args.workload]
+    if kind in ("nonrigid", "filterreg"):
+        if world > 1:
+            raise SystemExit("%s runs as single-GPU replicas (DESIGN.md section 6)" % args.workload)
+        out = bench_nonrigid(args, n, desc) if kind == "nonrigid" else bench_filterreg(args, n, desc)
+        print(json.dumps(out))
+        return
     if kind == "rigid":
         src, tgt, truth = synthetic.rigid_pair(n, seed=0)
         reg = cpd.RigidCPD(src)

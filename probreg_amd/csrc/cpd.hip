@@ -15,6 +15,8 @@
 //   k_mstep    one thread, fp64: 3x3 one-sided Jacobi SVD / 3x3 solve, sigma2, q.
 #include <math.h>
 
+#include <algorithm>
+
 #include "cpd_plan.h"
 #include "cpd_sweeps.h"
 #include "small_linalg.h"
@@ -230,11 +232,11 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
                                                         int64_t m, const float4* __restrict__ src4,
                                                         const float4* __restrict__ z4, double* __restrict__ rowacc,
                                                         double* __restrict__ mompart) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     double a[kMomComp];
 #pragma unroll
     for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
-    if (i < m) {
+    // grid-stride over the rows: few workgroups -> few partials for the single-block final reduction
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double p1 = 0, u[3] = {0, 0, 0}, e = 0;
         for (int s = 0; s < nseg; ++s) {
             const float* __restrict__ o = rowpart + (int64_t)s * 5 * mcap + i;
@@ -250,9 +252,14 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
         double px[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) px[k] = u[k] + p1 * z[k];  // exact identity: sum P x = sum P (x - z) + p1 z
-        row_moment_terms(a, p1, px, y);
+        double t[kMomComp];
+#pragma unroll
+        for (int c = 0; c < kMomComp; ++c) t[c] = 0.0;
+        row_moment_terms(t, p1, px, y);
         // sum_n pt1_n |x_n|^2 restricted to this row: sum_n P |x|^2 = p1 |z|^2 + 2 z.u + e
-        a[22] = p1 * (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) + 2.0 * (z[0] * u[0] + z[1] * u[1] + z[2] * u[2]) + e;
+        t[22] = p1 * (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) + 2.0 * (z[0] * u[0] + z[1] * u[1] + z[2] * u[2]) + e;
+#pragma unroll
+        for (int c = 0; c < kMomComp; ++c) a[c] += t[c];
         rowacc[i] = p1;
         rowacc[mcap + i] = px[0];
         rowacc[2 * mcap + i] = px[1];
@@ -421,12 +428,15 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const float4* __restri
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
 // choose the segment count so that the grid has a few thousand blocks and segments stay long
+// Segment count for the streamed axis: ~1.5k streamed points per workgroup (tens of microseconds of work, so
+// the prologue / partial-store epilogue and the merge kernels stay small), but at least ~1k workgroups in
+// the grid (4 per CU) as long as segments keep >= 256 points.  C1 on one GPU -> 64 segments (12.5k
+// workgroups, measured best in profiles/r1_estep_tuning_sweep.log); an 8-way target shard -> 8.
 int auto_segments(int64_t nblk_x, int64_t stream_len) {
-    int64_t s = prg::ceil_div(6144, nblk_x);
-    int64_t max_by_len = stream_len / 256;
-    if (s > max_by_len) s = max_by_len;
-    if (s > 64) s = 64;
+    int64_t s = stream_len / 1536;
     if (s < 1) s = 1;
+    while (s * nblk_x < 1024 && stream_len / (s + 1) >= 256) ++s;
+    if (s > 64) s = 64;
     return (int)s;
 }
 
@@ -697,7 +707,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (rb < 0) prg::launch_rowpass_scalar(h, RB, SB, segB); else prg::launch_rowpass_packed(h, RB, SB, segB);
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
-    const int nblk = (int)prg::ceil_div(h->M, kBlock);
+    const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 128);
     k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart);
     k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);

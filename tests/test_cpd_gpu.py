@@ -388,3 +388,57 @@ def test_nonrigid_vs_oracle_medium():
     assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
     got = res.transformation.transform(src)
     assert np.max(np.abs(got - want)) < TOL_TF * np.max(np.abs(want - want.mean(0)))
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(2, 3), (1, 5), (7, 1), (513, 1025)])
+def test_tiny_and_odd_sizes_vs_oracle(m, n):
+    """Sizes below one chunk / one wave and just past a block boundary."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd
+
+    rng = np.random.default_rng(100 + m + n)
+    src = rng.normal(size=(m, 3))
+    tgt = rng.normal(size=(n, 3)) * 0.9 + 0.1
+    want = co.expectation_step(src, tgt, 0.7, 0.2)
+    got = cpd.RigidCPD().expectation_step(src, tgt, 0.7, 0.2)
+    assert np.max(np.abs(got.pt1 - want.pt1)) < 2e-6
+    assert rel_err(got.p1, want.p1) < 1e-5 and rel_err(got.px, want.px) < 1e-5
+
+
+def test_two_dimensional_clouds_vs_oracle():
+    """D = 2 (examples/cpd_affine2d.py): rigid and affine, fixed iterations."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd
+
+    rng = np.random.default_rng(77)
+    u = rng.uniform(0, 2 * np.pi, 800)
+    src = np.stack([np.cos(u) * (1 + 0.3 * np.cos(3 * u)), 0.6 * np.sin(u) * (1 + 0.2 * np.sin(2 * u))], axis=1)
+    th = 0.4
+    r = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    tgt = src[rng.permutation(800)[:700]] @ r.T * 1.1 + np.array([0.2, -0.1]) + rng.normal(scale=0.01, size=(700, 2))
+    for kind in ("rigid", "affine"):
+        p, s2, q, _ = co.registration(kind, src, tgt, w=0.05, maxiter=8, tol=-1.0, closed_form_init=True)
+        res = cpd.registration_cpd(src, tgt, kind, w=0.05, maxiter=8, tol=-1.0)
+        lin = res.transformation.rot if kind == "rigid" else res.transformation.b
+        assert lin.shape == (2, 2) and res.transformation.t.shape == (2,)
+        assert rel_err(lin, p["rot"] if kind == "rigid" else p["b"]) < TOL_TF
+        assert np.max(np.abs(res.transformation.t - p["t"])) < TOL_TF
+        assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
+
+
+def test_duplicate_points_and_wide_kernel():
+    """Exact duplicates in both clouds and a kernel much wider than the data (P nearly uniform)."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd
+
+    rng = np.random.default_rng(5)
+    base = rng.normal(size=(300, 3))
+    src = np.concatenate([base, base[:50]])
+    tgt = np.concatenate([base[::-1] + 0.01, base[:20] + 0.01])
+    want = co.expectation_step(src, tgt, 50.0, 0.3)
+    got = cpd.RigidCPD().expectation_step(src, tgt, 50.0, 0.3)
+    assert rel_err(got.p1, want.p1) < 1e-5 and rel_err(got.px, want.px) < 1e-5
+    assert np.max(np.abs(got.pt1 - want.pt1)) < 2e-6
