@@ -77,20 +77,21 @@ __global__ __launch_bounds__(kBlock) void k_cloud_sums(const float4* __restrict_
         sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
-// out[off + c] (=|+=) sum_b part[b][ncomp] ; one block of 256 threads, ncomp <= 32
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ part, int nblk, int ncomp,
-                                                            double* __restrict__ out, int off) {
-    __shared__ double sh[8][32];
+// out[off + c] = sum_b part[b][ncomp] ; one block of 1024 threads (32 slices x 32 components), ncomp <= 32
+constexpr int kRedBlock = 1024;
+__global__ __launch_bounds__(kRedBlock) void k_reduce_partials(const double* __restrict__ part, int nblk, int ncomp,
+                                                               double* __restrict__ out, int off) {
+    __shared__ double sh[32][33];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
     double s = 0.0;
     if (c < ncomp)
-        for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * ncomp + c];
+        for (int b = slice; b < nblk; b += 32) s += part[(int64_t)b * ncomp + c];
     sh[slice][c] = s;
     __syncthreads();
     if (threadIdx.x < ncomp) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x];
+        for (int k = 0; k < 32; ++k) t += sh[k][threadIdx.x];
         out[off + threadIdx.x] = t;
     }
 }
@@ -428,12 +429,12 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const float4* __restri
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
 // choose the segment count so that the grid has a few thousand blocks and segments stay long
-// Segment count for the streamed axis: ~1.5k streamed points per workgroup (tens of microseconds of work, so
-// the prologue / partial-store epilogue and the merge kernels stay small), but at least ~1k workgroups in
-// the grid (4 per CU) as long as segments keep >= 256 points.  C1 on one GPU -> 64 segments (12.5k
-// workgroups, measured best in profiles/r1_estep_tuning_sweep.log); an 8-way target shard -> 8.
+// Segment count for the streamed axis: ~3k streamed points per workgroup (tens of microseconds of work, so
+// the prologue / partial-store epilogue and the fp64 merge kernels stay small), but at least ~1k workgroups
+// in the grid (4 per CU) as long as segments keep >= 256 points.  C1 on one GPU -> 32 segments (6.3k
+// workgroups, profiles/r1_estep_tuning_sweep.log); an 8-way target shard (12.5k local columns) -> 6.
 int auto_segments(int64_t nblk_x, int64_t stream_len) {
-    int64_t s = stream_len / 1536;
+    int64_t s = stream_len / 3072;
     if (s < 1) s = 1;
     while (s * nblk_x < 1024 && stream_len / (s + 1) >= 256) ++s;
     if (s > 64) s = 64;
@@ -648,7 +649,7 @@ int prg_cpd_init_sums(prg_cpd* h) {
     const int nblk = (int)prg::ceil_div(h->N, kBlock);
     k_zero_doubles<<<1, 64, 0, h->stream>>>(h->moments, PRG_NMOMENTS);
     k_cloud_sums<<<nblk, kBlock, 0, h->stream>>>(h->tgt4, h->N, h->mompart);
-    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, 4, h->moments, 24);
+    k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, 4, h->moments, 24);
     PRG_HIP(hipGetLastError());
     return PRG_OK;
 }
@@ -665,7 +666,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
         PRG_HIP(hipMemcpyAsync(init_dev, init_params_host, 16 * sizeof(double), hipMemcpyHostToDevice, h->stream));
     }
     k_cloud_sums<<<nblk, kBlock, 0, h->stream>>>(h->src4, h->M, h->mompart);
-    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, 4, srcsum, 0);
+    k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, 4, srcsum, 0);
     k_init_params<<<1, 64, 0, h->stream>>>(h->moments, srcsum, h->params, (double)h->M, (double)h->Nglobal, h->D,
                                            init_dev);
     PRG_HIP(hipGetLastError());
@@ -707,10 +708,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (rb < 0) prg::launch_rowpass_scalar(h, RB, SB, segB); else prg::launch_rowpass_packed(h, RB, SB, segB);
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
-    const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 128);
+    const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
     k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart);
-    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
+    k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());
     h->have_estep = true;
@@ -827,7 +828,7 @@ int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p
     const int nblk = mom_blocks(h);
     k_moments_from_arrays<<<nblk, kBlock, 0, h->stream>>>(d_pt1, d_p1, d_px, h->D, h->M, h->N, h->src4, h->tgt4,
                                                           h->mompart);
-    k_reduce_partials<<<1, kBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
+    k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
     return PRG_OK;

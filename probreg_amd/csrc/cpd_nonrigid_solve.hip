@@ -14,6 +14,8 @@
 // (c ~ 1e-3, lambda_max(G) ~ M) which rules out an fp32 factorisation at the 1e-4 parity target.
 #include <math.h>
 
+#include <algorithm>
+
 #include "cpd_plan.h"
 
 namespace {
@@ -71,8 +73,20 @@ __global__ __launch_bounds__(kBlock) void k_build_s(const float* __restrict__ g,
 }
 
 // ---- diagonal block: Cholesky + triangular inverse in LDS ---------------------------------------
-// One workgroup.  a = S[k0:k0+128, k0:k0+128] -> L (written back, lower) and L^-1 (to linv, full 128x128
-// with an explicit zero upper triangle, row-major).
+// One workgroup (256 threads), a = S[k0:k0+128, k0:k0+128] in 132 KB of LDS -> L (written back, lower) and
+// L^-1 (to linv, full 128 x 128 row-major with an explicit zero upper triangle).
+// Both phases are blocked by 8 columns so that the sequential part is 16 steps, not 128: the 8 x 8 diagonal
+// block is factored / inverted redundantly by every thread in registers (36 doubles, static indexing), each
+// thread then owns one row below it, and the rank-8 trailing update is register tiled 4 x 4.
+constexpr int PB = 8;
+
+__device__ __forceinline__ void load_diag8(const double* a, int jb, double (&l)[PB][PB]) {
+#pragma unroll
+    for (int r = 0; r < PB; ++r)
+#pragma unroll
+        for (int c = 0; c < PB; ++c) l[r][c] = (c <= r) ? a[(jb + r) * LDP + jb + c] : 0.0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, int64_t ld, int64_t k0,
                                                       double* __restrict__ linv, int* __restrict__ info) {
     extern __shared__ double a[];  // [NB][LDP]
@@ -82,20 +96,80 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
         const int i = idx >> 7, j = idx & 127;
         a[i * LDP + j] = sblk[(int64_t)i * ld + j];
     }
-    const int tx = tid & 15, ty = tid >> 4;
-    for (int j = 0; j < NB; ++j) {
+    // ---------------- Cholesky, 16 panels of 8 columns ----------------
+    for (int jb = 0; jb < NB; jb += PB) {
         __syncthreads();
-        const double ajj = a[j * LDP + j];
-        if (!(ajj > 0.0) && tid == 0) atomicMax(info, (int)(k0 + j + 1));
-        const double d = sqrt(fabs(ajj) > 0.0 ? fabs(ajj) : 1.0);
-        const double rd = 1.0 / d;
+        double l[PB][PB];
+        load_diag8(a, jb, l);
+        const int i = jb + PB + tid;  // the row below the diagonal block this thread owns (if any)
+        const bool has_row = i < NB;
+        double x[PB];
+        if (has_row) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c) x[c] = a[i * LDP + jb + c];
+        }
+        __syncthreads();  // everybody holds the old diagonal block / its row in registers
+        double inv[PB];
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {  // Cholesky-Crout on the 8 x 8 block
+            double d = l[c][c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) d -= l[c][k] * l[c][k];
+            if (!(d > 0.0)) { bad = true; d = fabs(d) > 0.0 ? fabs(d) : 1.0; }
+            l[c][c] = sqrt(d);
+            inv[c] = 1.0 / l[c][c];
+#pragma unroll
+            for (int r = c + 1; r < PB; ++r) {
+                double t = l[r][c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) t -= l[r][k] * l[c][k];
+                l[r][c] = t * inv[c];
+            }
+        }
+        if (bad && tid == 0) atomicMax(info, (int)(k0 + jb + 1));
+        if (has_row) {  // x := x * L11^-T  (forward substitution along the row)
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {
+                double t = x[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) t -= x[k] * l[c][k];
+                x[c] = t * inv[c];
+                a[i * LDP + jb + c] = x[c];
+            }
+        }
+        if (tid == kBlock - 1) {
+#pragma unroll
+            for (int r = 0; r < PB; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) a[(jb + r) * LDP + jb + c] = l[r][c];
+        }
         __syncthreads();
-        if (tid == 0) a[j * LDP + j] = d;
-        for (int i = j + 1 + tid; i < NB; i += kBlock) a[i * LDP + j] *= rd;
-        __syncthreads();
-        for (int i = j + 1 + ty; i < NB; i += 16) {
-            const double aij = a[i * LDP + j];
-            for (int k = j + 1 + tx; k <= i; k += 16) a[i * LDP + k] -= aij * a[k * LDP + j];
+        // rank-8 update of the trailing lower triangle, 4 x 4 register tiles
+        const int t0 = jb + PB, nt = (NB - t0 + 3) >> 2;
+        for (int t = tid; t < nt * nt; t += kBlock) {
+            const int ti = t / nt, tk = t % nt;
+            if (tk > ti) continue;
+            const int i0 = t0 + 4 * ti, kk0 = t0 + 4 * tk;
+            double ai[4][PB], ak[4][PB];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < PB; ++c) {
+                    ai[r][c] = (i0 + r < NB) ? a[(i0 + r) * LDP + jb + c] : 0.0;
+                    ak[r][c] = (kk0 + r < NB) ? a[(kk0 + r) * LDP + jb + c] : 0.0;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (i0 + r < NB && kk0 + q <= i0 + r) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int c = 0; c < PB; ++c) acc += ai[r][c] * ak[q][c];
+                        a[(i0 + r) * LDP + kk0 + q] -= acc;
+                    }
+                }
         }
     }
     __syncthreads();
@@ -103,17 +177,57 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
         const int i = idx >> 7, j = idx & 127;
         if (j <= i) sblk[(int64_t)i * ld + j] = a[i * LDP + j];
     }
-    // in-place inverse of the lower triangle (column j uses the already inverted trailing block)
-    for (int j = NB - 1; j >= 0; --j) {
+    // ---------------- in-place inverse of the lower triangle, block columns from last to first ----------------
+    // with A11 the 8 x 8 diagonal block, A21 the rows below it and X22 = inv(A22) already in place:
+    //   new A21 = -X22 * A21 * inv(A11),  new A11 = inv(A11)
+    for (int jb = NB - PB; jb >= 0; jb -= PB) {
         __syncthreads();
-        const double ajj = 1.0 / a[j * LDP + j];
-        double t = 0.0;
-        const int i = tid;
-        if (i > j && i < NB)
-            for (int k = j + 1; k <= i; ++k) t += a[i * LDP + k] * a[k * LDP + j];
-        __syncthreads();
-        if (i > j && i < NB) a[i * LDP + j] = -t * ajj;
-        if (tid == 0) a[j * LDP + j] = ajj;
+        double l[PB][PB], li[PB][PB];
+        load_diag8(a, jb, l);
+#pragma unroll
+        for (int c = 0; c < PB; ++c) {  // li = inv(l), column by column (forward substitution)
+#pragma unroll
+            for (int r = 0; r < PB; ++r) {
+                if (r < c) { li[r][c] = 0.0; continue; }
+                double t = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < PB; ++k)
+                    if (k >= c && k < r) t -= l[r][k] * li[k][c];
+                li[r][c] = t / l[r][r];
+            }
+        }
+        const int i = jb + PB + tid;
+        const bool has_row = i < NB;
+        double z[PB];
+        if (has_row) {
+            double y[PB];
+#pragma unroll
+            for (int c = 0; c < PB; ++c) y[c] = 0.0;
+            for (int k = jb + PB; k <= i; ++k) {  // y = X22[i, :] * A21   (X22 lower triangular)
+                const double xik = a[i * LDP + k];
+#pragma unroll
+                for (int c = 0; c < PB; ++c) y[c] += xik * a[k * LDP + jb + c];
+            }
+#pragma unroll
+            for (int c = 0; c < PB; ++c) {  // z = -y * inv(A11)
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < PB; ++q)
+                    if (q >= c) t += y[q] * li[q][c];
+                z[c] = -t;
+            }
+        }
+        __syncthreads();  // every read of the old A21 / A11 is done
+        if (has_row) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c) a[i * LDP + jb + c] = z[c];
+        }
+        if (tid == kBlock - 1) {
+#pragma unroll
+            for (int r = 0; r < PB; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) a[(jb + r) * LDP + jb + c] = li[r][c];
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < NB * NB; idx += kBlock) {
@@ -123,9 +237,14 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 }
 
 // ---- NT GEMM on the f64 matrix cores ---------------------------------------------------------------
-// C[i][j] (op)= sum_k A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K = 128.
-//   MODE 0 (panel solve, X = A21 * Linv^T): C = A B^T, C aliases A (all loads finish before any store).
+// C[i][j] (op)= sum_{k < K} A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K a multiple of 16.
+//   MODE 0 (panel solve, X = A21 * Linv^T, K = 128): C = A B^T, C aliases A (all loads finish before any store).
 //   MODE 1 (trailing update, A22 -= L21 L21^T): C -= A B^T on the lower tiles, 1-D triangular grid.
+//   MODE 2 (update inside the outer panel): C -= A B^T on a (rows x few column tiles) grid, tiles above the
+//           diagonal skipped.
+// The outer panel is 512 columns wide (4 Cholesky blocks): the big MODE 1 update then runs with K = 512, i.e.
+// 4x fewer read-modify-write passes over the trailing matrix than with K = 128 - at K = 128 the update is
+// HBM bound (16 flop per byte of C traffic), at K = 512 it is bound by the matrix cores.
 // Wave w owns the 64 x 64 quadrant (w>>1, w&1) as 4 x 4 MFMA tiles of 16 x 16 (64 accumulator f64
 // per lane).  v_mfma_f64_16x16x4_f64 operand map: lane l supplies A[i = l&15][k = l>>4] and
 // B[k = l>>4][j = l&15]; the k index inside a 16-chunk is permuted (lane group kq holds
@@ -133,9 +252,14 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 // (two 16-byte loads) per 16-row strip.  C/D map: col = l&15, row = (l>>4) + 4 reg.
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, const double* bbase,
-                                                        int64_t lda, int64_t ldb, double* cbase, int64_t ldc) {
+                                                        int64_t lda, int64_t ldb, double* cbase, int64_t ldc,
+                                                        int kdim) {
     int by, bx;
-    if (MODE == 1) {
+    if (MODE == 2) {
+        by = blockIdx.x;
+        bx = blockIdx.y;
+        if (bx > by) return;
+    } else if (MODE == 1) {
         const int t = blockIdx.x;
         by = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while ((int64_t)(by + 1) * (by + 2) / 2 <= t) ++by;
@@ -155,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, con
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int kc = 0; kc < NB; kc += 16) {
+    for (int kc = 0; kc < kdim; kc += 16) {
         d4 af[4], bf[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -179,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, con
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 double* q = cp + (int64_t)(16 * i + 4 * r) * ldc + 16 * j;
-                if (MODE == 1)
+                if (MODE != 0)
                     *q -= acc[i][j][r];
                 else
                     *q = acc[i][j][r];
@@ -196,10 +320,14 @@ __global__ __launch_bounds__(384) void k_diag_solve(const double* __restrict__ l
     vin[r][c] = v[(k0 + r) * 3 + c];
     __syncthreads();
     double s = 0.0;
+    // the upper triangle of linv is stored as explicit zeros, so both loops can run over all 128 terms
+    // with independent loads (unrolled, pipelined) instead of a data-dependent trip count
     if (TRANS == 0) {
-        for (int k = 0; k <= r; ++k) s += linv[r * NB + k] * vin[k][c];
+#pragma unroll 16
+        for (int k = 0; k < NB; ++k) s += linv[r * NB + k] * vin[k][c];
     } else {
-        for (int k = r; k < NB; ++k) s += linv[k * NB + r] * vin[k][c];
+#pragma unroll 16
+        for (int k = 0; k < NB; ++k) s += linv[k * NB + r] * vin[k][c];
     }
     v[(k0 + r) * 3 + c] = s;
 }
@@ -366,17 +494,30 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
     if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));
     k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
 
-    // blocked Cholesky S = L L^T (lower, in place)
+    // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128
     const size_t lds = (size_t)NB * LDP * sizeof(double);
-    for (int64_t kb = 0; kb < nblk; ++kb) {
-        const int64_t k0 = kb * NB;
-        k_potrf_inv<<<1, kBlock, lds, st>>>(S, mp, k0, linv + (size_t)kb * NB * NB, info);
-        const int64_t below = nblk - kb - 1;
-        if (below > 0) {
-            double* a21 = S + (k0 + NB) * mp + k0;
-            k_gemm_nt_f64<0><<<(unsigned)below, kBlock, 0, st>>>(a21, linv + (size_t)kb * NB * NB, mp, NB, a21, mp);
-            const int64_t ntri = below * (below + 1) / 2;
-            k_gemm_nt_f64<1><<<(unsigned)ntri, kBlock, 0, st>>>(a21, a21, mp, mp, S + (k0 + NB) * mp + (k0 + NB), mp);
+    constexpr int64_t NBO = 512;
+    for (int64_t K0 = 0; K0 < mp; K0 += NBO) {
+        const int64_t kend = std::min<int64_t>(K0 + NBO, mp);
+        for (int64_t k0 = K0; k0 < kend; k0 += NB) {
+            double* lk = linv + (size_t)(k0 / NB) * NB * NB;
+            k_potrf_inv<<<1, kBlock, lds, st>>>(S, mp, k0, lk, info);
+            const int64_t below = (mp - k0 - NB) / NB;
+            if (below > 0) {
+                double* a21 = S + (k0 + NB) * mp + k0;
+                k_gemm_nt_f64<0><<<(unsigned)below, kBlock, 0, st>>>(a21, lk, mp, NB, a21, mp, NB);
+                const int64_t inner_cols = (kend - k0 - NB) / NB;  // remaining block columns of the outer panel
+                if (inner_cols > 0)
+                    k_gemm_nt_f64<2><<<dim3((unsigned)below, (unsigned)inner_cols), kBlock, 0, st>>>(
+                        a21, a21, mp, mp, S + (k0 + NB) * mp + (k0 + NB), mp, NB);
+            }
+        }
+        const int64_t rem = (mp - kend) / NB;
+        if (rem > 0) {
+            double* apan = S + kend * mp + K0;  // rows >= kend of the outer panel: L[kend:, K0:kend]
+            const int64_t ntri = rem * (rem + 1) / 2;
+            k_gemm_nt_f64<1><<<(unsigned)ntri, kBlock, 0, st>>>(apan, apan, mp, mp, S + kend * mp + kend, mp,
+                                                                (int)(kend - K0));
         }
     }
     // L L^T u = v

@@ -440,5 +440,7 @@ def test_duplicate_points_and_wide_kernel():
     tgt = np.concatenate([base[::-1] + 0.01, base[:20] + 0.01])
     want = co.expectation_step(src, tgt, 50.0, 0.3)
     got = cpd.RigidCPD().expectation_step(src, tgt, 50.0, 0.3)
-    assert rel_err(got.p1, want.p1) < 1e-5 and rel_err(got.px, want.px) < 1e-5
+    assert rel_err(got.p1, want.p1) < 1e-5
+    # px = sum_n P x_n nearly cancels here (uniform P, centred x): measure its error against p1 * |x|
+    assert np.max(np.abs(got.px - want.px)) < 1e-5 * np.max(want.p1) * np.max(np.abs(tgt))
     assert np.max(np.abs(got.pt1 - want.pt1)) < 2e-6
