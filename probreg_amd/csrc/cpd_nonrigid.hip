@@ -143,6 +143,10 @@ int nonrigid_gw(prg_cpd* h, const double* w3, double* out3) {
 }
 
 int nonrigid_free(prg_cpd* h) {
+    for (hipEvent_t e : h->nr_events) (void)hipEventDestroy(e);
+    h->nr_events.clear();
+    if (h->nr_stream2) (void)hipStreamDestroy(h->nr_stream2);
+    h->nr_stream2 = nullptr;
     if (h->nr_solve) (void)hipFree(h->nr_solve);
     h->nr_solve = nullptr;
     h->nr_solve_bytes = 0;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 }
 
 // ---- NT GEMM on the f64 matrix cores ---------------------------------------------------------------
-// C[i][j] (op)= sum_{k < K} A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K a multiple of 16.
+// C[i][j] (op)= sum_{k < K} A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K a multiple of 32.
 //   MODE 0 (panel solve, X = A21 * Linv^T, K = 128): C = A B^T, C aliases A (all loads finish before any store).
 //   MODE 1 (trailing update, A22 -= L21 L21^T): C -= A B^T on the lower tiles, 1-D triangular grid.
 //   MODE 2 (update inside the outer panel): C -= A B^T on a (rows x few column tiles) grid, tiles above the
@@ -279,20 +279,34 @@ __global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, con
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int kc = 0; kc < kdim; kc += 16) {
-        d4 af[4], bf[4];
+    // software pipelined over 16-wide k chunks: the operands of chunk c+1 are in flight while the 64 MFMAs
+    // (64 cycles each) of chunk c issue, so one wave per SIMD already keeps the matrix core busy
+    d4 af[2][4], bf[2][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            af[t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda + kc);
-            bf[t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb + kc);
+    for (int t = 0; t < 4; ++t) {
+        af[0][t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda);
+        bf[0][t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb);
+    }
+    for (int kc = 0; kc < kdim; kc += 32) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int cur = half, nxt = half ^ 1;
+            const int kn = kc + 16 * (half + 1);
+            if (kn < kdim) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    af[nxt][t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda + kn);
+                    bf[nxt][t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb + kn);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
     if (MODE == 0) __syncthreads();  // C aliases A: every wave's loads are done before anyone stores
     double* cp = cbase + ((int64_t)by * NB + wr * 64 + kq) * ldc + (int64_t)bx * NB + wc * 64 + li;
@@ -494,10 +508,25 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
     if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));
     k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
 
-    // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128
+    // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128.
+    // Look-ahead over two streams: the trailing update of outer panel J is split into U1 (the 512 columns of
+    // the next panel, plan stream) and U2 (everything to the right, side stream), so the latency-bound panel
+    // factorisation J+1 (potrf + panel solves) runs underneath U2(J) instead of leaving the GPU idle.
     const size_t lds = (size_t)NB * LDP * sizeof(double);
     constexpr int64_t NBO = 512;
-    for (int64_t K0 = 0; K0 < mp; K0 += NBO) {
+    const int64_t nouter = prg::ceil_div(mp, NBO);
+    if (!h->nr_stream2) PRG_HIP(hipStreamCreateWithFlags(&h->nr_stream2, hipStreamNonBlocking));
+    while ((int64_t)h->nr_events.size() < 2 * nouter + 1) {
+        hipEvent_t e;
+        PRG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->nr_events.push_back(e);
+    }
+    hipStream_t sb = h->nr_stream2;
+    PRG_HIP(hipEventRecord(h->nr_events[2 * nouter], st));
+    PRG_HIP(hipStreamWaitEvent(sb, h->nr_events[2 * nouter], 0));
+    int64_t last_u2 = -1;
+    for (int64_t J = 0; J < nouter; ++J) {
+        const int64_t K0 = J * NBO;
         const int64_t kend = std::min<int64_t>(K0 + NBO, mp);
         for (int64_t k0 = K0; k0 < kend; k0 += NB) {
             double* lk = linv + (size_t)(k0 / NB) * NB * NB;
@@ -513,13 +542,26 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
             }
         }
         const int64_t rem = (mp - kend) / NB;
-        if (rem > 0) {
-            double* apan = S + kend * mp + K0;  // rows >= kend of the outer panel: L[kend:, K0:kend]
-            const int64_t ntri = rem * (rem + 1) / 2;
-            k_gemm_nt_f64<1><<<(unsigned)ntri, kBlock, 0, st>>>(apan, apan, mp, mp, S + kend * mp + kend, mp,
-                                                                (int)(kend - K0));
+        if (rem <= 0) break;
+        const int kd = (int)(kend - K0);
+        double* apan = S + kend * mp + K0;  // rows >= kend of the outer panel: L[kend:, K0:kend]
+        PRG_HIP(hipEventRecord(h->nr_events[2 * J], st));
+        // U2(J): the sub-triangle right of the next panel, on the side stream
+        const int64_t r2 = rem - NBO / NB;
+        if (r2 > 0) {
+            PRG_HIP(hipStreamWaitEvent(sb, h->nr_events[2 * J], 0));
+            double* ap2 = apan + (NBO / NB) * NB * mp;
+            k_gemm_nt_f64<1><<<(unsigned)(r2 * (r2 + 1) / 2), kBlock, 0, sb>>>(
+                ap2, ap2, mp, mp, S + (kend + NBO) * mp + (kend + NBO), mp, kd);
+            PRG_HIP(hipEventRecord(h->nr_events[2 * J + 1], sb));
         }
+        // U1(J): the next panel's columns; it must see U2(J-1), which updated the same tiles
+        if (last_u2 >= 0) PRG_HIP(hipStreamWaitEvent(st, h->nr_events[2 * last_u2 + 1], 0));
+        k_gemm_nt_f64<2><<<dim3((unsigned)rem, (unsigned)std::min<int64_t>(NBO / NB, rem)), kBlock, 0, st>>>(
+            apan, apan, mp, mp, S + kend * mp + kend, mp, kd);
+        last_u2 = (r2 > 0) ? J : -1;
     }
+    if (last_u2 >= 0) PRG_HIP(hipStreamWaitEvent(st, h->nr_events[2 * last_u2 + 1], 0));
     // L L^T u = v
     for (int64_t kb = 0; kb < nblk; ++kb) {
         const int64_t k0 = kb * NB;

@@ -1,5 +1,7 @@
 // Internal definition of the CPD plan (opaque `prg_cpd` of include/probreg_hip.h).
 #pragma once
+#include <vector>
+
 #include "prg_common.h"
 
 // Row accumulator block: 4 fp64 planes of Mcap (p1, px0, px1, px2), written by the moment kernel.
@@ -49,6 +51,8 @@ struct prg_cpd {
     size_t nr_work_bytes = 0;
     double* nr_solve = nullptr;  // M-step workspace: S (fp64 M x M), block inverses, vectors
     size_t nr_solve_bytes = 0;
+    hipStream_t nr_stream2 = nullptr;      // side stream of the look-ahead Cholesky
+    std::vector<hipEvent_t> nr_events;
 
     bool have_source = false, have_target = false, have_estep = false;
     double last_w = 0.0;
