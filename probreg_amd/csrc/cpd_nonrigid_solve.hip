@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 }
 
 // ---- NT GEMM on the f64 matrix cores ---------------------------------------------------------------
-// C[i][j] (op)= sum_{k < K} A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K a multiple of 32.
+// C[i][j] (op)= sum_{k < K} A[i][k] * B[j][k] for one 128 x 128 tile per workgroup, K a multiple of 16.
 //   MODE 0 (panel solve, X = A21 * Linv^T, K = 128): C = A B^T, C aliases A (all loads finish before any store).
 //   MODE 1 (trailing update, A22 -= L21 L21^T): C -= A B^T on the lower tiles, 1-D triangular grid.
 //   MODE 2 (update inside the outer panel): C -= A B^T on a (rows x few column tiles) grid, tiles above the
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 // k = 4 kq + s at step s) identically for A and B, so every lane fetches 4 consecutive doubles
 // (two 16-byte loads) per 16-row strip.  C/D map: col = l&15, row = (l>>4) + 4 reg.
 template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, const double* bbase,
+__global__ __launch_bounds__(kBlock, 2) void k_gemm_nt_f64(const double* abase, const double* bbase,
                                                         int64_t lda, int64_t ldb, double* cbase, int64_t ldc,
                                                         int kdim) {
     int by, bx;
@@ -279,49 +279,46 @@ __global__ __launch_bounds__(kBlock) void k_gemm_nt_f64(const double* abase, con
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    // software pipelined over 16-wide k chunks: the operands of chunk c+1 are in flight while the 64 MFMAs
-    // (64 cycles each) of chunk c issue, so one wave per SIMD already keeps the matrix core busy
-    d4 af[2][4], bf[2][4];
+    for (int kc = 0; kc < kdim; kc += 16) {
+        // operands straight from global / L2 into registers; with two workgroups per CU the loads of one wave
+        // overlap the 64 MFMAs (64 cycles each) of the other wave on the same SIMD
+        d4 af[4], bf[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        af[0][t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda);
-        bf[0][t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb);
-    }
-    for (int kc = 0; kc < kdim; kc += 32) {
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int cur = half, nxt = half ^ 1;
-            const int kn = kc + 16 * (half + 1);
-            if (kn < kdim) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    af[nxt][t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda + kn);
-                    bf[nxt][t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb + kn);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            af[t] = *reinterpret_cast<const d4*>(ap + (int64_t)t * 16 * lda + kc);
+            bf[t] = *reinterpret_cast<const d4*>(bp + (int64_t)t * 16 * ldb + kc);
         }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
     if (MODE == 0) __syncthreads();  // C aliases A: every wave's loads are done before anyone stores
-    double* cp = cbase + ((int64_t)by * NB + wr * 64 + kq) * ldc + (int64_t)bx * NB + wc * 64 + li;
+    // epilogue: the read-modify-write of the C tile is batched (16 independent loads in flight, then 16
+    // stores) - a load/sub/store chain per element would serialise 64 global round trips per lane
+    double* __restrict__ cp = cbase + ((int64_t)by * NB + wr * 64 + kq) * ldc + (int64_t)bx * NB + wc * 64 + li;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        if (MODE != 0) {
+            double cv[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* q = cp + (int64_t)(16 * i + 4 * r) * ldc + 16 * j;
-                if (MODE != 0)
-                    *q -= acc[i][j][r];
-                else
-                    *q = acc[i][j][r];
-            }
+                for (int r = 0; r < 4; ++r) cv[j][r] = cp[(int64_t)(16 * i + 4 * r) * ldc + 16 * j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cp[(int64_t)(16 * i + 4 * r) * ldc + 16 * j] = cv[j][r] - acc[i][j][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cp[(int64_t)(16 * i + 4 * r) * ldc + 16 * j] = acc[i][j][r];
+        }
+    }
 }
 
 // ---- block triangular solves with 3 right-hand sides ----------------------------------------------

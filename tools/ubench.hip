@@ -90,6 +90,27 @@ __global__ __launch_bounds__(256) void k_mfma4_pk(float* out, float a, float b) 
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_mfma_f64(double* out, double a, double b) {
+    d4 c[8];
+    for (int i = 0; i < 8; ++i) c[i] = (d4){0, 0, 0, 0};
+    double x = threadIdx.x * 1e-3, y = threadIdx.x * 2e-3;
+    for (int it = 0; it < ITER / 4; ++it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c[i], 0, 0, 0);
+    double s = 0; for (int i = 0; i < 8; ++i) s += c[i].x + c[i].y + c[i].z + c[i].w;
+    out[blockIdx.x * 256 + threadIdx.x] = s + a + b;
+}
+__global__ __launch_bounds__(256) void k_fma_f64(double* out, double a, double b) {
+    double v[8];
+    for (int i = 0; i < 8; ++i) v[i] = threadIdx.x * 1e-3 + i;
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = __builtin_fma(v[i], a, b);
+    double s = 0; for (int i = 0; i < 8; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 template <typename F>
 float time_kernel(F launch) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -119,6 +140,16 @@ int main() {
     printf("mfma_4x4x1 f32 : %.3f ms  %.1f Gwave-instr/s  (%.1f TFLOP/s)\n", ms, lanes / 64 * ITER * 4 / ms / 1e6, lanes / 64 * ITER * 4 * 512 / ms / 1e9);
     ms = time_kernel([&] { k_mfma4_pk<<<blocks, 256>>>(out, 1.0001f, 0.5f); });
     printf("mfma4x4 + 2pk  : %.3f ms  (same mfma count as above + 2 pk_fma per mfma)\n", ms);
+    double* outd; CHECK(hipMalloc(&outd, blocks * 256 * sizeof(double)));
+    for (int wpc = 1; wpc <= 2; ++wpc) {   // 1 or 2 workgroups (4 / 8 waves) per CU
+        const int nb = prop.multiProcessorCount * wpc;
+        ms = time_kernel([&] { k_mfma_f64<<<nb, 256>>>(outd, 1.0001, 0.5); });
+        printf("mfma_f64 16x16x4 (%d WG/CU): %.3f ms  %.2f TFLOP/s  (%.1f cycles per MFMA per SIMD at 2.4 GHz)\n", wpc, ms,
+               (double)nb * 4 * (ITER / 4) * 8 * 2048.0 / ms / 1e9, ms * 1e-3 * 2.4e9 / ((ITER / 4) * 8.0 * wpc));
+    }
+    ms = time_kernel([&] { k_fma_f64<<<blocks, 256>>>(outd, 1.0001, 0.5); });
+    printf("v_fma_f64      : %.3f ms  %.1f TFLOP/s\n", ms, lanes * ITER * 8 * 2 / ms / 1e9);
+    hipFree(outd);
     hipFree(out);
     return 0;
 }
