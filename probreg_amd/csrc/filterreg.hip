@@ -141,8 +141,11 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
         const unsigned long long pk = pack_key(key, D);
         unsigned long long slot = mix64(pk) & mask;
         for (;;) {
-            const unsigned long long prev = atomicCAS(&tkeys[slot], kEmpty, pk);
-            if (prev == kEmpty || prev == pk) break;
+            // plain (L2-coherent) read first: once a vertex exists, the ~N/L points sharing it never issue an
+            // atomic - a CAS storm on a few hundred hot keys costs milliseconds when sigma is large
+            unsigned long long cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == kEmpty) cur = atomicCAS(&tkeys[slot], kEmpty, pk);
+            if (cur == kEmpty || cur == pk) break;
             slot = (slot + 1) & mask;
         }
         pslot[i * D1 + r] = (int)slot;
@@ -218,6 +221,68 @@ __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset
     for (int k = 0; k < ch; ++k) {
         const float p = __fmul_rn(w, in[i * ch + k]);
         if (p != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], p);
+    }
+}
+
+// Block-private splat: every workgroup accumulates its chunk of points into an LDS hash table keyed by the
+// vertex id (ds atomics), then flushes each occupied entry with ONE global atomic per channel.  While the
+// lattice is small (sigma large: a few hundred vertices shared by 2M point-vertex incidences) this removes
+// the same-address global atomic storm; when a chunk touches more distinct vertices than the table holds,
+// the overflow goes straight to global memory, where contention is low by then.
+constexpr int kSplatSlots = 2048;       // LDS table entries (key + up to 8 channels)
+constexpr int kSplatMaxCh = 8;
+constexpr int kSplatPts = 2048;         // points per workgroup
+__global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ offset, const float* __restrict__ bary,
+                                                      const float* __restrict__ in, int64_t first, int64_t n, int d1,
+                                                      int ch, float* __restrict__ vals) {
+    __shared__ int skey[kSplatSlots];
+    __shared__ float sval[kSplatSlots * kSplatMaxCh];
+    __shared__ int sfill;
+    for (int t = threadIdx.x; t < kSplatSlots; t += kBlock) skey[t] = -1;
+    for (int t = threadIdx.x; t < kSplatSlots * kSplatMaxCh; t += kBlock) sval[t] = 0.f;
+    if (threadIdx.x == 0) sfill = 0;
+    __syncthreads();
+    const int64_t p0 = first + (int64_t)blockIdx.x * kSplatPts;
+    const int64_t p1 = (p0 + kSplatPts < n) ? p0 + kSplatPts : n;
+    for (int64_t t = (p0 - first) * d1 + threadIdx.x; t < (p1 - first) * d1; t += kBlock) {
+        const int64_t i = first + t / d1;
+        const int r = (int)(t % d1);
+        const float w = bary[i * d1 + r];
+        const int o = offset[i * d1 + r] + 1;
+        bool any = false;
+        float p[kSplatMaxCh];
+        for (int k = 0; k < ch; ++k) {
+            p[k] = __fmul_rn(w, in[i * ch + k]);
+            any |= p[k] != 0.f;
+        }
+        if (!any) continue;
+        unsigned h = ((unsigned)o * 2654435761u) >> 21;  // 11 bits
+        int slot = -1;
+        for (int probe = 0; probe < 16; ++probe) {
+            int cur = skey[h];
+            if (cur == -1 && sfill < kSplatSlots * 3 / 4) {
+                cur = atomicCAS(&skey[h], -1, o);
+                if (cur == -1) { atomicAdd(&sfill, 1); cur = o; }
+            }
+            if (cur == o) { slot = (int)h; break; }
+            h = (h + 1) & (kSplatSlots - 1);
+        }
+        if (slot >= 0) {
+            for (int k = 0; k < ch; ++k)
+                if (p[k] != 0.f) atomicAdd(&sval[slot * kSplatMaxCh + k], p[k]);
+        } else {
+            for (int k = 0; k < ch; ++k)
+                if (p[k] != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], p[k]);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < kSplatSlots; t += kBlock) {
+        const int o = skey[t];
+        if (o < 0) continue;
+        for (int k = 0; k < ch; ++k) {
+            const float v = sval[t * kSplatMaxCh + k];
+            if (v != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], v);
+        }
     }
 }
 
@@ -356,8 +421,12 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
     float* a = L->vals;
     float* b = L->vals + plane;
     PRG_HIP(hipMemsetAsync(a, 0, 2 * plane * sizeof(float), st));
-    k_splat<<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, in, first,
-                                                                                    L->n, d1, ch, a);
+    if (ch <= kSplatMaxCh)
+        k_splat_lds<<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(L->pslot, L->bary, in, first,
+                                                                                        L->n, d1, ch, a);
+    else
+        k_splat<<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, in,
+                                                                                        first, L->n, d1, ch, a);
     if (L->with_blur) {
         const int* nb1 = L->nb;
         const int* nb2 = L->nb + (int64_t)d1 * L->size;
