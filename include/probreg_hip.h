@@ -152,6 +152,10 @@ int prg_cpd_nonrigid_get_w(prg_cpd* h, double* w_hd);
 /* T = Y + G W for the current W (m x dim float64): NonRigidTransformation._transform on the control
  * points, transformation.py:101-102. */
 int prg_cpd_nonrigid_apply(prg_cpd* h, double* t_hd);
+/* Correspondence priors of ConstrainedNonRigidCPD (cpd.py:306-404): p1_tilde [m] and px_tilde [m x dim]
+ * (float64) are the row sums / target-weighted row sums of the 0-1 prior matrix, `alpha` its reliability;
+ * the next prg_cpd_mstep_nonrigid then solves cpd.py:391-396.  NULL pointers clear the priors. */
+int prg_cpd_nonrigid_set_priors(prg_cpd* h, const double* p1_tilde_hd, const double* px_tilde_hd, double alpha);
 /* Device address of the per-point E-step block (4*m doubles: p1[m], px0[m], px1[m], px2[m])
  * followed by MOMENTS-style scalars; this is the non-rigid all-reduce payload. */
 int prg_cpd_rowacc_ptr(prg_cpd* h, double** rowacc_dev, int64_t* count);

@@ -180,6 +180,23 @@ def mstep_nonrigid(source, target, es, sigma2_p, g, lmd):
     return MstepResult(dict(w=w), sigma2, sigma2)
 
 
+def mstep_nonrigid_constrained(source, target, es, sigma2_p, g, lmd, alpha, p1_tilde, px_tilde):
+    """ConstrainedNonRigidCPD._maximization_step, cpd.py:377-404."""
+    source = np.asarray(source, dtype=np.float64)
+    target = np.asarray(target, dtype=np.float64)
+    pt1, p1, px, n_p = es
+    m, dim = source.shape
+    lhs = (p1 * g).T + sigma2_p / alpha * (p1_tilde * g).T + lmd * sigma2_p * np.identity(m)
+    rhs = px - (source.T * p1).T + sigma2_p / alpha * (px_tilde - (source.T * p1_tilde).T)
+    w = np.linalg.solve(lhs, rhs)
+    t = source + g @ w
+    tr_xp1x = np.trace((target.T * pt1) @ target)
+    tr_pxt = np.trace(px.T @ t)
+    tr_tpt = np.trace((t.T * p1) @ t)
+    sigma2 = (tr_xp1x - 2.0 * tr_pxt + tr_tpt) / (n_p * dim)
+    return MstepResult(dict(w=w), sigma2, sigma2)
+
+
 # ----------------------------------------------------------------------------------------------
 # transforms + driver
 # ----------------------------------------------------------------------------------------------
@@ -190,14 +207,14 @@ def transform(kind, params, source, g=None):
         return params["scale"] * source @ params["rot"].T + params["t"]
     if kind == "affine":
         return source @ params["b"].T + params["t"]
-    if kind == "nonrigid":
+    if kind in ("nonrigid", "nonrigid_constrained"):
         return source + g @ params["w"]
     raise ValueError("Unknown transformation type %s" % kind)
 
 
 def registration(kind, source, target, w=0.0, maxiter=50, tol=0.001, update_scale=True,
                  tf_init_params=None, beta=2.0, lmd=2.0, chunk=1024, closed_form_init=False,
-                 history=None):
+                 history=None, alpha=1e-8, idx_source=None, idx_target=None):
     """EM driver, cpd.py:106-120 with the per-type ``_initialize`` (:145-153, :209-217, :277-282).
 
     Returns (params, sigma2, q, n_iter).  ``history`` (a list) receives (sigma2, q) per iteration.
@@ -217,9 +234,15 @@ def registration(kind, source, target, w=0.0, maxiter=50, tol=0.001, update_scal
         params = dict(b=np.identity(dim), t=np.zeros(dim))
         if tf_init_params:
             params.update(tf_init_params)
-    elif kind == "nonrigid":
+    elif kind in ("nonrigid", "nonrigid_constrained"):
         g = rbf_kernel(source, source, beta)
         params = dict(w=np.zeros_like(source))
+        if kind == "nonrigid_constrained":  # cpd.py:370-376
+            p_tilde = np.zeros((source.shape[0], target.shape[0]))
+            if idx_source is not None and idx_target is not None:
+                p_tilde[idx_source, idx_target] = 1
+            p1_tilde = p_tilde.sum(axis=1)
+            px_tilde = p_tilde @ target
     else:
         raise ValueError("Unknown transformation type %s" % kind)
     n_iter = 0
@@ -230,6 +253,9 @@ def registration(kind, source, target, w=0.0, maxiter=50, tol=0.001, update_scal
             params, sigma2_new, q_new = mstep_rigid(source, target, es, update_scale)
         elif kind == "affine":
             params, sigma2_new, q_new = mstep_affine(source, target, es)
+        elif kind == "nonrigid_constrained":
+            params, sigma2_new, q_new = mstep_nonrigid_constrained(source, target, es, sigma2, g, lmd, alpha,
+                                                                   p1_tilde, px_tilde)
         else:
             params, sigma2_new, q_new = mstep_nonrigid(source, target, es, sigma2, g, lmd)
         sigma2 = sigma2_new

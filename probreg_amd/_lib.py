@@ -75,6 +75,7 @@ SIGNATURES = {
     "prg_cpd_nonrigid_set_w": [_vp, _vp],
     "prg_cpd_nonrigid_get_w": [_vp, _vp],
     "prg_cpd_nonrigid_apply": [_vp, _vp],
+    "prg_cpd_nonrigid_set_priors": [_vp, _vp, _vp, _d],
     "prg_cpd_rowacc_ptr": [_vp, _pp, _c.POINTER(_i64)],
     "prg_cpd_mstep_nonrigid": [_vp, _d],
     "prg_gauss_transform_direct": [_i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _d, _vp],

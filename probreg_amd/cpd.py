@@ -374,6 +374,43 @@ class NonRigidCPD(CoherentPointDrift):
         )
 
 
+class ConstrainedNonRigidCPD(NonRigidCPD):
+    """Extended CPD with point-correspondence priors (reference cpd.py:306-404, Golyanik et al. 2016).
+
+    Args:
+        source (numpy.ndarray, optional): Source point cloud data.
+        beta (float, optional): Parameter of RBF kernel.
+        lmd (float, optional): Parameter for regularization term.
+        alpha (float): Degree of reliability of priors, ~1e-8 (highly reliable) .. 1 (highly unreliable).
+        use_cuda (bool, optional): accepted for compatibility, ignored.
+        idx_source / idx_target (numpy.ndarray of ints, optional): indices of known correspondences.
+
+    The reference materialises a dense M x N 0-1 matrix ``p_tilde`` (cpd.py:370-374); only its row sums
+    ``p1_tilde`` and ``px_tilde = p_tilde @ target`` enter the M-step, so they are formed directly from the
+    index lists here.
+    """
+
+    def __init__(self, source=None, beta=2.0, lmd=2.0, alpha=1e-8, use_cuda=False, idx_source=None, idx_target=None,
+                 device=None):
+        self.alpha = alpha
+        self.idx_source, self.idx_target = idx_source, idx_target
+        super(ConstrainedNonRigidCPD, self).__init__(source, beta, lmd, use_cuda, device)
+
+    def _initialize(self, target):
+        res = super(ConstrainedNonRigidCPD, self)._initialize(target)
+        target = _as_points(target)
+        m, dim = self._source.shape
+        self.p1_tilde = np.zeros(m)
+        self.px_tilde = np.zeros((m, dim))
+        if self.idx_source is not None and self.idx_target is not None:
+            # p_tilde[idx_source, idx_target] = 1 is an assignment: duplicate pairs count once (cpd.py:372-373)
+            pairs = np.unique(np.stack([np.asarray(self.idx_source), np.asarray(self.idx_target)], axis=1), axis=0)
+            np.add.at(self.p1_tilde, pairs[:, 0], 1.0)
+            np.add.at(self.px_tilde, pairs[:, 0], target[pairs[:, 1]])
+        self._plan.set_priors(self.p1_tilde, self.px_tilde, self.alpha)
+        return res
+
+
 def registration_cpd(source, target, tf_type_name="rigid", w=0.0, maxiter=50, tol=0.001, callbacks=[],
                      use_cuda=False, **kwargs):
     """CPD Registraion (reference cpd.py:407-456).
@@ -381,7 +418,7 @@ def registration_cpd(source, target, tf_type_name="rigid", w=0.0, maxiter=50, to
     Args:
         source (numpy.ndarray): Source point cloud data.
         target (numpy.ndarray): Target point cloud data.
-        tf_type_name (str, optional): Transformation type('rigid', 'affine', 'nonrigid')
+        tf_type_name (str, optional): Transformation type('rigid', 'affine', 'nonrigid', 'nonrigid_constrained')
         w (float, optional): Weight of the uniform distribution, 0 < `w` < 1.
         maxitr (int, optional): Maximum number of iterations to EM algorithm.
         tol (float, optional): Tolerance for termination.
@@ -404,7 +441,7 @@ def registration_cpd(source, target, tf_type_name="rigid", w=0.0, maxiter=50, to
     elif tf_type_name == "nonrigid":
         cpd = NonRigidCPD(_as_points(source), use_cuda=use_cuda, **kwargs)
     elif tf_type_name == "nonrigid_constrained":
-        raise NotImplementedError("ConstrainedNonRigidCPD is a next-row (SURVEY.md section 8f), not built yet.")
+        cpd = ConstrainedNonRigidCPD(_as_points(source), use_cuda=use_cuda, **kwargs)
     else:
         raise ValueError("Unknown transformation type %s" % tf_type_name)
     cpd.set_callbacks(callbacks)

@@ -119,6 +119,14 @@ __global__ __launch_bounds__(kBlock) void k_pack_w(const double* __restrict__ in
     }
 }
 
+// [m][dim] row-major -> 3 planes of m (missing dims zero)
+__global__ __launch_bounds__(kBlock) void k_unpack_planes(const double* __restrict__ in, int64_t m, int dim,
+                                                          double* __restrict__ planes) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    for (int k = 0; k < 3; ++k) planes[(int64_t)k * m + i] = k < dim ? in[i * dim + k] : 0.0;
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
 }  // namespace
@@ -147,6 +155,9 @@ int nonrigid_free(prg_cpd* h) {
     h->nr_events.clear();
     if (h->nr_stream2) (void)hipStreamDestroy(h->nr_stream2);
     h->nr_stream2 = nullptr;
+    if (h->nr_prior) (void)hipFree(h->nr_prior);
+    h->nr_prior = nullptr;
+    h->nr_alpha = 0.0;
     if (h->nr_solve) (void)hipFree(h->nr_solve);
     h->nr_solve = nullptr;
     h->nr_solve_bytes = 0;
@@ -211,6 +222,26 @@ int prg_cpd_nonrigid_get_w(prg_cpd* h, double* w_hd) {
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipMemcpyAsync(w_hd, h->stage, (size_t)h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));
+    return PRG_OK;
+}
+
+int prg_cpd_nonrigid_set_priors(prg_cpd* h, const double* p1_tilde_hd, const double* px_tilde_hd, double alpha) {
+    PRG_REQUIRE(h && h->G, PRG_ERR_STATE, "prg_cpd_nonrigid_set_priors: G has not been built");
+    prg::DeviceGuard g(h->device);
+    if (!p1_tilde_hd || !px_tilde_hd) {  // clear
+        h->nr_alpha = 0.0;
+        return PRG_OK;
+    }
+    PRG_REQUIRE(alpha > 0.0, PRG_ERR_INVALID, "prg_cpd_nonrigid_set_priors: alpha must be > 0 (got %g)", alpha);
+    const int64_t m = h->M;
+    if (!h->nr_prior) PRG_HIP(hipMalloc((void**)&h->nr_prior, (size_t)m * 4 * sizeof(double)));
+    PRG_TRY(prg::ensure_stage(h, (size_t)m * h->D * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(h->nr_prior, p1_tilde_hd, (size_t)m * sizeof(double), hipMemcpyDefault, h->stream));
+    PRG_HIP(hipMemcpyAsync(h->stage, px_tilde_hd, (size_t)m * h->D * sizeof(double), hipMemcpyDefault, h->stream));
+    k_unpack_planes<<<grid1(m), kBlock, 0, h->stream>>>((const double*)h->stage, m, h->D, h->nr_prior + m);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    h->nr_alpha = alpha;
     return PRG_OK;
 }
 

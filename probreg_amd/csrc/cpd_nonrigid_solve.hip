@@ -33,17 +33,31 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ---- right-hand side and S --------------------------------------------------------------------
 // B = px - p1 * y   (cpd.py:296, right-hand side), rows >= m zero.  sp = sqrt(p1).
+// With correspondence priors (ConstrainedNonRigidCPD, cpd.py:391-396): p1 -> p1 + sigma2/alpha * p1_tilde on the
+// left-hand side and B += sigma2/alpha * (px_tilde - p1_tilde * y).
 __global__ __launch_bounds__(kBlock) void k_rhs(const double* __restrict__ rowacc, int64_t mcap,
                                                 const float4* __restrict__ src4, int64_t m, int64_t mp,
-                                                double* __restrict__ b3, double* __restrict__ sp) {
+                                                const double* __restrict__ prior, double alpha,
+                                                const double* __restrict__ params, double* __restrict__ b3,
+                                                double* __restrict__ sp) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= mp) return;
     if (i < m) {
-        const double p1 = rowacc[i];
+        double p1 = rowacc[i];
         const float4 y = src4[i];
-        b3[i * 3 + 0] = rowacc[mcap + i] - p1 * (double)y.x;
-        b3[i * 3 + 1] = rowacc[2 * mcap + i] - p1 * (double)y.y;
-        b3[i * 3 + 2] = rowacc[3 * mcap + i] - p1 * (double)y.z;
+        double b0 = rowacc[mcap + i] - p1 * (double)y.x;
+        double b1 = rowacc[2 * mcap + i] - p1 * (double)y.y;
+        double b2 = rowacc[3 * mcap + i] - p1 * (double)y.z;
+        if (prior) {
+            const double f = params[13] / alpha, pt = prior[i];
+            b0 += f * (prior[m + i] - pt * (double)y.x);
+            b1 += f * (prior[2 * m + i] - pt * (double)y.y);
+            b2 += f * (prior[3 * m + i] - pt * (double)y.z);
+            p1 += f * pt;
+        }
+        b3[i * 3 + 0] = b0;
+        b3[i * 3 + 1] = b1;
+        b3[i * 3 + 2] = b2;
         sp[i] = sqrt(fmax(p1, 0.0));
     } else {
         b3[i * 3] = b3[i * 3 + 1] = b3[i * 3 + 2] = 0.0;
@@ -499,7 +513,8 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
     hipStream_t st = h->stream;
 
     PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-    k_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, mp, b3, sp);
+    k_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, mp, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
+                                        h->nr_alpha, h->params, b3, sp);
     PRG_TRY(prg::nonrigid_gw(h, b3, gb));                       // G B
     k_scale_rows<<<grid1(m), kBlock, 0, st>>>(sp, gb, m, v);    // v = D^1/2 G B (pad rows of v stay 0 below)
     if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));

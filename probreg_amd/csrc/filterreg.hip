@@ -59,7 +59,9 @@ struct Lattice {
     float* bary = nullptr;              // [n][d+1]
     unsigned long long* dkeys = nullptr;  // [n*(d+1)] dense keys
     int* nb = nullptr;                  // [2][d+1][size] blur neighbours (dense id or -1)
-    int* count = nullptr;               // device counter
+    int* count = nullptr;               // device counters: [0] vertices, [1] table overflow flag
+    int64_t cap_used = 0;               // slots of the table in use for the current build (power of two <= cap)
+    int prev_size = 0;
     float* vals = nullptr;              // [2][(size+1)][C] ping-pong value buffers
     int64_t vals_elems = 0;
     int64_t n_alloc = 0, nb_alloc = 0;
@@ -72,7 +74,7 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, int64_t n, float s0, float s1,
                                                   float s2, unsigned long long* __restrict__ tkeys,
                                                   unsigned long long mask, int* __restrict__ pslot,
-                                                  float* __restrict__ bary) {
+                                                  float* __restrict__ bary, int* __restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     constexpr int D1 = D + 1;
@@ -140,7 +142,12 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
         }
         const unsigned long long pk = pack_key(key, D);
         unsigned long long slot = mix64(pk) & mask;
-        for (;;) {
+        for (int probes = 0;; ++probes) {
+            if (probes > 4096) {  // table (sized from the previous lattice) is too small: the host rebuilds
+                *overflow = 1;
+                slot = 0;
+                break;
+            }
             // plain (L2-coherent) read first: once a vertex exists, the ~N/L points sharing it never issue an
             // atomic - a CAS storm on a few hundred hot keys costs milliseconds when sigma is large
             unsigned long long cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -364,29 +371,48 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur) {
         PRG_HIP(hipMalloc((void**)&L->pslot, na * d1 * sizeof(int)));
         PRG_HIP(hipMalloc((void**)&L->bary, na * d1 * sizeof(float)));
         PRG_HIP(hipMalloc((void**)&L->dkeys, na * d1 * sizeof(unsigned long long)));
-        if (!L->count) PRG_HIP(hipMalloc((void**)&L->count, sizeof(int)));
+        if (!L->count) PRG_HIP(hipMalloc((void**)&L->count, 2 * sizeof(int)));
         L->n_alloc = na;
     }
     L->n = n;
     L->d = d;
     L->with_blur = with_blur;
-    PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, L->cap * sizeof(unsigned long long), st));
-    PRG_HIP(hipMemsetAsync(L->count, 0, sizeof(int), st));
     // scale_factor[i] = float(1/sqrt((i+2)(i+1)) * inv_std_dev), inv_std_dev a float (:180-183)
     const float inv_std = with_blur ? (float)(sqrt(2.0 / 3.0) * d1) : (float)(sqrt(1.0 / 6.0) * d1);
     float sc[3] = {0.f, 0.f, 0.f};
     for (int i = 0; i < d; ++i) sc[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std);
-    const unsigned long long mask = (unsigned long long)L->cap - 1;
-    const unsigned nb = (unsigned)prg::ceil_div(n, kBlock);
-    if (d == 1) k_embed<1><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary);
-    else if (d == 2) k_embed<2><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary);
-    else k_embed<3><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary);
-    k_compact<<<(unsigned)prg::ceil_div(L->cap, kBlock), kBlock, 0, st>>>(L->tkeys, L->cap, L->slot_id, L->dkeys,
-                                                                         L->count);
+    // The table is sized from the previous lattice (x32 head room, the lattice at most doubles per EM iteration)
+    // so that clearing and compacting it costs microseconds; an overflow falls back to the worst-case size.
+    int64_t capu = L->cap;
+    if (L->prev_size > 0) {
+        capu = 65536;
+        while (capu < 32 * (int64_t)L->prev_size) capu <<= 1;
+        if (capu > L->cap) capu = L->cap;
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        L->cap_used = capu;
+        PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, capu * sizeof(unsigned long long), st));
+        PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
+        const unsigned long long mask = (unsigned long long)capu - 1;
+        const unsigned nb = (unsigned)prg::ceil_div(n, kBlock);
+        if (d == 1) k_embed<1><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+        else if (d == 2) k_embed<2><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+        else k_embed<3><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+        k_compact<<<(unsigned)prg::ceil_div(capu, kBlock), kBlock, 0, st>>>(L->tkeys, capu, L->slot_id, L->dkeys,
+                                                                           L->count);
+        PRG_HIP(hipGetLastError());
+        int host[2] = {0, 0};
+        PRG_HIP(hipMemcpyAsync(host, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        PRG_HIP(hipStreamSynchronize(st));
+        L->size = host[0];
+        if (host[1] == 0 && (int64_t)L->size * 2 <= capu) break;
+        PRG_REQUIRE(capu < L->cap, PRG_ERR_STATE, "permutohedral lattice: hash table overflow at full capacity");
+        capu = L->cap;
+    }
+    L->prev_size = L->size;
+    const unsigned long long mask = (unsigned long long)L->cap_used - 1;
     k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id);
     PRG_HIP(hipGetLastError());
-    PRG_HIP(hipMemcpyAsync(&L->size, L->count, sizeof(int), hipMemcpyDeviceToHost, st));
-    PRG_HIP(hipStreamSynchronize(st));
     if (with_blur) {
         const int64_t need = 2 * (int64_t)d1 * L->size;
         if (need > L->nb_alloc) {

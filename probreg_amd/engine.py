@@ -175,6 +175,12 @@ class CpdPlan(object):
         check(lib.prg_cpd_nonrigid_get_w(self._h, ptr(out)))
         return out
 
+    def set_priors(self, p1_tilde, px_tilde, alpha):
+        a = np.ascontiguousarray(p1_tilde, dtype=np.float64)
+        b = np.ascontiguousarray(px_tilde, dtype=np.float64)
+        assert a.shape == (self.m,) and b.shape == (self.m, self.dim)
+        check(lib.prg_cpd_nonrigid_set_priors(self._h, ptr(a), ptr(b), float(alpha)))
+
     def nonrigid_apply(self):
         out = np.empty((self.m, self.dim), dtype=np.float64)
         check(lib.prg_cpd_nonrigid_apply(self._h, ptr(out)))

@@ -201,7 +201,48 @@ def main_filterreg():
     print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
 
 
+def main_constrained():
+    """ConstrainedNonRigidCPD fixtures (cpd.py:306-404) with known index correspondences."""
+    ref = ref_import.load(with_filterreg=False)
+    fish_s = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_source.txt"))
+    fish_t = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_target.txt"))
+    flat = {}
+
+    def add(name, src, tgt, idx_s, idx_t, alpha, **kw):
+        reg = ref.cpd.ConstrainedNonRigidCPD(src.copy(), alpha=alpha, idx_source=idx_s, idx_target=idx_t)
+        niter = [0]
+        reg.set_callbacks([lambda t: niter.__setitem__(0, niter[0] + 1)])
+        res = reg.registration(tgt.copy(), **kw)
+        pre = "reg/%s/" % name
+        flat[pre + "source"], flat[pre + "target"] = src, tgt
+        flat[pre + "idx_source"], flat[pre + "idx_target"] = np.asarray(idx_s), np.asarray(idx_t)
+        flat[pre + "alpha"] = np.asarray(alpha)
+        flat[pre + "out_sigma2"] = np.asarray(res.sigma2)
+        flat[pre + "out_niter"] = np.asarray(niter[0])
+        flat[pre + "out_w"] = res.transformation.w
+        flat[pre + "out_tsource"] = res.transformation.transform(src)
+        for k, v in kw.items():
+            flat[pre + "arg_" + k] = np.asarray(v)
+        print("constrained %-24s niter=%3d sigma2=%.10e" % (name, niter[0], res.sigma2))
+
+    idx = np.array([0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 10])  # one duplicate pair on purpose
+    add("fish_alpha1e-8_k6", fish_s, fish_t, idx, idx, 1e-8, maxiter=6, tol=-1.0)
+    add("fish_alpha1e-2_default", fish_s, fish_t, idx[:5], idx[:5], 1e-2)
+    s, t = synthetic.nonrigid_pair(900, m=800, seed=9)
+    rng = np.random.default_rng(0)
+    isrc = rng.choice(800, 25, replace=False)
+    # prior: the nearest target point of each chosen source point
+    itgt = np.array([np.argmin(((t - s[i]) ** 2).sum(axis=1)) for i in isrc])
+    add("synth_800_alpha1e-4_k4", s, t, isrc, itgt, 1e-4, maxiter=4, tol=-1.0)
+    out = os.path.join(HERE, "cpd_constrained_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "constrained":
+        main_constrained()
+        sys.exit(0)
     if len(sys.argv) < 2 or sys.argv[1] == "cpd":
         main()
     if len(sys.argv) < 2 or sys.argv[1] == "filterreg":

@@ -91,3 +91,25 @@ def test_moment_form_equals_direct_mstep(cpd_golden):
         assert abs(via.q - direct.q) < 1e-9 * abs(direct.q)
         for k in direct.params:
             assert np.max(np.abs(np.asarray(via.params[k]) - np.asarray(direct.params[k]))) < 1e-10
+
+
+def test_constrained_nonrigid_matches_reference():
+    """ConstrainedNonRigidCPD (cpd.py:306-404) fixtures from the reference's own class."""
+    import os
+    from conftest import GOLDEN_DIR, Golden
+
+    gold = Golden(os.path.join(GOLDEN_DIR, "cpd_constrained_golden.npz"))
+    for name in gold.group("reg"):
+        c = gold.case("reg/" + name)
+        kw = {}
+        if "arg_maxiter" in c:
+            kw["maxiter"] = int(c["arg_maxiter"])
+        if "arg_tol" in c:
+            kw["tol"] = float(c["arg_tol"])
+        params, sigma2, q, niter = co.registration("nonrigid_constrained", c["source"], c["target"], alpha=float(c["alpha"]),
+                                                   idx_source=c["idx_source"], idx_target=c["idx_target"], **kw)
+        assert niter == c["out_niter"], name
+        assert abs(sigma2 - c["out_sigma2"]) <= 1e-6 * abs(c["out_sigma2"]), name
+        g = co.rbf_kernel(c["source"], c["source"], 2.0)
+        ts = co.transform("nonrigid", params, c["source"], g)
+        assert rel_err(ts, c["out_tsource"]) < 1e-6, name
