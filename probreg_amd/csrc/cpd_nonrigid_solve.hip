@@ -433,6 +433,25 @@ __global__ __launch_bounds__(kBlock) void k_form_w(const double* __restrict__ b3
     w[i * 3 + 2] = (b3[i * 3 + 2] - f * u[i * 3 + 2]) * rc;
 }
 
+// iterative refinement: r = b - (sp^2 .* (G w) + c w)   (residual of (D G + c I) w = b, fp64)
+__global__ __launch_bounds__(kBlock) void k_residual(const double* __restrict__ b3, const double* __restrict__ sp,
+                                                     const double* __restrict__ gw, const double* __restrict__ w,
+                                                     int64_t m, int64_t mp, const double* __restrict__ params,
+                                                     double lmd, double* __restrict__ r3) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= mp) return;
+    if (i < m) {
+        const double c = lmd * params[13], d = sp[i] * sp[i];
+        for (int k = 0; k < 3; ++k) r3[i * 3 + k] = b3[i * 3 + k] - (d * gw[i * 3 + k] + c * w[i * 3 + k]);
+    } else {
+        r3[i * 3] = r3[i * 3 + 1] = r3[i * 3 + 2] = 0.0;
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_axpy3(const double* __restrict__ x, int64_t m, double* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m * 3) y[i] += x[i];
+}
+
 // partial sums of tr(px^T T) and tr(T^T diag(p1) T), T = y + gw   (cpd.py:298-300)
 __global__ __launch_bounds__(kBlock) void k_traces(const double* __restrict__ rowacc, int64_t mcap,
                                                    const float4* __restrict__ src4, const double* __restrict__ gw,
@@ -492,7 +511,7 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
     // workspace: S [mp*mp] | Linv [nblk*128*128] | b3, gb, v, sp (each <= 3 mp) | trace partials | info
     const size_t n_s = (size_t)mp * mp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)mp * 3;
     const int tr_blk = (int)prg::ceil_div(m, kBlock);
-    const size_t need = (n_s + n_linv + 4 * n_vec + 2 * (size_t)tr_blk + 16) * sizeof(double);
+    const size_t need = (n_s + n_linv + 6 * n_vec + 2 * (size_t)tr_blk + 16) * sizeof(double);
     if (h->nr_solve_bytes < need) {
         if (h->nr_solve) (void)hipFree(h->nr_solve);
         h->nr_solve = nullptr;
@@ -508,16 +527,15 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
     double* gb = b3 + n_vec;
     double* v = gb + n_vec;
     double* sp = v + n_vec;
-    double* trpart = sp + n_vec;
+    double* r3 = sp + n_vec;
+    double* dw = r3 + n_vec;
+    double* trpart = dw + n_vec;
     int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
     hipStream_t st = h->stream;
 
     PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
     k_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, mp, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
                                         h->nr_alpha, h->params, b3, sp);
-    PRG_TRY(prg::nonrigid_gw(h, b3, gb));                       // G B
-    k_scale_rows<<<grid1(m), kBlock, 0, st>>>(sp, gb, m, v);    // v = D^1/2 G B (pad rows of v stay 0 below)
-    if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));
     k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
 
     // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128.
@@ -574,19 +592,37 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
         last_u2 = (r2 > 0) ? J : -1;
     }
     if (last_u2 >= 0) PRG_HIP(hipStreamWaitEvent(st, h->nr_events[2 * last_u2 + 1], 0));
-    // L L^T u = v
-    for (int64_t kb = 0; kb < nblk; ++kb) {
-        const int64_t k0 = kb * NB;
-        k_diag_solve<0><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
-        const int64_t rows = mp - k0 - NB;
-        if (rows > 0) k_fwd_update<<<(unsigned)prg::ceil_div(rows, 64), kBlock, 0, st>>>(S, mp, k0, mp, v);
+    // w = (rhs - D^1/2 S^-1 D^1/2 (G rhs)) / c with the factor above: two blocked triangular sweeps, 3 RHS
+    auto solve_with_factor = [&](const double* rhs, double* wout) -> int {
+        PRG_TRY(prg::nonrigid_gw(h, rhs, gb));                    // G rhs
+        k_scale_rows<<<grid1(m), kBlock, 0, st>>>(sp, gb, m, v);  // v = D^1/2 G rhs
+        if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));
+        for (int64_t kb = 0; kb < nblk; ++kb) {                   // L u' = v
+            const int64_t k0 = kb * NB;
+            k_diag_solve<0><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+            const int64_t rows = mp - k0 - NB;
+            if (rows > 0) k_fwd_update<<<(unsigned)prg::ceil_div(rows, 64), kBlock, 0, st>>>(S, mp, k0, mp, v);
+        }
+        for (int64_t kb = nblk - 1; kb >= 0; --kb) {              // L^T u = u'
+            const int64_t k0 = kb * NB;
+            k_diag_solve<1><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+            if (k0 > 0) k_bwd_update<<<grid1(k0), kBlock, 0, st>>>(S, mp, k0, v);
+        }
+        k_form_w<<<grid1(m), kBlock, 0, st>>>(rhs, sp, v, m, h->params, lmd, wout);
+        PRG_HIP(hipGetLastError());
+        return PRG_OK;
+    };
+    PRG_TRY(solve_with_factor(b3, h->W));
+    // With correspondence priors the diagonal scaling spans sigma2/alpha ~ 1e7 and the push-through form
+    // loses digits to cancellation; two steps of fp64 iterative refinement on the ORIGINAL system
+    // (D G + c I) w = b bring the solution back to the backward-stable level LAPACK gesv delivers.
+    const int nrefine = h->nr_alpha > 0.0 ? 2 : 0;
+    for (int it = 0; it < nrefine; ++it) {
+        PRG_TRY(prg::nonrigid_gw(h, h->W, gb));
+        k_residual<<<grid1(mp), kBlock, 0, st>>>(b3, sp, gb, h->W, m, mp, h->params, lmd, r3);
+        PRG_TRY(solve_with_factor(r3, dw));
+        k_axpy3<<<grid1(m * 3), kBlock, 0, st>>>(dw, m, h->W);
     }
-    for (int64_t kb = nblk - 1; kb >= 0; --kb) {
-        const int64_t k0 = kb * NB;
-        k_diag_solve<1><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
-        if (k0 > 0) k_bwd_update<<<grid1(k0), kBlock, 0, st>>>(S, mp, k0, v);
-    }
-    k_form_w<<<grid1(m), kBlock, 0, st>>>(b3, sp, v, m, h->params, lmd, h->W);
     PRG_TRY(prg::nonrigid_gw(h, h->W, gb));                     // G W
     k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, gb, m, trpart);
     k_nonrigid_finish<<<1, 64, 0, st>>>(trpart, tr_blk, h->moments, h->params, h->D);
