@@ -73,6 +73,11 @@ typedef struct prg_cpd prg_cpd;
 int prg_cpd_create(prg_cpd** out, int device, void* hip_stream);
 int prg_cpd_destroy(prg_cpd* h);
 
+/* Engine options, before the clouds are uploaded (all default to 1): Morton-sort the source / the target at
+ * upload (every output keeps the caller's point order) and skip (wave, 32-point group) blocks whose every pair
+ * is an exact zero in fp32.  The non-rigid path keeps the source unsorted. */
+int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
+
 /* Upload the (already centred) source cloud, replicated on every device.
  * Replaces: CoherentPointDrift.set_source, cpd.py:61-62. */
 int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim);

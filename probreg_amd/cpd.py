@@ -324,6 +324,8 @@ class NonRigidCPD(CoherentPointDrift):
 
     def _build(self):
         self._plan = CpdPlan(self._device)
+        # G, W and the per-point all-reduce block are indexed by the caller's source order
+        self._plan.set_options(sort_source=False, sort_target=True, cull=False)
         self._plan.set_source(self._source)
         self._source_uploaded = True
         self._plan.build_g(self._beta)

@@ -21,6 +21,9 @@
 #include "cpd_sweeps.h"
 #include "small_linalg.h"
 
+#include <numeric>
+#include <vector>
+
 namespace {
 
 constexpr double kLog2e = 1.4426950408889634;
@@ -39,14 +42,15 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pack_cloud(const float* __restrict__ in, int64_t n, int dim,
                                                        float4* __restrict__ out, int64_t cap, float pad,
-                                                       float aux) {
+                                                       float aux, const int* __restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= cap) return;
     float4 v;
     if (i < n) {
-        v.x = in[i * dim];
-        v.y = in[i * dim + 1];
-        v.z = dim > 2 ? in[i * dim + 2] : 0.f;
+        const int64_t j = perm ? perm[i] : i;  // sorted position i holds original point perm[i]
+        v.x = in[j * dim];
+        v.y = in[j * dim + 1];
+        v.z = dim > 2 ? in[j * dim + 2] : 0.f;
         v.w = aux;
     } else {
         v.x = v.y = v.z = pad;
@@ -138,11 +142,14 @@ __global__ void k_init_params(double* __restrict__ moments, const double* __rest
 // z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).
 __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __restrict__ src4, float4* __restrict__ z4,
                                                              int64_t m, int64_t cap,
-                                                             const double* __restrict__ params) {
+                                                             const double* __restrict__ params,
+                                                             unsigned* __restrict__ motion) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= cap) return;
+    float moved = 0.f;
     float4 o;
-    if (i < m) {
+    if (i >= cap) {
+        o = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (i < m) {
         const double s = params[12];
         float4 y = src4[i];
         double yx = y.x, yy = y.y, yz = y.z;
@@ -150,11 +157,39 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
         o.y = (float)(s * (params[3] * yx + params[4] * yy + params[5] * yz) + params[10]);
         o.z = (float)(s * (params[6] * yx + params[7] * yy + params[8] * yz) + params[11]);
         o.w = 0.f;
+        const float4 old = z4[i];  // how far did this point move since the last E-step (cull bound, see k_colpass_cull)
+        const float dx = o.x - old.x, dy = o.y - old.y, dz = o.z - old.z;
+        moved = sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f;
     } else {
         o.x = o.y = o.z = prg::kSrcPad;
         o.w = 0.f;
     }
-    z4[i] = o;
+    if (i < cap) z4[i] = o;
+    // non-negative floats order like their bit patterns: one atomicMax per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) moved = fmaxf(moved, __shfl_xor(moved, off, 64));
+    if ((threadIdx.x & 63) == 0 && moved > 0.f) atomicMax(motion, __float_as_uint(moved));
+}
+
+// bounding box (+ max of .w) of every group of 32 consecutive points -> meta[g][8] = lo.xyz, hi.xyz, max w, 0
+__global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict__ pts, int64_t ngroups,
+                                                       float* __restrict__ meta) {
+    const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= ngroups) return;
+    const float4* p = pts + g * prg::kGroup;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = -INFINITY;
+    for (int k = 0; k < prg::kGroup; ++k) {
+        const float4 v = p[k];
+        lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
+        lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
+        lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
+        wmax = fmaxf(wmax, v.w);
+    }
+    float* o = meta + g * 8;
+    o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
+    o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
+    o[6] = wmax;
+    o[7] = 0.f;
 }
 
 // (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip)
@@ -165,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
 __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, const float2* __restrict__ colpart,
                                                      int nseg, int64_t ncap, int64_t n, float* __restrict__ pt1,
                                                      const double* __restrict__ params, double w, double m_over_n,
-                                                     int dim) {
+                                                     int dim, float* __restrict__ colmin) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const double sigma2 = params[13];
@@ -192,6 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     }
     reinterpret_cast<float*>(tgt4 + i)[3] = b;
     pt1[i] = p;
+    colmin[i] = gmin;  // min_m |x_n - z_m|^2 of this E-step: seed of the next column pass' cull bound
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,6 +312,8 @@ __global__ __launch_bounds__(kBlock) void k_moments_from_arrays(const double* __
                                                                 const double* __restrict__ px, int dim, int64_t m,
                                                                 int64_t n, const float4* __restrict__ src4,
                                                                 const float4* __restrict__ tgt4,
+                                                                const int* __restrict__ perm_src,
+                                                                const int* __restrict__ perm_tgt,
                                                                 double* __restrict__ mompart) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     double a[kMomComp];
@@ -284,12 +322,14 @@ __global__ __launch_bounds__(kBlock) void k_moments_from_arrays(const double* __
     if (i < m) {
         const float4 yf = src4[i];
         const double y[3] = {yf.x, yf.y, yf.z};
-        double pxi[3] = {px[i * dim], px[i * dim + 1], dim > 2 ? px[i * dim + 2] : 0.0};
-        row_moment_terms(a, p1[i], pxi, y);
+        const int64_t j = perm_src ? perm_src[i] : i;  // the caller's arrays are in the original point order
+        double pxi[3] = {px[j * dim], px[j * dim + 1], dim > 2 ? px[j * dim + 2] : 0.0};
+        row_moment_terms(a, p1[j], pxi, y);
     }
     if (i < n) {
         const float4 xf = tgt4[i];
-        a[22] = pt1[i] * ((double)xf.x * xf.x + (double)xf.y * xf.y + (double)xf.z * xf.z);
+        const int64_t j = perm_tgt ? perm_tgt[i] : i;
+        a[22] = pt1[j] * ((double)xf.x * xf.x + (double)xf.y * xf.y + (double)xf.z * xf.z);
     }
     block_reduce_store(a, mompart);
 }
@@ -405,25 +445,33 @@ __global__ void k_mstep(const double* __restrict__ mom, double* __restrict__ par
 }
 
 // EstepResult materialisation helpers
+// Outputs go back to the caller's point order: sorted position i holds original point perm[i].
 __global__ __launch_bounds__(kBlock) void k_float_to_double(const float* __restrict__ in, double* __restrict__ out,
-                                                            int64_t n) {
+                                                            int64_t n, const int* __restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i < n) out[i] = in[i];
+    if (i < n) out[perm ? perm[i] : i] = in[i];
+}
+__global__ __launch_bounds__(kBlock) void k_scatter_double(const double* __restrict__ in, double* __restrict__ out,
+                                                           int64_t n, const int* __restrict__ perm) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) out[perm ? perm[i] : i] = in[i];
 }
 __global__ __launch_bounds__(kBlock) void k_pack_px(const double* __restrict__ rowacc, int64_t mcap, int64_t m,
-                                                    int dim, double* __restrict__ out) {
+                                                    int dim, double* __restrict__ out, const int* __restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
-    for (int k = 0; k < dim; ++k) out[i * dim + k] = rowacc[(int64_t)(1 + k) * mcap + i];
+    const int64_t j = perm ? perm[i] : i;
+    for (int k = 0; k < dim; ++k) out[j * dim + k] = rowacc[(int64_t)(1 + k) * mcap + i];
 }
 __global__ __launch_bounds__(kBlock) void k_unpack_points(const float4* __restrict__ in, int64_t m, int dim,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, const int* __restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
     const float4 v = in[i];
-    out[i * dim] = v.x;
-    out[i * dim + 1] = v.y;
-    if (dim > 2) out[i * dim + 2] = v.z;
+    const int64_t j = perm ? perm[i] : i;
+    out[j * dim] = v.x;
+    out[j * dim + 1] = v.y;
+    if (dim > 2) out[j * dim + 2] = v.z;
 }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
@@ -451,6 +499,12 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->rowacc) (void)hipFree(h->rowacc);
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
+    for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
+                    (void*)h->motion})
+        if (q) (void)hipFree(q);
+    h->perm_src = h->perm_tgt = nullptr;
+    h->zmeta = h->tmeta = h->colmin = nullptr;
+    h->motion = nullptr;
     h->src4 = h->z4 = h->tgt4 = nullptr;
     h->pt1 = nullptr;
     h->colpart = nullptr;
@@ -473,7 +527,58 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
     return PRG_OK;
 }
 
-int cap_for(int64_t n) { return (int)prg::round_up(n + 1024, 1024); }
+int cap_for(int64_t n) { return (int)prg::round_up(n + 3072, 1024); }
+
+// Morton (Z-curve) order of a cloud: sorted position -> original index.  One-off host work at upload
+// (std::sort over n 64-bit keys: ~10 ms per 100k points).
+static inline uint64_t spread21(uint64_t v) {  // 21 bits -> every third bit
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev) {
+    std::vector<float> host((size_t)n * dim);
+    PRG_HIP(hipMemcpy(host.data(), pts_hd, host.size() * sizeof(float), hipMemcpyDefault));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < dim; ++k) {
+            lo[k] = std::min(lo[k], host[i * dim + k]);
+            hi[k] = std::max(hi[k], host[i * dim + k]);
+        }
+    float ext = 0.f;
+    for (int k = 0; k < dim; ++k) ext = std::max(ext, hi[k] - lo[k]);
+    const double scale = ext > 0.f ? 2097151.0 / ext : 0.0;  // one isotropic 21-bit grid
+    std::vector<uint64_t> key((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t code = 0;
+        for (int k = 0; k < dim; ++k)
+            code |= spread21((uint64_t)((host[i * dim + k] - lo[k]) * scale)) << k;
+        key[i] = code;
+    }
+    std::vector<int> perm((size_t)n);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    if (*perm_dev) (void)hipFree(*perm_dev);
+    *perm_dev = nullptr;
+    PRG_HIP(hipMalloc((void**)perm_dev, (size_t)n * sizeof(int)));
+    PRG_HIP(hipMemcpy(*perm_dev, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    (void)h;
+    return PRG_OK;
+}
+
+template <typename T>
+int ensure_exact(T** p, size_t count) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    PRG_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    return PRG_OK;
+}
+
 
 int mom_blocks(const prg_cpd* h) {
     int64_t items = h->M > h->N ? h->M : h->N;
@@ -562,16 +667,28 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
         PRG_HIP(hipMalloc((void**)&h->z4, cap * sizeof(float4)));
         PRG_HIP(hipMalloc((void**)&h->rowacc, 4 * cap * sizeof(double)));
     }
+    if (cap != h->Mcap || !h->zmeta) {
+        PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
+        if (!h->motion) PRG_TRY(ensure_exact(&h->motion, 1));
+    }
     h->M = m;
     h->D = dim;
     h->Mcap = cap;
+    if (h->opt_sort_src) {
+        PRG_TRY(morton_permutation(h, source_hd, m, dim, &h->perm_src));
+    } else if (h->perm_src) {
+        (void)hipFree(h->perm_src);
+        h->perm_src = nullptr;
+    }
     PRG_TRY(prg::ensure_stage(h, (size_t)m * dim * sizeof(float)));
     PRG_HIP(hipMemcpyAsync(h->stage, source_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, h->stream));
     k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, m, dim, h->src4, cap, prg::kSrcPad,
-                                                       0.f);
-    k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, m, dim, h->z4, cap, prg::kSrcPad, 0.f);
+                                                       0.f, h->perm_src);
+    k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, m, dim, h->z4, cap, prg::kSrcPad, 0.f,
+                                                       h->perm_src);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));  // the caller's buffer may be pageable host memory
+    h->have_colmin = false;
     h->have_source = true;
     h->have_estep = false;
     prg::nonrigid_free(h);
@@ -595,16 +712,28 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
         PRG_HIP(hipMalloc((void**)&h->tgt4, cap * sizeof(float4)));
         PRG_HIP(hipMalloc((void**)&h->pt1, cap * sizeof(float)));
     }
+    if (cap != h->Ncap || !h->tmeta) {
+        PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
+        PRG_TRY(ensure_exact(&h->colmin, (size_t)cap));
+        PRG_HIP(hipMemsetAsync(h->colmin, 0, (size_t)cap * sizeof(float), h->stream));
+    }
     h->N = n_local;
     h->Nglobal = n_global;
     h->D = dim;
     h->Ncap = cap;
+    if (h->opt_sort_tgt) {
+        PRG_TRY(morton_permutation(h, target_hd, n_local, dim, &h->perm_tgt));
+    } else if (h->perm_tgt) {
+        (void)hipFree(h->perm_tgt);
+        h->perm_tgt = nullptr;
+    }
     PRG_TRY(prg::ensure_stage(h, (size_t)n_local * dim * sizeof(float)));
     PRG_HIP(hipMemcpyAsync(h->stage, target_hd, (size_t)n_local * dim * sizeof(float), hipMemcpyDefault, h->stream));
     k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, n_local, dim, h->tgt4, cap,
-                                                       prg::kTgtPad, 0.f);
+                                                       prg::kTgtPad, 0.f, h->perm_tgt);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
+    h->have_colmin = false;
     h->have_target = true;
     h->have_estep = false;
     return PRG_OK;
@@ -639,6 +768,16 @@ int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_ro
     h->seg_col = seg_col;
     h->r_row = r_row;
     h->seg_row = seg_row;
+    return PRG_OK;
+}
+
+int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_options: NULL handle");
+    PRG_REQUIRE(!h->have_source && !h->have_target, PRG_ERR_STATE,
+                "prg_cpd_set_options: must be called before the clouds are uploaded");
+    h->opt_sort_src = sort_source != 0;
+    h->opt_sort_tgt = sort_target != 0;
+    h->opt_cull = cull != 0;
     return PRG_OK;
 }
 
@@ -683,9 +822,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int64_t nblkA = prg::ceil_div(h->N, kBlock * RA), nblkB = prg::ceil_div(h->M, kBlock * RB);
     int SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M);
     int SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N);
-    // segment lengths are multiples of the loop trip (8 points); the pads absorb the overshoot and the
-    // prefetch over-read of the last segment
-    auto seg_of = [](int64_t len, int s) { return (int)prg::round_up(prg::ceil_div(len, s), 8); };
+    // Culled sweeps need both clouds Morton-sorted (compact waves / groups); they walk the stream in groups of 32.
+    const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;
+    // segment lengths are multiples of the loop trip (8 points, or one 32-point group); the pads absorb the
+    // overshoot and the prefetch over-read of the last segment
+    const int quantum = use_cull ? prg::kGroup : 8;
+    auto seg_of = [quantum](int64_t len, int s) { return (int)prg::round_up(prg::ceil_div(len, s), quantum); };
     int segA = seg_of(h->M, SA), segB = seg_of(h->N, SB);
     while (SA > 1 && (int64_t)SA * segA + prg::kOverRead > h->Mcap) --SA, segA = seg_of(h->M, SA);
     while (SB > 1 && (int64_t)SB * segB + prg::kOverRead > h->Ncap) --SB, segB = seg_of(h->N, SB);
@@ -696,17 +838,33 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_TRY(ensure_mompart(h));
 
     if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
+    PRG_HIP(hipMemsetAsync(h->motion, 0, sizeof(unsigned), h->stream));
     if (h->nonrigid)
         PRG_TRY(prg::nonrigid_transform(h));
     else
-        k_transform_linear<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->Mcap, h->params);
+        k_transform_linear<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->Mcap, h->params,
+                                                                     h->motion);
+    if (use_cull)
+        k_group_meta<<<grid1(h->Mcap / prg::kGroup), kBlock, 0, h->stream>>>(h->z4, h->Mcap / prg::kGroup, h->zmeta);
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
-    if (ra < 0) prg::launch_colpass_scalar(h, RA, SA, segA); else prg::launch_colpass_packed(h, RA, SA, segA);
+    if (use_cull)
+        prg::launch_colpass_cull(h, SA, segA, h->have_colmin);
+    else if (ra < 0)
+        prg::launch_colpass_scalar(h, RA, SA, segA);
+    else
+        prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
-                                                      (double)h->M / (double)h->Nglobal, h->D);
+                                                      (double)h->M / (double)h->Nglobal, h->D, h->colmin);
+    if (use_cull)
+        k_group_meta<<<grid1(h->Ncap / prg::kGroup), kBlock, 0, h->stream>>>(h->tgt4, h->Ncap / prg::kGroup, h->tmeta);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
-    if (rb < 0) prg::launch_rowpass_scalar(h, RB, SB, segB); else prg::launch_rowpass_packed(h, RB, SB, segB);
+    if (use_cull)
+        prg::launch_rowpass_cull(h, SB, segB);
+    else if (rb < 0)
+        prg::launch_rowpass_scalar(h, RB, SB, segB);
+    else
+        prg::launch_rowpass_packed(h, RB, SB, segB);
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
     const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
     k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
@@ -715,6 +873,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());
     h->have_estep = true;
+    h->have_colmin = !h->nonrigid;  // colmin now describes the z4 of this E-step (motion is measured against it)
     h->last_w = w;
     return PRG_OK;
 }
@@ -784,16 +943,17 @@ int prg_cpd_get_estep(prg_cpd* h, double* pt1_hd, double* p1_hd, double* px_hd) 
     const size_t need = (size_t)(h->N > h->M * h->D ? h->N : h->M * h->D) * sizeof(double);
     PRG_TRY(prg::ensure_stage(h, need));
     if (pt1_hd) {
-        k_float_to_double<<<grid1(h->N), kBlock, 0, h->stream>>>(h->pt1, (double*)h->stage, h->N);
+        k_float_to_double<<<grid1(h->N), kBlock, 0, h->stream>>>(h->pt1, (double*)h->stage, h->N, h->perm_tgt);
         PRG_HIP(hipMemcpyAsync(pt1_hd, h->stage, h->N * sizeof(double), hipMemcpyDefault, h->stream));
         PRG_HIP(hipStreamSynchronize(h->stream));
     }
     if (p1_hd) {
-        PRG_HIP(hipMemcpyAsync(p1_hd, h->rowacc, h->M * sizeof(double), hipMemcpyDefault, h->stream));
+        k_scatter_double<<<grid1(h->M), kBlock, 0, h->stream>>>(h->rowacc, (double*)h->stage, h->M, h->perm_src);
+        PRG_HIP(hipMemcpyAsync(p1_hd, h->stage, h->M * sizeof(double), hipMemcpyDefault, h->stream));
         PRG_HIP(hipStreamSynchronize(h->stream));
     }
     if (px_hd) {
-        k_pack_px<<<grid1(h->M), kBlock, 0, h->stream>>>(h->rowacc, h->Mcap, h->M, h->D, (double*)h->stage);
+        k_pack_px<<<grid1(h->M), kBlock, 0, h->stream>>>(h->rowacc, h->Mcap, h->M, h->D, (double*)h->stage, h->perm_src);
         PRG_HIP(hipMemcpyAsync(px_hd, h->stage, h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
         PRG_HIP(hipStreamSynchronize(h->stream));
     }
@@ -805,7 +965,7 @@ int prg_cpd_get_tsource(prg_cpd* h, float* tsource_hd) {
     PRG_REQUIRE(h && h->have_source && tsource_hd, PRG_ERR_STATE, "prg_cpd_get_tsource: source not set");
     prg::DeviceGuard g(h->device);
     PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(float)));
-    k_unpack_points<<<grid1(h->M), kBlock, 0, h->stream>>>(h->z4, h->M, h->D, (float*)h->stage);
+    k_unpack_points<<<grid1(h->M), kBlock, 0, h->stream>>>(h->z4, h->M, h->D, (float*)h->stage, h->perm_src);
     PRG_HIP(hipMemcpyAsync(tsource_hd, h->stage, h->M * h->D * sizeof(float), hipMemcpyDefault, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));
     return PRG_OK;
@@ -827,7 +987,7 @@ int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p
     PRG_HIP(hipMemcpyAsync(d_px, px_hd, nb_px, hipMemcpyDefault, h->stream));
     const int nblk = mom_blocks(h);
     k_moments_from_arrays<<<nblk, kBlock, 0, h->stream>>>(d_pt1, d_p1, d_px, h->D, h->M, h->N, h->src4, h->tgt4,
-                                                          h->mompart);
+                                                          h->perm_src, h->perm_tgt, h->mompart);
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));

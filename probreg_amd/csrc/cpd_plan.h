@@ -38,6 +38,16 @@ struct prg_cpd {
     // tuning (0 = auto)
     int r_col = 0, seg_col = 0, r_row = 0, seg_row = 0;
 
+    // spatial sorting + exact culling
+    bool opt_sort_src = true, opt_sort_tgt = true, opt_cull = true;
+    int* perm_src = nullptr;    // [M] sorted position -> original index (nullptr = identity order)
+    int* perm_tgt = nullptr;    // [N]
+    float* zmeta = nullptr;     // [Mcap/32][8] per group of 32 transformed source points: lo.xyz, hi.xyz, -, -
+    float* tmeta = nullptr;     // [Ncap/32][8] per group of 32 target points: lo.xyz, hi.xyz, max b_n, -
+    float* colmin = nullptr;    // [Ncap] min_m d^2 per column from the previous E-step (seed of the cull bound)
+    unsigned* motion = nullptr; // float bits of max_m |z_new - z_old| of the last transform
+    bool have_colmin = false;
+
     // staging for uploads / moments_from_estep
     void* stage = nullptr;
     size_t stage_bytes = 0;

@@ -11,6 +11,10 @@ constexpr int kColChunk = 8;   // source points consumed per column-pass loop tr
 constexpr int kRowChunk = 4;   // target points consumed per row-pass loop trip
 constexpr int kOverRead = 8;   // points read past the end of the last segment (software prefetch)
 
+constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
+// culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup
+void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed);
+void launch_rowpass_cull(prg_cpd* h, int S, int seg_len);
 void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len);
 void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len);
 void launch_colpass_scalar(prg_cpd* h, int R, int S, int seg_len);

@@ -173,3 +173,171 @@ void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len) {
 }
 
 }  // namespace prg
+
+// =============================================================================================
+// Culled sweeps.  Clouds are Morton-sorted at upload, so the 128 points a wave owns
+// and every group of 32 streamed points are spatially compact.  Per group one axis-aligned bounding box
+// (plus max b_n for the row pass) is fetched through SGPRs; if EVERY pair of the (wave, group) block is
+// provably an exact zero in fp32 - exp2 argument below -150 - the whole group is skipped.  Skipped terms are
+// exactly 0 (row pass) or below 2^-150 of a sum that is >= 1 (column pass), so the results are those of the
+// dense sweeps; what changes is that late EM iterations (small sigma) touch ~1 % of the pairs.
+// =============================================================================================
+namespace {
+
+constexpr float kCullLog2 = -150.0f;
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; };
+
+// squared distance between two axis-aligned boxes (0 if they overlap)
+__device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&ahi)[3], const GroupMeta& g) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float gap = fmaxf(fmaxf(alo[k] - g.hi[k], g.lo[k] - ahi[k]), 0.f);
+        d2 = fmaf(gap, gap, d2);
+    }
+    return d2;
+}
+
+// Column pass with culling.  Lane owns the 2 adjacent columns n0 + 2*tid, +1.  `colmin_prev` (may be null) holds
+// min_m d^2 of every column from the previous E-step and `motion` the largest displacement any source point made
+// since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle inequality), which is
+// what makes a far group's contribution provably < 2^-150 of the final column sum.
+__global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
+                                                         const GroupMeta* __restrict__ zmeta, int seg_len,
+                                                         const double* __restrict__ params,
+                                                         const float* __restrict__ colmin_prev,
+                                                         const unsigned* __restrict__ motion,
+                                                         float2* __restrict__ colpart, int64_t ncap) {
+    const float kk = (float)(-kLog2e / (2.0 * params[13]));
+    const int64_t n0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
+    const float4 a = tgt4[n0], b = tgt4[n0 + 1];
+    const f2 x = {a.x, b.x}, y = {a.y, b.y}, z = {a.z, b.z};
+    f2 run = splat(INFINITY), s = splat(0.f);
+    float lo[3], hi[3];
+    lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
+    lo[1] = wave_min(fminf(a.y, b.y)); hi[1] = wave_max(fmaxf(a.y, b.y));
+    lo[2] = wave_min(fminf(a.z, b.z)); hi[2] = wave_max(fmaxf(a.z, b.z));
+    float thr = INFINITY;  // skip a group when its box is farther than thr (squared) from the wave's box
+    if (colmin_prev) {
+        const float delta = __uint_as_float(*motion);
+        const float r0 = sqrtf(colmin_prev[n0]) + delta, r1 = sqrtf(colmin_prev[n0 + 1]) + delta;
+        const float seed = wave_max(fmaxf(r0 * r0, r1 * r1)) * 1.00001f;
+        thr = seed + kCullLog2 / kk;  // kk < 0: kk * (d2 - seed) < -150  <=>  d2 > seed + 150 / |kk|
+    }
+    const int64_t base = (int64_t)blockIdx.y * seg_len;
+    const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + base);
+    const GroupMeta* __restrict__ mp = zmeta + base / prg::kGroup;
+    const int ngroups = seg_len / prg::kGroup;
+    for (int g = 0; g < ngroups; ++g) {
+        const GroupMeta gm = mp[g];
+        const float bd2 = box_dist2(lo, hi, gm);
+        if (__builtin_amdgcn_readfirstlane((int)(bd2 > thr))) continue;
+        const Quad* __restrict__ q = zp + g * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const Quad qa = q[2 * t], qb = q[2 * t + 1];
+            f2 d2[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
+                d2[c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
+                d2[4 + c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+            }
+            f2 cm = d2[0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) cm = minv(cm, d2[c]);
+            if ((cm.x < run.x) | (cm.y < run.y)) {
+                const f2 nm = minv(run, cm);
+                s *= exp2v(splat(kk) * (run - nm));
+                run = nm;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) s += exp2v(splat(kk) * (d2[c] - run));
+        }
+    }
+    float4* out = reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.y * ncap + n0);
+    *out = make_float4(run.x, s.x, run.y, s.y);
+}
+
+// Row pass with culling.  Lane owns the 2 adjacent rows m0 + 2*tid, +1; a group is skipped when
+// kk * dist2(boxes) + max_n b_n < -150, i.e. every P of the block is exactly 0 in fp32.
+__global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
+                                                         const GroupMeta* __restrict__ tmeta, int seg_len,
+                                                         const double* __restrict__ params,
+                                                         float* __restrict__ rowpart, int64_t mcap) {
+    const float kk = (float)(-kLog2e / (2.0 * params[13]));
+    const int64_t m0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
+    const float4 a = z4[m0], b = z4[m0 + 1];
+    const f2 zx = {a.x, b.x}, zy = {a.y, b.y}, zz = {a.z, b.z};
+    f2 p1 = splat(0.f), ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), e = splat(0.f);
+    float lo[3], hi[3];
+    lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
+    lo[1] = wave_min(fminf(a.y, b.y)); hi[1] = wave_max(fmaxf(a.y, b.y));
+    lo[2] = wave_min(fminf(a.z, b.z)); hi[2] = wave_max(fmaxf(a.z, b.z));
+    const int64_t base = (int64_t)blockIdx.y * seg_len;
+    const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + base);
+    const GroupMeta* __restrict__ mp = tmeta + base / prg::kGroup;
+    const int ngroups = seg_len / prg::kGroup;
+    for (int g = 0; g < ngroups; ++g) {
+        const GroupMeta gm = mp[g];
+        const float bound = fmaf(box_dist2(lo, hi, gm), kk, gm.aux);
+        if (__builtin_amdgcn_readfirstlane((int)(bound < kCullLog2))) continue;
+        const Quad* __restrict__ q = tp + g * 8;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const Quad cur = q[t];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f2 dx = zx - splat(cur.q[c].x), dy = zy - splat(cur.q[c].y), dz = zz - splat(cur.q[c].z);
+                const f2 d = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                const f2 pr = exp2v(fmav(d, splat(kk), splat(cur.q[c].w)));
+                p1 += pr;
+                ux = fmav(pr, dx, ux);
+                uy = fmav(pr, dy, uy);
+                uz = fmav(pr, dz, uz);
+                e = fmav(pr, d, e);
+            }
+        }
+    }
+    float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
+    *reinterpret_cast<float2*>(o) = make_float2(p1.x, p1.y);
+    *reinterpret_cast<float2*>(o + mcap) = make_float2(-ux.x, -ux.y);
+    *reinterpret_cast<float2*>(o + 2 * mcap) = make_float2(-uy.x, -uy.y);
+    *reinterpret_cast<float2*>(o + 3 * mcap) = make_float2(-uz.x, -uz.y);
+    *reinterpret_cast<float2*>(o + 4 * mcap) = make_float2(e.x, e.y);
+}
+
+}  // namespace
+
+namespace prg {
+
+void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
+    dim3 grid((unsigned)ceil_div(h->N, kBlock * 2), (unsigned)S);
+    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta), seg_len,
+                                                   h->params, use_seed ? h->colmin : nullptr, h->motion, h->colpart,
+                                                   h->Ncap);
+}
+
+void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
+    dim3 grid((unsigned)ceil_div(h->M, kBlock * 2), (unsigned)S);
+    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len,
+                                                   h->params, h->rowpart, h->Mcap);
+}
+
+}  // namespace prg

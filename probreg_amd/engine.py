@@ -62,6 +62,9 @@ class CpdPlan(object):
             return a
         return np.ascontiguousarray(a, dtype=np.float32)
 
+    def set_options(self, sort_source=True, sort_target=True, cull=True):
+        check(lib.prg_cpd_set_options(self._h, int(sort_source), int(sort_target), int(cull)))
+
     def set_source(self, source):
         a = self._f32(source)
         self.m, self.dim = int(a.shape[0]), int(a.shape[1])

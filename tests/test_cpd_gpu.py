@@ -481,3 +481,71 @@ def test_constrained_nonrigid_vs_reference():
         if float(c["alpha"]) <= 1e-6:
             d = ts[c["idx_source"]] - c["target"][c["idx_target"]]
             assert np.max(np.abs(d)) < 1e-3 * extent
+
+
+# ---------------------------------------------------------------------------------------------
+# exact culling: same numbers as the dense sweeps
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("sigma2,w", [(3e-5, 0.0), (1e-3, 0.1), (0.05, 0.0)])
+def test_culled_sweeps_equal_dense_sweeps(sigma2, w):
+    """Default plan (Morton-sorted, culled) against a plan with sorting and culling switched off: the skipped
+    (wave, group) blocks are exact zeros, so moments, pt1, p1 and px agree to float32 summation order."""
+    from probreg_amd import _lib, synthetic
+    from probreg_amd.engine import CpdPlan
+
+    src, tgt, (r, t, _) = synthetic.rigid_pair(20000, m=15000, seed=51)
+    z = (src @ r.T + t)                      # aligned clouds: small sigma2 is meaningful
+    s32, t32 = (z - tgt.mean(0)).astype(np.float32), (tgt - tgt.mean(0)).astype(np.float32)
+    params = np.zeros(_lib.PRG_NPARAMS)
+    params[[0, 4, 8, 12]] = 1.0
+    params[13] = sigma2
+    out = []
+    for opts in (dict(sort_source=True, sort_target=True, cull=True), dict(sort_source=False, sort_target=False, cull=False)):
+        plan = CpdPlan()
+        plan.set_options(**opts)
+        plan.set_source(s32)
+        plan.set_target(t32)
+        plan.set_params(params)
+        plan.estep(w)
+        first = plan.get_moments()[:23]
+        plan.estep(w)                        # second E-step: the column pass now runs with the seeded bound
+        mom = plan.get_moments()[:23]
+        pt1, p1, px = plan.get_estep()
+        out.append((first, mom, pt1, p1, px))
+        plan.close()
+    (f0, m0, pt0, p0, x0), (f1, m1, pt1_, p1_, x1) = out
+    scale = np.max(np.abs(m1))
+    assert np.max(np.abs(f0 - f1)) <= 2e-6 * scale
+    assert np.max(np.abs(m0 - m1)) <= 2e-6 * scale
+    assert np.max(np.abs(pt0 - pt1_)) <= 2e-6
+    assert np.max(np.abs(p0 - p1_)) <= 2e-6 * np.max(p1_)
+    assert np.max(np.abs(x0 - x1)) <= 2e-6 * np.max(np.abs(x1))
+
+
+def test_culled_registration_tracks_dense_registration():
+    """30 EM iterations, culled vs dense, parameters compared every iteration (the seed of the column-pass bound
+    comes from the previous iteration's minima plus the measured source motion)."""
+    from probreg_amd import _lib, synthetic
+    from probreg_amd.engine import CpdPlan
+
+    src, tgt, _ = synthetic.rigid_pair(12000, seed=52)
+    s32, t32 = (src - src.mean(0)).astype(np.float32), (tgt - tgt.mean(0)).astype(np.float32)
+    plans = []
+    for cull in (True, False):
+        plan = CpdPlan()
+        plan.set_options(sort_source=cull, sort_target=cull, cull=cull)
+        plan.set_source(s32)
+        plan.set_target(t32)
+        plan.init_sums()
+        plan.init_params(None)
+        plans.append(plan)
+    for it in range(30):
+        ps = []
+        for plan in plans:
+            plan.estep(0.0)
+            plan.mstep(_lib.PRG_TF_RIGID, True)
+            ps.append(plan.get_params())
+        assert np.max(np.abs(ps[0][:13] - ps[1][:13])) < 2e-6, it
+        assert abs(ps[0][13] - ps[1][13]) <= 2e-6 * ps[1][13], it
+    for plan in plans:
+        plan.close()
