@@ -210,6 +210,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    start_params = plan.get_params()  # EM state at the start of the timed region (replayed below)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -219,17 +220,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    res = reg._result_from_params(plan.get_params())
 
-    # per-kernel timing with HIP events on the plan's stream (outside the timed region)
-    reps = 5
-    acc = {}
-    for _ in range(reps):
+    # Per-kernel timing with HIP events on the plan's stream: the SAME K iterations replayed from the saved
+    # state (the sweeps skip provably-zero blocks, so their duration depends on sigma2 and must be averaged
+    # over the same trajectory the timed region walked).
+    plan.set_params(start_params)
+    acc, first = {}, None
+    for _ in range(args.steps):
         ms = plan.estep_timed(0.0)
         reg._all_reduce_moments(plan)
         plan.mstep(kind_id, True)
+        first = first or dict(ms)
         for k, v in ms.items():
-            acc[k] = acc.get(k, 0.0) + v / reps
-    res = reg._result_from_params(plan.get_params())
+            acc[k] = acc.get(k, 0.0) + v / args.steps
+    last = dict(ms)
 
     if rank == 0:
         m_pts, n_loc = plan.m, plan.n
@@ -277,11 +282,17 @@ def main():
                             "avg_launch_ms": acc["colpass"]},
                 "e_step": {"algorithmic_bytes": row_bytes + col_bytes, "ms": acc["total"],
                            "frac": (row_bytes + col_bytes) / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "dense_regime": {"avg_launch_ms": first["rowpass"],
+                                 "frac": row_bytes / (first["rowpass"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "what": "first timed iteration: sigma2 still large, no (wave, group) block is "
+                                         "skipped - the sweep's VALU-bound throughput on all M x N pairs"},
                 "note": "algorithmic bytes = the reference formulation's irreducible fp32 traffic (8 B per "
-                        "source-target pair per E-step); the fused kernels keep P in registers, so physical "
-                        "HBM traffic is MBs and the kernels are VALU/transcendental bound (DESIGN.md section 5)",
+                        "source-target pair per E-step); the fused kernels keep P in registers and skip blocks "
+                        "whose every pair is an exact fp32 zero, so physical HBM traffic is MBs and the kernels "
+                        "are VALU/transcendental bound (DESIGN.md section 3.1)",
             },
-            "kernel_ms": acc,
+            "kernel_ms": {"mean_over_timed_iterations": acc, "first_timed_iteration": first,
+                          "last_timed_iteration": last},
             "result": {"sigma2": res.sigma2, "q": res.q},
         }
         if kind == "rigid":
