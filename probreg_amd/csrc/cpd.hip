@@ -171,25 +171,42 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
     if ((threadIdx.x & 63) == 0 && moved > 0.f) atomicMax(motion, __float_as_uint(moved));
 }
 
-// bounding box (+ max of .w) of every group of 32 consecutive points -> meta[g][8] = lo.xyz, hi.xyz, max w, 0
+// bounding box (+ range of .w) of every group of 32 consecutive points -> meta[g][8] = lo.xyz, hi.xyz, max w, min w
 __global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict__ pts, int64_t ngroups,
                                                        float* __restrict__ meta) {
     const int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (g >= ngroups) return;
     const float4* p = pts + g * prg::kGroup;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = -INFINITY;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = -INFINITY,
+          wmin = INFINITY;
     for (int k = 0; k < prg::kGroup; ++k) {
         const float4 v = p[k];
         lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
         lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
         lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
         wmax = fmaxf(wmax, v.w);
+        wmin = fminf(wmin, v.w);
     }
     float* o = meta + g * 8;
     o[0] = lo[0]; o[1] = lo[1]; o[2] = lo[2];
     o[3] = hi[0]; o[4] = hi[1]; o[5] = hi[2];
     o[6] = wmax;
-    o[7] = 0.f;
+    o[7] = wmin;
+}
+
+// super-group boxes: union of 8 consecutive group boxes (max / min of the aux range)
+__global__ __launch_bounds__(kBlock) void k_super_meta(const float* __restrict__ meta, int64_t nsuper,
+                                                       float* __restrict__ smeta) {
+    const int64_t sg = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (sg >= nsuper) return;
+    float o[8] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, INFINITY};
+    for (int k = 0; k < 8; ++k) {
+        const float* m = meta + (sg * 8 + k) * 8;
+        for (int c = 0; c < 3; ++c) { o[c] = fminf(o[c], m[c]); o[3 + c] = fmaxf(o[3 + c], m[3 + c]); }
+        o[6] = fmaxf(o[6], m[6]);
+        o[7] = fminf(o[7], m[7]);
+    }
+    for (int c = 0; c < 8; ++c) smeta[sg * 8 + c] = o[c];
 }
 
 // (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip)
@@ -500,10 +517,10 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion})
+                    (void*)h->motion, (void*)h->zsmeta, (void*)h->tsmeta})
         if (q) (void)hipFree(q);
     h->perm_src = h->perm_tgt = nullptr;
-    h->zmeta = h->tmeta = h->colmin = nullptr;
+    h->zmeta = h->tmeta = h->colmin = h->zsmeta = h->tsmeta = nullptr;
     h->motion = nullptr;
     h->src4 = h->z4 = h->tgt4 = nullptr;
     h->pt1 = nullptr;
@@ -527,7 +544,8 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
     return PRG_OK;
 }
 
-int cap_for(int64_t n) { return (int)prg::round_up(n + 3072, 1024); }
+// capacity: the cloud + room for 64 segments each rounded up to a 256-point super-group + prefetch slack
+int cap_for(int64_t n) { return (int)prg::round_up(n + 64 * prg::kSuper + 1024, 1024); }
 
 // Morton (Z-curve) order of a cloud: sorted position -> original index.  One-off host work at upload
 // (std::sort over n 64-bit keys: ~10 ms per 100k points).
@@ -669,6 +687,8 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     }
     if (cap != h->Mcap || !h->zmeta) {
         PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
+        PRG_TRY(ensure_exact(&h->zsmeta, (size_t)(cap / prg::kSuper + 1) * 8));
+        PRG_HIP(hipMemsetAsync(h->zsmeta, 0, (size_t)(cap / prg::kSuper + 1) * 8 * sizeof(float), h->stream));
         if (!h->motion) PRG_TRY(ensure_exact(&h->motion, 1));
     }
     h->M = m;
@@ -714,6 +734,8 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     }
     if (cap != h->Ncap || !h->tmeta) {
         PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
+        PRG_TRY(ensure_exact(&h->tsmeta, (size_t)(cap / prg::kSuper + 1) * 8));
+        PRG_HIP(hipMemsetAsync(h->tsmeta, 0, (size_t)(cap / prg::kSuper + 1) * 8 * sizeof(float), h->stream));
         PRG_TRY(ensure_exact(&h->colmin, (size_t)cap));
         PRG_HIP(hipMemsetAsync(h->colmin, 0, (size_t)cap * sizeof(float), h->stream));
     }
@@ -826,7 +848,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;
     // segment lengths are multiples of the loop trip (8 points, or one 32-point group); the pads absorb the
     // overshoot and the prefetch over-read of the last segment
-    const int quantum = use_cull ? prg::kGroup : 8;
+    const int quantum = use_cull ? prg::kSuper : 8;
     auto seg_of = [quantum](int64_t len, int s) { return (int)prg::round_up(prg::ceil_div(len, s), quantum); };
     int segA = seg_of(h->M, SA), segB = seg_of(h->N, SB);
     while (SA > 1 && (int64_t)SA * segA + prg::kOverRead > h->Mcap) --SA, segA = seg_of(h->M, SA);
@@ -844,8 +866,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     else
         k_transform_linear<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->Mcap, h->params,
                                                                      h->motion);
-    if (use_cull)
+    if (use_cull) {
         k_group_meta<<<grid1(h->Mcap / prg::kGroup), kBlock, 0, h->stream>>>(h->z4, h->Mcap / prg::kGroup, h->zmeta);
+        k_super_meta<<<grid1(h->Mcap / prg::kSuper), kBlock, 0, h->stream>>>(h->zmeta, h->Mcap / prg::kSuper, h->zsmeta);
+    }
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, h->have_colmin);
@@ -856,8 +880,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       (double)h->M / (double)h->Nglobal, h->D, h->colmin);
-    if (use_cull)
+    if (use_cull) {
         k_group_meta<<<grid1(h->Ncap / prg::kGroup), kBlock, 0, h->stream>>>(h->tgt4, h->Ncap / prg::kGroup, h->tmeta);
+        k_super_meta<<<grid1(h->Ncap / prg::kSuper), kBlock, 0, h->stream>>>(h->tmeta, h->Ncap / prg::kSuper, h->tsmeta);
+    }
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);

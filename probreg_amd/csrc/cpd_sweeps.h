@@ -12,6 +12,7 @@ constexpr int kRowChunk = 4;   // target points consumed per row-pass loop trip
 constexpr int kOverRead = 8;   // points read past the end of the last segment (software prefetch)
 
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
+constexpr int kSuper = 256;    // streamed points per super-group (8 groups); culled segments are multiples of this
 // culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup
 void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed);
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len);

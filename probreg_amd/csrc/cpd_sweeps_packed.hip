@@ -210,12 +210,28 @@ __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&
     return d2;
 }
 
+// largest squared distance between any two points of two boxes
+__device__ __forceinline__ float box_maxdist2(const float (&alo)[3], const float (&ahi)[3], const GroupMeta& g) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float far = fmaxf(ahi[k] - g.lo[k], g.hi[k] - alo[k]);
+        d2 = fmaf(far, far, d2);
+    }
+    return d2;
+}
+
+// Two-level metadata: `smeta` holds one box per super-group of 256 streamed points (lo, hi, max aux, min aux),
+// `gmeta` one per group of 32.  A wave first tests the super-group (one scalar load, prefetched one trip ahead);
+// only if it cannot be skipped as a whole AND is not provably needed as a whole are the 8 group boxes consulted.
+
 // Column pass with culling.  Lane owns the 2 adjacent columns n0 + 2*tid, +1.  `colmin_prev` (may be null) holds
 // min_m d^2 of every column from the previous E-step and `motion` the largest displacement any source point made
 // since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle inequality), which is
 // what makes a far group's contribution provably < 2^-150 of the final column sum.
 __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
-                                                         const GroupMeta* __restrict__ zmeta, int seg_len,
+                                                         const GroupMeta* __restrict__ zmeta,
+                                                         const GroupMeta* __restrict__ zsmeta, int seg_len,
                                                          const double* __restrict__ params,
                                                          const float* __restrict__ colmin_prev,
                                                          const unsigned* __restrict__ motion,
@@ -238,37 +254,50 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
     }
     const int64_t base = (int64_t)blockIdx.y * seg_len;
     const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + base);
-    const GroupMeta* __restrict__ mp = zmeta + base / prg::kGroup;
-    const int ngroups = seg_len / prg::kGroup;
-    for (int g = 0; g < ngroups; ++g) {
-        const GroupMeta gm = mp[g];
-        const float bd2 = box_dist2(lo, hi, gm);
-        if (__builtin_amdgcn_readfirstlane((int)(bd2 > thr))) continue;
-        const Quad* __restrict__ q = zp + g * 8;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const Quad qa = q[2 * t], qb = q[2 * t + 1];
-            f2 d2[8];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
-                d2[c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+    const GroupMeta* __restrict__ gp = zmeta + base / prg::kGroup;
+    const GroupMeta* __restrict__ sp = zsmeta + base / prg::kSuper;
+    const int nsuper = seg_len / prg::kSuper;
+    GroupMeta sm = sp[0];
+    for (int sg = 0; sg < nsuper; ++sg) {
+        const GroupMeta cur = sm;
+        sm = sp[sg + 1];  // prefetch (the array has one spare entry)
+        if (__builtin_amdgcn_readfirstlane((int)(box_dist2(lo, hi, cur) > thr))) continue;
+        const bool all = box_maxdist2(lo, hi, cur) <= thr;  // no group of this super-group can be skipped
+#pragma unroll 1
+        for (int g8 = 0; g8 < 8; ++g8) {
+            const int g = sg * 8 + g8;
+            if (!__builtin_amdgcn_readfirstlane((int)all)) {
+                const GroupMeta gm = gp[g];
+                if (__builtin_amdgcn_readfirstlane((int)(box_dist2(lo, hi, gm) > thr))) continue;
             }
+            const Quad* __restrict__ q = zp + g * 8;
+            Quad qa = q[0];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
-                d2[4 + c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+            for (int t = 0; t < 4; ++t) {
+                const Quad qb = q[2 * t + 1];
+                f2 d2[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
+                    d2[c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                }
+                if (t < 3) qa = q[2 * t + 2];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
+                    d2[4 + c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                }
+                f2 cm = d2[0];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) cm = minv(cm, d2[c]);
+                if ((cm.x < run.x) | (cm.y < run.y)) {
+                    const f2 nm = minv(run, cm);
+                    s *= exp2v(splat(kk) * (run - nm));
+                    run = nm;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) s += exp2v(splat(kk) * (d2[c] - run));
             }
-            f2 cm = d2[0];
-#pragma unroll
-            for (int c = 1; c < 8; ++c) cm = minv(cm, d2[c]);
-            if ((cm.x < run.x) | (cm.y < run.y)) {
-                const f2 nm = minv(run, cm);
-                s *= exp2v(splat(kk) * (run - nm));
-                run = nm;
-            }
-#pragma unroll
-            for (int c = 0; c < 8; ++c) s += exp2v(splat(kk) * (d2[c] - run));
         }
     }
     float4* out = reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.y * ncap + n0);
@@ -278,7 +307,8 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
 // Row pass with culling.  Lane owns the 2 adjacent rows m0 + 2*tid, +1; a group is skipped when
 // kk * dist2(boxes) + max_n b_n < -150, i.e. every P of the block is exactly 0 in fp32.
 __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
-                                                         const GroupMeta* __restrict__ tmeta, int seg_len,
+                                                         const GroupMeta* __restrict__ tmeta,
+                                                         const GroupMeta* __restrict__ tsmeta, int seg_len,
                                                          const double* __restrict__ params,
                                                          float* __restrict__ rowpart, int64_t mcap) {
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
@@ -292,26 +322,40 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
     lo[2] = wave_min(fminf(a.z, b.z)); hi[2] = wave_max(fmaxf(a.z, b.z));
     const int64_t base = (int64_t)blockIdx.y * seg_len;
     const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + base);
-    const GroupMeta* __restrict__ mp = tmeta + base / prg::kGroup;
-    const int ngroups = seg_len / prg::kGroup;
-    for (int g = 0; g < ngroups; ++g) {
-        const GroupMeta gm = mp[g];
-        const float bound = fmaf(box_dist2(lo, hi, gm), kk, gm.aux);
-        if (__builtin_amdgcn_readfirstlane((int)(bound < kCullLog2))) continue;
-        const Quad* __restrict__ q = tp + g * 8;
+    const GroupMeta* __restrict__ gp = tmeta + base / prg::kGroup;
+    const GroupMeta* __restrict__ sp = tsmeta + base / prg::kSuper;
+    const int nsuper = seg_len / prg::kSuper;
+    GroupMeta sm = sp[0];
+    for (int sg = 0; sg < nsuper; ++sg) {
+        const GroupMeta cur = sm;
+        sm = sp[sg + 1];  // prefetch
+        // cur.aux = max b_n, cur.pad = min b_n over the 256 points
+        if (__builtin_amdgcn_readfirstlane((int)(fmaf(box_dist2(lo, hi, cur), kk, cur.aux) < kCullLog2))) continue;
+        const bool all = fmaf(box_maxdist2(lo, hi, cur), kk, cur.pad) > kCullLog2;  // every P is non-zero
+#pragma unroll 1
+        for (int g8 = 0; g8 < 8; ++g8) {
+            const int g = sg * 8 + g8;
+            if (!__builtin_amdgcn_readfirstlane((int)all)) {
+                const GroupMeta gm = gp[g];
+                if (__builtin_amdgcn_readfirstlane((int)(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2))) continue;
+            }
+            const Quad* __restrict__ q = tp + g * 8;
+            Quad cq = q[0];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const Quad cur = q[t];
+            for (int t = 0; t < 8; ++t) {
+                const Quad nq = q[t < 7 ? t + 1 : t];  // prefetch the next quad of this group
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f2 dx = zx - splat(cur.q[c].x), dy = zy - splat(cur.q[c].y), dz = zz - splat(cur.q[c].z);
-                const f2 d = fmav(dz, dz, fmav(dy, dy, dx * dx));
-                const f2 pr = exp2v(fmav(d, splat(kk), splat(cur.q[c].w)));
-                p1 += pr;
-                ux = fmav(pr, dx, ux);
-                uy = fmav(pr, dy, uy);
-                uz = fmav(pr, dz, uz);
-                e = fmav(pr, d, e);
+                for (int c = 0; c < 4; ++c) {
+                    const f2 dx = zx - splat(cq.q[c].x), dy = zy - splat(cq.q[c].y), dz = zz - splat(cq.q[c].z);
+                    const f2 d = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                    const f2 pr = exp2v(fmav(d, splat(kk), splat(cq.q[c].w)));
+                    p1 += pr;
+                    ux = fmav(pr, dx, ux);
+                    uy = fmav(pr, dy, uy);
+                    uz = fmav(pr, dz, uz);
+                    e = fmav(pr, d, e);
+                }
+                cq = nq;
             }
         }
     }
@@ -329,15 +373,16 @@ namespace prg {
 
 void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
     dim3 grid((unsigned)ceil_div(h->N, kBlock * 2), (unsigned)S);
-    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta), seg_len,
-                                                   h->params, use_seed ? h->colmin : nullptr, h->motion, h->colpart,
-                                                   h->Ncap);
+    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
+                                                   reinterpret_cast<const GroupMeta*>(h->zsmeta), seg_len, h->params,
+                                                   use_seed ? h->colmin : nullptr, h->motion, h->colpart, h->Ncap);
 }
 
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->M, kBlock * 2), (unsigned)S);
-    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len,
-                                                   h->params, h->rowpart, h->Mcap);
+    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta),
+                                                   reinterpret_cast<const GroupMeta*>(h->tsmeta), seg_len, h->params,
+                                                   h->rowpart, h->Mcap);
 }
 
 }  // namespace prg
