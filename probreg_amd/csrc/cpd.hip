@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     double ssum = 0.0;
     for (int s = 0; s < nseg; ++s) {
         const float2 p = colpart[(int64_t)s * ncap + i];
-        ssum += (double)p.y * exp2(kk * ((double)p.x - (double)gmin));
+        if (p.y != 0.f) ssum += (double)p.y * exp2(kk * ((double)p.x - (double)gmin));  // culled segments are empty
     }
     const double den = ssum * exp2(kk * (double)gmin);  // underflows to 0 exactly where fp64 exp() does
     double c = pow(2.0 * M_PI * sigma2, dim * 0.5);
@@ -494,12 +494,12 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const float4* __restri
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
 // choose the segment count so that the grid has a few thousand blocks and segments stay long
-// Segment count for the streamed axis: ~3k streamed points per workgroup (tens of microseconds of work, so
-// the prologue / partial-store epilogue and the fp64 merge kernels stay small), but at least ~1k workgroups
-// in the grid (4 per CU) as long as segments keep >= 256 points.  C1 on one GPU -> 32 segments (6.3k
-// workgroups, profiles/r1_estep_tuning_sweep.log); an 8-way target shard (12.5k local columns) -> 6.
+// Segment count for the streamed axis: ~1.5k streamed points per workgroup, at least ~1k workgroups in the
+// grid (4 per CU) as long as segments keep >= 256 points, at most 64 segments.  C1 on one GPU -> 64 segments
+// (12.5k workgroups: best both in the dense and in the culled regime, tools/cull_floor.py); an 8-way target
+// shard (12.5k local columns) -> 8.
 int auto_segments(int64_t nblk_x, int64_t stream_len) {
-    int64_t s = stream_len / 3072;
+    int64_t s = stream_len / 1536;
     if (s < 1) s = 1;
     while (s * nblk_x < 1024 && stream_len / (s + 1) >= 256) ++s;
     if (s > 64) s = 64;
@@ -845,7 +845,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     int SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M);
     int SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N);
     // Culled sweeps need both clouds Morton-sorted (compact waves / groups); they walk the stream in groups of 32.
-    const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;
+    const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;  // (segment counts stay tunable)
     // segment lengths are multiples of the loop trip (8 points, or one 32-point group); the pads absorb the
     // overshoot and the prefetch over-read of the last segment
     const int quantum = use_cull ? prg::kSuper : 8;
