@@ -139,17 +139,60 @@ __global__ void k_init_params(double* __restrict__ moments, const double* __rest
     for (int i = 24; i < PRG_NMOMENTS; ++i) moments[i] = 0.0;
 }
 
-// z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).
+// half-wave (32-lane) reductions: a cull group is 32 consecutive points = one half of a wave
+__device__ __forceinline__ float half_min(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Writes the 8 group boxes and the super-group box of the 256 points this workgroup holds (one point per thread).
+// aux_lo / aux_hi < 0: only the aux range is refreshed (the boxes of a static cloud were written at upload).
+__device__ __forceinline__ void block_group_meta(float x, float y, float z, float wmax_in, float wmin_in,
+                                                 bool write_boxes, float* __restrict__ gmeta,
+                                                 float* __restrict__ smeta) {
+    __shared__ float sh[8][8];
+    float v[8];
+    v[0] = half_min(x); v[1] = half_min(y); v[2] = half_min(z);
+    v[3] = half_max(x); v[4] = half_max(y); v[5] = half_max(z);
+    v[6] = half_max(wmax_in);
+    v[7] = half_min(wmin_in);
+    const int gl = threadIdx.x >> 5;  // group within the block
+    if ((threadIdx.x & 31) == 0) {
+        float* o = gmeta + ((int64_t)blockIdx.x * 8 + gl) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (write_boxes || c >= 6) o[c] = v[c];
+            sh[gl][c] = v[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int c = threadIdx.x;
+        if (write_boxes || c >= 6) {
+            float r = sh[0][c];
+            for (int k = 1; k < 8; ++k) r = (c < 3 || c == 7) ? fminf(r, sh[k][c]) : fmaxf(r, sh[k][c]);
+            smeta[(int64_t)blockIdx.x * 8 + c] = r;
+        }
+    }
+}
+
+// z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).  The same kernel measures
+// how far the source moved since the previous E-step (cull bound of k_colpass_cull) and writes the group /
+// super-group boxes of the transformed cloud.  grid = cap / 256, one point per thread.
 __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __restrict__ src4, float4* __restrict__ z4,
-                                                             int64_t m, int64_t cap,
-                                                             const double* __restrict__ params,
-                                                             unsigned* __restrict__ motion) {
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+                                                             int64_t m, const double* __restrict__ params,
+                                                             unsigned* __restrict__ motion, int slot,
+                                                             float* __restrict__ gmeta, float* __restrict__ smeta) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     float moved = 0.f;
     float4 o;
-    if (i >= cap) {
-        o = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (i < m) {
+    if (i < m) {
         const double s = params[12];
         float4 y = src4[i];
         double yx = y.x, yy = y.y, yz = y.z;
@@ -157,18 +200,21 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
         o.y = (float)(s * (params[3] * yx + params[4] * yy + params[5] * yz) + params[10]);
         o.z = (float)(s * (params[6] * yx + params[7] * yy + params[8] * yz) + params[11]);
         o.w = 0.f;
-        const float4 old = z4[i];  // how far did this point move since the last E-step (cull bound, see k_colpass_cull)
+        const float4 old = z4[i];
         const float dx = o.x - old.x, dy = o.y - old.y, dz = o.z - old.z;
         moved = sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f;
     } else {
         o.x = o.y = o.z = prg::kSrcPad;
         o.w = 0.f;
     }
-    if (i < cap) z4[i] = o;
-    // non-negative floats order like their bit patterns: one atomicMax per wave
+    z4[i] = o;
+    // non-negative floats order like their bit patterns: one atomicMax per wave into this E-step's slot; the other
+    // slot (next E-step's) is cleared here - nobody touches it until the next launch of this kernel
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) moved = fmaxf(moved, __shfl_xor(moved, off, 64));
-    if ((threadIdx.x & 63) == 0 && moved > 0.f) atomicMax(motion, __float_as_uint(moved));
+    if ((threadIdx.x & 63) == 0 && moved > 0.f) atomicMax(motion + slot, __float_as_uint(moved));
+    if (i == 0) motion[slot ^ 1] = 0u;
+    block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta, smeta);
 }
 
 // bounding box (+ range of .w) of every group of 32 consecutive points -> meta[g][8] = lo.xyz, hi.xyz, max w, min w
@@ -217,9 +263,11 @@ __global__ __launch_bounds__(kBlock) void k_super_meta(const float* __restrict__
 __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, const float2* __restrict__ colpart,
                                                      int nseg, int64_t ncap, int64_t n, float* __restrict__ pt1,
                                                      const double* __restrict__ params, double w, double m_over_n,
-                                                     int dim, float* __restrict__ colmin) {
+                                                     int dim, float* __restrict__ colmin, float* __restrict__ gmeta,
+                                                     float* __restrict__ smeta) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    float b = 0.f;  // pads keep b = 0
+    if (i < n) {
     const double sigma2 = params[13];
     const float kkf = (float)(-kLog2e / (2.0 * sigma2));
     const double kk = (double)kkf;
@@ -233,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     const double den = ssum * exp2(kk * (double)gmin);  // underflows to 0 exactly where fp64 exp() does
     double c = pow(2.0 * M_PI * sigma2, dim * 0.5);
     c *= w / (1.0 - w) * m_over_n;
-    float b, p;
+    float p;
     if (den == 0.0) {
         b = -INFINITY;
         p = 0.f;
@@ -245,6 +293,9 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     reinterpret_cast<float*>(tgt4 + i)[3] = b;
     pt1[i] = p;
     colmin[i] = gmin;  // min_m |x_n - z_m|^2 of this E-step: seed of the next column pass' cull bound
+    }
+    // refresh the b_n range of this workgroup's 8 groups / 1 super-group (their boxes are static)
+    if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta, smeta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,49 +409,66 @@ __global__ __launch_bounds__(kBlock) void k_moments_from_arrays(const double* __
 __global__ void k_mstep(const double* __restrict__ mom, double* __restrict__ params, int kind, int update_scale,
                         int dim) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // NB: every array index below is a compile-time constant after unrolling (run-time indices would push the
+    // 3 x 3 arrays into scratch memory and cost ~1 us per access); the D = 2 case lives in the upper-left block
+    // of the same 3 x 3 problem (z = 0 makes the third row / column of every moment vanish).
     const int d = dim;
     const double S0 = mom[0];
     double mu_x[3], mu_y[3], A[3][3], YPY[3][3];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
         mu_x[i] = mom[1 + i] / S0;  // cpd.py:169
         mu_y[i] = mom[4 + i] / S0;  // cpd.py:170
     }
     // a = px^T (Y - mu_y) - mu_x (p1^T (Y - mu_y)) ; the second term is identically 0   (cpd.py:173-175)
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) A[i][j] = mom[7 + 3 * i + j] - mom[1 + i] * mu_y[j];
     const double syy[3][3] = {{mom[16], mom[17], mom[18]}, {mom[17], mom[19], mom[20]}, {mom[18], mom[20], mom[21]}};
     double tr_yp1y = 0.0, mux2 = 0.0;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
+#pragma unroll
         for (int j = 0; j < 3; ++j) YPY[i][j] = syy[i][j] - S0 * mu_y[i] * mu_y[j];  // (Y-mu)^T diag(p1) (Y-mu)
-        if (i < d) tr_yp1y += YPY[i][i];
+        tr_yp1y += YPY[i][i];
         mux2 += mu_x[i] * mu_x[i];
     }
     const double tr_xp1x = mom[22] - S0 * mux2;  // cpd.py:183 / 237
-    double L[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    double t[3] = {0, 0, 0};
+    double L[3][3], t[3];
     double scale = 1.0, sigma2, q;
     if (kind == PRG_TF_RIGID) {
         double U[3][3], V[3][3], sv[3];
         prg::jacobi_svd(A, d, U, V, sv);
         // rot = U diag(1,..,det(U V^T)) V^T with the correction on the smallest singular value (cpd.py:176-179)
-        int jmin = 0;
-        for (int j = 1; j < d; ++j)
-            if (sv[j] < sv[jmin]) jmin = j;
         const double dd = prg::det3(U, d) * prg::det3(V, d);
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) {
-                double r = 0;
-                for (int k = 0; k < d; ++k) r += (k == jmin ? dd : 1.0) * U[i][k] * V[j][k];
-                L[i][j] = r;
-            }
+        double c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            bool is_min = k < d;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (j < d && j != k && (sv[j] < sv[k] || (sv[j] == sv[k] && j < k))) is_min = false;
+            c[k] = is_min ? dd : 1.0;
+        }
         double tr_atr = 0.0;
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) tr_atr += A[i][j] * L[i][j];  // trace(a^T rot), cpd.py:180
-        scale = update_scale ? tr_atr / tr_yp1y : 1.0;                // cpd.py:182
-        for (int i = 0; i < d; ++i) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double r = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r += c[k] * U[i][k] * V[j][k];
+                L[i][j] = r;
+                tr_atr += (i < d && j < d) ? A[i][j] * r : 0.0;  // trace(a^T rot), cpd.py:180
+            }
+        scale = update_scale ? tr_atr / tr_yp1y : 1.0;  // cpd.py:182
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
             double r = 0;
-            for (int j = 0; j < d; ++j) r += L[i][j] * mu_y[j];
-            t[i] = mu_x[i] - scale * r;  // cpd.py:183
+#pragma unroll
+            for (int j = 0; j < 3; ++j) r += L[i][j] * mu_y[j];
+            t[i] = (i < d) ? mu_x[i] - scale * r : 0.0;  // cpd.py:183
         }
         if (update_scale)
             sigma2 = (tr_xp1x - scale * tr_atr) / (S0 * d);  // cpd.py:186
@@ -410,41 +478,55 @@ __global__ void k_mstep(const double* __restrict__ mom, double* __restrict__ par
         q = (tr_xp1x - 2.0 * scale * tr_atr + scale * scale * tr_yp1y) / (2.0 * sigma2);
         q += d * S0 * 0.5 * log(sigma2);  // cpd.py:190-191
     } else {
-        // b = solve(yp1y^T, a^T)^T : Gaussian elimination with partial pivoting on the d x d system (cpd.py:235)
+        // b = solve(yp1y^T, a^T)^T : Gaussian elimination with partial pivoting (cpd.py:235) on the 3 x 3 embedding
+        // [yp1y^T | a^T] with a unit diagonal in the unused dimension
         double Mx[3][6];
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) {
-                Mx[i][j] = YPY[j][i];
-                Mx[i][d + j] = A[j][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bool in = i < d && j < d;
+                Mx[i][j] = in ? YPY[j][i] : ((i == j) ? 1.0 : 0.0);
+                Mx[i][3 + j] = in ? A[j][i] : 0.0;
             }
-        for (int c = 0; c < d; ++c) {
-            int piv = c;
-            for (int r = c + 1; r < d; ++r)
-                if (fabs(Mx[r][c]) > fabs(Mx[piv][c])) piv = r;
-            if (piv != c)
-                for (int j = 0; j < 2 * d; ++j) { double tmp = Mx[c][j]; Mx[c][j] = Mx[piv][j]; Mx[piv][j] = tmp; }
-            for (int r = c + 1; r < d; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int r = c + 1; r < 3; ++r) {  // bring the largest pivot candidate up by conditional row swaps
+                if (fabs(Mx[r][c]) > fabs(Mx[c][c])) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) { const double tmp = Mx[c][j]; Mx[c][j] = Mx[r][j]; Mx[r][j] = tmp; }
+                }
+            }
+#pragma unroll
+            for (int r = c + 1; r < 3; ++r) {
                 const double f = Mx[r][c] / Mx[c][c];
-                for (int j = c; j < 2 * d; ++j) Mx[r][j] -= f * Mx[c][j];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Mx[r][j] -= (j >= c) ? f * Mx[c][j] : 0.0;
             }
         }
         double Xs[3][3];
-        for (int col = 0; col < d; ++col)
-            for (int r = d - 1; r >= 0; --r) {
-                double v = Mx[r][d + col];
-                for (int j = r + 1; j < d; ++j) v -= Mx[r][j] * Xs[j][col];
+#pragma unroll
+        for (int col = 0; col < 3; ++col)
+#pragma unroll
+            for (int r = 2; r >= 0; --r) {
+                double v = Mx[r][3 + col];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v -= (j > r) ? Mx[r][j] * Xs[j][col] : 0.0;
                 Xs[r][col] = v / Mx[r][r];
             }
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) L[i][j] = Xs[j][i];
         double tr_ab = 0.0;
-        for (int i = 0; i < d; ++i) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
             double r = 0;
-            for (int j = 0; j < d; ++j) {
-                r += L[i][j] * mu_y[j];
-                tr_ab += A[i][j] * L[i][j];  // trace(a b^T), cpd.py:238,240
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bool in = i < d && j < d;
+                L[i][j] = in ? Xs[j][i] : ((i == j) ? 1.0 : 0.0);
+                r += in ? L[i][j] * mu_y[j] : 0.0;
+                tr_ab += in ? A[i][j] * L[i][j] : 0.0;  // trace(a b^T), cpd.py:238,240
             }
-            t[i] = mu_x[i] - r;  // cpd.py:236
+            t[i] = (i < d) ? mu_x[i] - r : 0.0;  // cpd.py:236
         }
         sigma2 = (tr_xp1x - tr_ab) / (S0 * d);  // cpd.py:239
         sigma2 = fmax(sigma2, kEps32);
@@ -689,7 +771,10 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
         PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
         PRG_TRY(ensure_exact(&h->zsmeta, (size_t)(cap / prg::kSuper + 1) * 8));
         PRG_HIP(hipMemsetAsync(h->zsmeta, 0, (size_t)(cap / prg::kSuper + 1) * 8 * sizeof(float), h->stream));
-        if (!h->motion) PRG_TRY(ensure_exact(&h->motion, 1));
+        if (!h->motion) {
+            PRG_TRY(ensure_exact(&h->motion, 2));
+            PRG_HIP(hipMemsetAsync(h->motion, 0, 2 * sizeof(unsigned), h->stream));
+        }
     }
     h->M = m;
     h->D = dim;
@@ -753,6 +838,9 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     PRG_HIP(hipMemcpyAsync(h->stage, target_hd, (size_t)n_local * dim * sizeof(float), hipMemcpyDefault, h->stream));
     k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, n_local, dim, h->tgt4, cap,
                                                        prg::kTgtPad, 0.f, h->perm_tgt);
+    // the target never moves: its group / super-group boxes are written once (k_colfinal refreshes the b_n range)
+    k_group_meta<<<grid1(cap / prg::kGroup), kBlock, 0, h->stream>>>(h->tgt4, cap / prg::kGroup, h->tmeta);
+    k_super_meta<<<grid1(cap / prg::kSuper), kBlock, 0, h->stream>>>(h->tmeta, cap / prg::kSuper, h->tsmeta);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
     h->have_colmin = false;
@@ -860,16 +948,13 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_TRY(ensure_mompart(h));
 
     if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
-    PRG_HIP(hipMemsetAsync(h->motion, 0, sizeof(unsigned), h->stream));
+    const int slot = (int)(h->estep_count & 1);
+    ++h->estep_count;
     if (h->nonrigid)
         PRG_TRY(prg::nonrigid_transform(h));
-    else
-        k_transform_linear<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->Mcap, h->params,
-                                                                     h->motion);
-    if (use_cull) {
-        k_group_meta<<<grid1(h->Mcap / prg::kGroup), kBlock, 0, h->stream>>>(h->z4, h->Mcap / prg::kGroup, h->zmeta);
-        k_super_meta<<<grid1(h->Mcap / prg::kSuper), kBlock, 0, h->stream>>>(h->zmeta, h->Mcap / prg::kSuper, h->zsmeta);
-    }
+    else  // one fused kernel: transform, source motion, group / super-group boxes of the transformed cloud
+        k_transform_linear<<<(unsigned)(h->Mcap / kBlock), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->params,
+                                                                                  h->motion, slot, h->zmeta, h->zsmeta);
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, h->have_colmin);
@@ -879,11 +964,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
-                                                      (double)h->M / (double)h->Nglobal, h->D, h->colmin);
-    if (use_cull) {
-        k_group_meta<<<grid1(h->Ncap / prg::kGroup), kBlock, 0, h->stream>>>(h->tgt4, h->Ncap / prg::kGroup, h->tmeta);
-        k_super_meta<<<grid1(h->Ncap / prg::kSuper), kBlock, 0, h->stream>>>(h->tmeta, h->Ncap / prg::kSuper, h->tsmeta);
-    }
+                                                      (double)h->M / (double)h->Nglobal, h->D, h->colmin,
+                                                      use_cull ? h->tmeta : nullptr, h->tsmeta);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);

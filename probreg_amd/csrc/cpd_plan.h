@@ -49,6 +49,7 @@ struct prg_cpd {
     float* colmin = nullptr;    // [Ncap] min_m d^2 per column from the previous E-step (seed of the cull bound)
     unsigned* motion = nullptr; // float bits of max_m |z_new - z_old| of the last transform
     bool have_colmin = false;
+    uint64_t estep_count = 0;   // parity selects the motion slot of the current E-step
 
     // staging for uploads / moments_from_estep
     void* stage = nullptr;

@@ -375,7 +375,7 @@ void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
     dim3 grid((unsigned)ceil_div(h->N, kBlock * 2), (unsigned)S);
     k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
                                                    reinterpret_cast<const GroupMeta*>(h->zsmeta), seg_len, h->params,
-                                                   use_seed ? h->colmin : nullptr, h->motion, h->colpart, h->Ncap);
+                                                   use_seed ? h->colmin : nullptr, h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap);
 }
 
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {

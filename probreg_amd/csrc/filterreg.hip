@@ -618,14 +618,23 @@ __device__ void kabsch_from_moments(const double* mom, int dim, double (&dr)[3][
         if (dim == 3) {
             double U[3][3], V[3][3], sv[3];
             prg::jacobi_svd(H, 3, U, V, sv);
-            int jmin = 0;
-            for (int j = 1; j < 3; ++j)
-                if (sv[j] < sv[jmin]) jmin = j;
             const double dd = prg::det3(U, 3) * prg::det3(V, 3);  // det(U V), kabsch.cc:48
+            double c[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {  // the correction goes on the smallest singular value (static indices only)
+                bool is_min = true;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    if (j != k && (sv[j] < sv[k] || (sv[j] == sv[k] && j < k))) is_min = false;
+                c[k] = is_min ? dd : 1.0;
+            }
+#pragma unroll
             for (int i = 0; i < 3; ++i)
+#pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     double r = 0.0;
-                    for (int k = 0; k < 3; ++k) r += (k == jmin ? dd : 1.0) * V[i][k] * U[j][k];  // V diag U^T
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) r += c[k] * V[i][k] * U[j][k];  // V diag U^T
                     dr[i][j] = r;
                 }
         } else {

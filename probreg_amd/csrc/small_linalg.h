@@ -48,20 +48,24 @@ __device__ inline void jacobi_svd(const double a[3][3], int d, double U[3][3], d
         }
         if (off < 1e-15) break;
     }
+    // Everything below uses compile-time array indices only (fully unrolled loops with predicates): a single
+    // run-time index into g / U / V would move the 3 x 3 arrays to scratch memory (~1 us per access).
     double nmax = 0.0;
-    for (int j = 0; j < d; ++j) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
         double nn = 0;
-        for (int i = 0; i < d; ++i) nn += g[i][j] * g[i][j];
-        sv[j] = sqrt(nn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) nn += g[i][j] * g[i][j];
+        sv[j] = (j < d) ? sqrt(nn) : 0.0;
         nmax = fmax(nmax, sv[j]);
     }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
-    bool ok[3] = {false, false, false};
-    for (int j = 0; j < d; ++j) {
-        ok[j] = sv[j] > 1e-14 * nmax && sv[j] > 0.0;
-        if (ok[j])
-            for (int i = 0; i < d; ++i) U[i][j] = g[i][j] / sv[j];
+    bool ok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        ok[j] = (j < d) && sv[j] > 1e-14 * nmax && sv[j] > 0.0;
+        const double inv = ok[j] ? 1.0 / sv[j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[i][j] = ok[j] ? g[i][j] * inv : ((i == j) ? 1.0 : 0.0);
     }
     // complete U to an orthonormal basis where singular values vanish (rank-deficient `a`)
     if (d == 2) {
@@ -69,35 +73,44 @@ __device__ inline void jacobi_svd(const double a[3][3], int d, double U[3][3], d
         else if (!ok[0] && ok[1]) { U[0][0] = U[1][1]; U[1][0] = -U[0][1]; }
         else if (!ok[0] && !ok[1]) { U[0][0] = U[1][1] = 1.0; U[0][1] = U[1][0] = 0.0; }
     } else if (d == 3) {
-        int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
+        const int nbad = (!ok[0]) + (!ok[1]) + (!ok[2]);
         if (nbad == 1) {
-            int b = !ok[0] ? 0 : (!ok[1] ? 1 : 2);
-            int p = (b + 1) % 3, q = (b + 2) % 3;
-            U[0][b] = U[1][p] * U[2][q] - U[2][p] * U[1][q];
-            U[1][b] = U[2][p] * U[0][q] - U[0][p] * U[2][q];
-            U[2][b] = U[0][p] * U[1][q] - U[1][p] * U[0][q];
-        } else if (nbad >= 2) {
-            int gidx = ok[0] ? 0 : (ok[1] ? 1 : (ok[2] ? 2 : -1));
-            if (gidx < 0) {
-                for (int i = 0; i < 3; ++i)
-                    for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
-            } else {
-                // pick the coordinate axis least aligned with the good column, Gram-Schmidt, cross
-                int ax = 0;
-                double best = fabs(U[0][gidx]);
-                for (int i = 1; i < 3; ++i)
-                    if (fabs(U[i][gidx]) < best) { best = fabs(U[i][gidx]); ax = i; }
-                double v[3] = {0, 0, 0};
-                v[ax] = 1.0;
-                double dp = U[ax][gidx];
-                double nn = 0;
-                for (int i = 0; i < 3; ++i) { v[i] -= dp * U[i][gidx]; nn += v[i] * v[i]; }
-                nn = sqrt(nn);
-                int p = (gidx + 1) % 3, q = (gidx + 2) % 3;
-                for (int i = 0; i < 3; ++i) U[i][p] = v[i] / nn;
-                U[0][q] = U[1][gidx] * U[2][p] - U[2][gidx] * U[1][p];
-                U[1][q] = U[2][gidx] * U[0][p] - U[0][gidx] * U[2][p];
-                U[2][q] = U[0][gidx] * U[1][p] - U[1][gidx] * U[0][p];
+#pragma unroll
+            for (int bcol = 0; bcol < 3; ++bcol) {
+                if (ok[bcol]) continue;
+                constexpr int nxt[3] = {1, 2, 0}, nx2[3] = {2, 0, 1};
+                const int p = nxt[bcol], q = nx2[bcol];  // compile-time after unrolling
+                U[0][bcol] = U[1][p] * U[2][q] - U[2][p] * U[1][q];
+                U[1][bcol] = U[2][p] * U[0][q] - U[0][p] * U[2][q];
+                U[2][bcol] = U[0][p] * U[1][q] - U[1][p] * U[0][q];
+            }
+        } else if (nbad == 3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) U[i][j] = (i == j) ? 1.0 : 0.0;
+        } else if (nbad == 2) {
+#pragma unroll
+            for (int gcol = 0; gcol < 3; ++gcol) {
+                if (!ok[gcol]) continue;
+                constexpr int nxt[3] = {1, 2, 0}, nx2[3] = {2, 0, 1};
+                const int p = nxt[gcol], q = nx2[gcol];
+                // coordinate axis least aligned with the good column, Gram-Schmidt, cross product
+                const double a0 = fabs(U[0][gcol]), a1 = fabs(U[1][gcol]), a2 = fabs(U[2][gcol]);
+                const int ax = (a0 <= a1 && a0 <= a2) ? 0 : ((a1 <= a2) ? 1 : 2);
+                const double dp = (ax == 0) ? U[0][gcol] : ((ax == 1) ? U[1][gcol] : U[2][gcol]);
+                double v[3], nn = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    v[i] = ((i == ax) ? 1.0 : 0.0) - dp * U[i][gcol];
+                    nn += v[i] * v[i];
+                }
+                nn = 1.0 / sqrt(nn);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) U[i][p] = v[i] * nn;
+                U[0][q] = U[1][gcol] * U[2][p] - U[2][gcol] * U[1][p];
+                U[1][q] = U[2][gcol] * U[0][p] - U[0][gcol] * U[2][p];
+                U[2][q] = U[0][gcol] * U[1][p] - U[1][gcol] * U[0][p];
             }
         }
     }
