@@ -3,7 +3,7 @@
 Public modules mirror the reference package (neka-nat/probreg):
 ``cpd`` (registration_cpd, RigidCPD, AffineCPD, NonRigidCPD), ``filterreg``
 (registration_filterreg), ``transformation``, ``math_utils``, ``gauss_transform``,
-``gaussian_filtering``.  All arithmetic of the hot path runs in ``csrc/libprobreg_hip.so``.
+``gaussian_filtering``, ``cost_functions.compute_l2_dist``.  All arithmetic of the hot path runs in ``csrc/libprobreg_hip.so``.
 Sub-modules are imported on first attribute access so that ``import probreg_amd`` itself
 never touches the GPU.
 """
@@ -12,7 +12,7 @@ import importlib
 from .version import __version__
 
 _SUBMODULES = ("cpd", "filterreg", "transformation", "math_utils", "gauss_transform", "gaussian_filtering",
-               "callbacks", "dist", "engine", "synthetic")
+               "cost_functions", "dist", "engine", "synthetic")
 
 
 def __getattr__(name):

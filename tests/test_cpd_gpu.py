@@ -549,3 +549,23 @@ def test_culled_registration_tracks_dense_registration():
         assert abs(ps[0][13] - ps[1][13]) <= 2e-6 * ps[1][13], it
     for plan in plans:
         plan.close()
+
+
+def test_compute_l2_dist_vs_direct_formula():
+    """reference cost_functions.py:33-41 (SVR / GMMReg objective + gradient) against the closed form."""
+    from probreg_amd import cost_functions as cf
+
+    rng = np.random.default_rng(21)
+    mu_s, mu_t = rng.normal(size=(120, 3)), rng.normal(size=(90, 3)) * 1.2
+    phi_s, phi_t = rng.uniform(0.5, 1.5, 120), rng.uniform(0.5, 1.5, 90)
+    sigma = 0.4
+    val, grad = cf.compute_l2_dist(mu_s, phi_s, mu_t, phi_t, sigma)
+    z = (2.0 * np.pi * sigma ** 2) ** 1.5
+    d2 = ((mu_s[:, None, :] - mu_t[None, :, :]) ** 2).sum(-1)
+    k = np.exp(-d2 / (2.0 * sigma ** 2))          # h^2 = 2 sigma^2
+    phi_j_e = k @ (phi_t / z)
+    phi_mu = k @ (phi_t[:, None] * mu_t / z)
+    want_val = -np.dot(phi_s, phi_j_e)
+    want_grad = (phi_s[:, None] * phi_j_e[:, None] * mu_s - phi_s[:, None] * phi_mu) / (2.0 * sigma ** 2)
+    assert abs(val - want_val) < 1e-5 * abs(want_val)
+    assert np.max(np.abs(grad - want_grad)) < 1e-5 * np.max(np.abs(want_grad))
