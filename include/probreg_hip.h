@@ -222,6 +222,14 @@ int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd)
  * Replaces: RigidFilterReg._maximization_step filterreg.py:158-196 + cc/kabsch.cc:6-109. */
 int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host);
 
+/* Point-to-plane objective (filterreg.py:101-105, 183-186): target normals (n x 3 float64, NULL clears) add a
+ * 3-channel filter `nx` to the E-step; prg_fr_mstep_pt2pl solves the 6 x 6 twist system
+ * (cc/point_to_plane.cc:6-32), applies se3_op.twist_mul (se3_op.py:44-56); out_host as prg_fr_mstep with
+ * [13] q = sum w^2 residual^2. */
+int prg_fr_set_target_normals(prg_filterreg* h, const double* normals_hd);
+int prg_fr_get_nx(prg_filterreg* h, float* nx_hd);
+int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double* out_host);
+
 /* Weighted Kabsch on float32 clouds: centroids weighted by w, covariance by w^2; rot_host dim x dim
  * row-major, t_host dim.  Replaces: _kabsch.kabsch / kabsch2d (cc/kabsch_py.cc, cc/kabsch.cc:6-109). */
 int prg_kabsch_weighted(int device, void* hip_stream, const float* model_hd, const float* target_hd,

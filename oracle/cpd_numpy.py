@@ -22,7 +22,7 @@ MstepResult = namedtuple("MstepResult", ["params", "sigma2", "q"])
 # ----------------------------------------------------------------------------------------------
 # one-off quantities
 # ----------------------------------------------------------------------------------------------
-def squared_kernel_sum(x, y, chunk=2048):
+def squared_kernel_sum(x, y, chunk=None):
     """sigma^2 initialiser: math_utils.py:28-29 over cc/math_utils.cc:5-15.
 
     The reference builds the dense M x N matrix of squared distances in float32
@@ -34,6 +34,9 @@ def squared_kernel_sum(x, y, chunk=2048):
     """
     x32 = np.ascontiguousarray(x, dtype=np.float32)
     y32 = np.ascontiguousarray(y, dtype=np.float32)
+    if chunk is None:
+        # one block (= the reference's single float32 .sum(), bit for bit) as long as the temporary stays < 1 GB
+        chunk = max(1, min(x32.shape[0], (1 << 28) // max(1, y32.shape[0] * x32.shape[1])))
     total = 0.0
     for s in range(0, x32.shape[0], chunk):
         d = x32[s:s + chunk, None, :] - y32[None, :, :]

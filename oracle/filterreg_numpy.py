@@ -76,10 +76,47 @@ def kabsch2d_f32(model, target, weight):
     return r, (tc - r @ mc).astype(np.float32)
 
 
+def pt2pl_f32(model, target, normal, weight):
+    """cc/point_to_plane.cc:6-32 (computeTwistForPointToPlane), float32 like the reference's Eigen build.
+
+    Normal equations of sum_k w_k (n_k . (t_k - v_k) - jac_k . tw)^2 with jac_k = [v_k x n_k, n_k]:
+    returns (twist[6], r_sum) with r_sum = sum_k w_k^2 residual_k^2 (note the squared weight there, :26).
+    """
+    v = np.ascontiguousarray(model, dtype=np.float32)
+    t = np.ascontiguousarray(target, dtype=np.float32)
+    n = np.ascontiguousarray(normal, dtype=np.float32)
+    w = np.ascontiguousarray(weight, dtype=np.float32)
+    residual = np.einsum("kd,kd->k", n, t - v, dtype=np.float32)
+    jac = np.concatenate([np.cross(v, n).astype(np.float32), n], axis=1)
+    ata = np.einsum("k,ki,kj->ij", w, jac, jac, dtype=np.float32)
+    atb = np.einsum("k,k,ki->i", w, residual, jac, dtype=np.float32)
+    r_sum = np.sum(w * w * residual * residual, dtype=np.float32)
+    tw = np.linalg.solve(ata.astype(np.float32), atb.astype(np.float32))  # selfadjointView<Upper>().ldlt().solve
+    return tw.astype(np.float32), np.float32(r_sum)
+
+
+def twist_trans(tw):
+    """se3_op.py:21-41 (non-linear branch): Rodrigues rotation of the first three entries, translation = last three."""
+    twd = np.linalg.norm(tw[:3])
+    if twd == 0.0:
+        return np.identity(3), tw[3:]
+    ntw = tw[:3] / twd
+    c, s = np.cos(twd), np.sin(twd)
+    skew = np.array([[0.0, -ntw[2], ntw[1]], [ntw[2], 0.0, -ntw[0]], [-ntw[1], ntw[0], 0.0]])
+    return c * np.identity(3) + (1.0 - c) * np.outer(ntw, ntw) + s * skew, tw[3:]
+
+
+def twist_mul(tw, rot, t):
+    """se3_op.py:44-56."""
+    tr, tt = twist_trans(tw)
+    return np.dot(tr, rot), np.dot(t, tr.T) + tt
+
+
 # ----------------------------------------------------------------------------------------------
 # E-step / M-step
 # ----------------------------------------------------------------------------------------------
-def expectation_step(t_source, target, y, sigma2, update_sigma2, alpha=0.015, prefer_ref=False, info=None):
+def expectation_step(t_source, target, y, sigma2, update_sigma2, alpha=0.015, prefer_ref=False, info=None,
+                     target_normals=None):
     """filterreg.py:78-108: lattice over [t_source; target]/sigma, three filters, first m rows kept."""
     assert t_source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
     m = t_source.shape[0]
@@ -99,15 +136,18 @@ def expectation_step(t_source, target, y, sigma2, update_sigma2, alpha=0.015, pr
     m2 = None
     if update_sigma2:
         m2 = lat.filter(np.r_[zero_m1, np.square(y).sum(axis=1)[:, None]]).flatten()[:m]
-    return EstepResult(m0, m1, m2, None)
+    nx = None
+    if target_normals is not None:  # objective_type == 'pt2pl', filterreg.py:103-105
+        nx = lat.filter(np.r_[np.zeros((m, y.shape[1])), target_normals])[:m]
+    return EstepResult(m0, m1, m2, nx)
 
 
-def maximization_step(t_source, target, es, rot_p, t_p, sigma2, w=0.0):
+def maximization_step(t_source, target, es, rot_p, t_p, sigma2, w=0.0, objective_type="pt2pt"):
     """filterreg.py:158-182 + :190-196 (pt2pt).  Returns MstepResult(rot, t, sigma2, q); q None if all m0 == 0."""
     m, dim = t_source.shape
     n = target.shape[0]
     assert dim == 2 or dim == 3, "dim must be 2 or 3."
-    m0, m1, m2, _ = es
+    m0, m1, m2, nx = es
     c = w / (1.0 - w) * n / m * (2.0 * sigma2 * np.pi) ** (dim / 2.0)
     nz = m0 != 0
     if not nz.any():
@@ -118,13 +158,18 @@ def maximization_step(t_source, target, es, rot_p, t_p, sigma2, w=0.0):
     m1m0 = np.divide(m1.T, m0).T
     m0m0 = m0 / (m0 + c)
     drxdx = np.sqrt(m0m0 * 1.0 / sigma2)
-    if dim == 2:
-        dr, dt = kabsch2d_f32(ts, m1m0, drxdx)
+    if objective_type == "pt2pl":  # filterreg.py:183-186
+        nxm0 = (nx[nz].T / m0).T
+        tw, q = pt2pl_f32(ts, m1m0, nxm0, drxdx)
+        rot, t = twist_mul(tw, rot_p, t_p)
     else:
-        dr, dt = kabsch_f32(ts, m1m0, drxdx)
-    rx = np.multiply(drxdx, (ts - m1m0).T).T
-    rot, t = np.dot(dr, rot_p), np.dot(t_p, dr.T) + dt
-    q = np.linalg.norm(rx, ord=2, axis=1).sum()
+        if dim == 2:
+            dr, dt = kabsch2d_f32(ts, m1m0, drxdx)
+        else:
+            dr, dt = kabsch_f32(ts, m1m0, drxdx)
+        rx = np.multiply(drxdx, (ts - m1m0).T).T
+        rot, t = np.dot(dr, rot_p), np.dot(t_p, dr.T) + dt
+        q = np.linalg.norm(rx, ord=2, axis=1).sum()
     if m2 is not None:
         m2 = m2[nz]
         sigma2 = ((m0 * np.square(ts).sum(axis=1) - 2.0 * (ts * m1).sum(axis=1) + m2) / (m0 + c)).sum()
@@ -140,7 +185,8 @@ def squared_kernel_sum_f32(x, y):
 
 
 def registration(source, target, sigma2=None, update_sigma2=False, w=0.0, maxiter=50, tol=0.001, min_sigma2=1.0e-4,
-                 rot0=None, t0=None, prefer_ref=False, history=None, info=None):
+                 rot0=None, t0=None, prefer_ref=False, history=None, info=None, target_normals=None,
+                 objective_type="pt2pt"):
     """filterreg.py:120-147 with identity feature_fn.  Returns (rot, t, sigma2_returned, q, n_iter)."""
     source = np.asarray(source, dtype=np.float64)
     target = np.asarray(target, dtype=np.float64)
@@ -154,8 +200,9 @@ def registration(source, target, sigma2=None, update_sigma2=False, w=0.0, maxite
     n_iter = 0
     for _ in range(maxiter):
         ts = np.dot(source, rot.T) + t  # RigidTransformation._transform with scale 1 (transformation.py:49-50)
-        es = expectation_step(ts, target, target, sigma2, update_sigma2, prefer_ref=prefer_ref, info=info)
-        res = maximization_step(ts, target, es, rot, t, sigma2, w=w)
+        es = expectation_step(ts, target, target, sigma2, update_sigma2, prefer_ref=prefer_ref, info=info,
+                              target_normals=target_normals if objective_type == "pt2pl" else None)
+        res = maximization_step(ts, target, es, rot, t, sigma2, w=w, objective_type=objective_type)
         if res.q is None:
             res = res._replace(q=q)
             break

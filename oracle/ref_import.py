@@ -147,7 +147,11 @@ def load(with_filterreg=False):
             sys.modules["transforms3d.quaternions"] = t3.quaternions
             sys.modules["transforms3d.euler"] = t3.euler
         sys.modules.setdefault("probreg._kabsch", _kabsch_standin())
-        sys.modules.setdefault("probreg._pt2pl", types.ModuleType("probreg._pt2pl"))
+        pt2pl_mod = types.ModuleType("probreg._pt2pl")
+        from . import filterreg_numpy as _fo
+
+        pt2pl_mod.compute_twist_for_pt2pl = _fo.pt2pl_f32  # float32 restatement of cc/point_to_plane.cc:6-32
+        sys.modules.setdefault("probreg._pt2pl", pt2pl_mod)
         ifgt = types.ModuleType("probreg._ifgt")
         ifgt.Ifgt = None
         sys.modules.setdefault("probreg._ifgt", ifgt)

@@ -484,9 +484,11 @@ struct prg_filterreg {
     int D = 0;
     double* src = nullptr;   // [M][D] fp64 source
     double* tgt = nullptr;   // [N][D] fp64 target
+    double* nrm = nullptr;   // [N][3] fp64 target normals (point-to-plane objective), optional
+    int ch = 5;              // value channels: 1 | y(3) | |y|^2  (+ normal(3) when normals are set)
     double* ts = nullptr;    // [M][3] fp64 transformed source
-    float* vin = nullptr;    // [M+N][5] values (source rows zero)
-    float* vout = nullptr;   // [M][5] filtered m0, m1(3), m2
+    float* vin = nullptr;    // [M+N][ch] values (source rows zero)
+    float* vout = nullptr;   // [M][ch] filtered m0, m1(3), m2 (, nx(3))
     double* state = nullptr; // [64]: 0..8 rot, 9..11 t, 12 sigma2, 13 q, 14 nonzero count, 15 sigma2_new
     double* part = nullptr;  // block partials
     int64_t part_blocks = 0;
@@ -495,7 +497,7 @@ struct prg_filterreg {
 
 namespace {
 
-constexpr int kFrComp = 28;  // 0 sw,1-3 sw*m,4-6 sw*t,7 sw2,8-10 sw2*m,11-13 sw2*t,14-22 sw2*m*t^T,23 q,24 s2num,25 m0m0,26 cnt
+constexpr int kFrComp = 32;  // 0 sw,1-3 sw*m,4-6 sw*t,7 sw2,8-10 sw2*m,11-13 sw2*t,14-22 sw2*m*t^T,23 q,24 s2num,25 m0m0,26 cnt
 
 __global__ __launch_bounds__(kBlock) void k_fr_transform(const double* __restrict__ src, int64_t m, int dim,
                                                          const double* __restrict__ state, double* __restrict__ ts,
@@ -523,12 +525,13 @@ __global__ __launch_bounds__(kBlock) void k_fr_target_features(const double* __r
     for (int k = 0; k < dim; ++k) feat[i * dim + k] = (float)(tgt[i * dim + k] / sigma);  // fy = target / sigma, :85
 }
 
-// values [M+N][5]: source rows 0; target rows (1, y, |y|^2)   (filterreg.py:92-99)
-__global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__ tgt, int64_t m, int64_t n, int dim,
+// values [M+N][ch]: source rows 0; target rows (1, y, |y|^2 [, normal])   (filterreg.py:92-105)
+__global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__ tgt, const double* __restrict__ nrm,
+                                                      int64_t m, int64_t n, int dim, int ch,
                                                       float* __restrict__ vin) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m + n) return;
-    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i >= m) {
         const double* y = tgt + (i - m) * dim;
         double s = 0.0;
@@ -538,14 +541,16 @@ __global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__
             s += y[k] * y[k];
         }
         v[4] = (float)s;
+        if (ch == 8)
+            for (int k = 0; k < 3; ++k) v[5 + k] = (float)nrm[(i - m) * 3 + k];
     }
-    for (int k = 0; k < 5; ++k) vin[i * 5 + k] = v[k];
+    for (int k = 0; k < ch; ++k) vin[i * ch + k] = v[k];
 }
 
 // per-point M-step terms (filterreg.py:163-182, 190-195) -> block partials [nblk][kFrComp]
-__global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout, const double* __restrict__ ts,
-                                                     int64_t m, int dim, double c, const double* __restrict__ state,
-                                                     double* __restrict__ part) {
+__global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout, int ch,
+                                                     const double* __restrict__ ts, int64_t m, int dim, double c,
+                                                     const double* __restrict__ state, double* __restrict__ part) {
     __shared__ double sh[4][kFrComp];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     double a[kFrComp];
@@ -553,11 +558,11 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
     for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
     const double sigma2 = state[12];
     if (i < m) {
-        const float m0 = vout[i * 5];
+        const float m0 = vout[i * ch];
         if (m0 != 0.f) {
             const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
-            const float m1[3] = {vout[i * 5 + 1], vout[i * 5 + 2], vout[i * 5 + 3]};
-            const float m2 = vout[i * 5 + 4];
+            const float m1[3] = {vout[i * ch + 1], vout[i * ch + 2], vout[i * ch + 3]};
+            const float m2 = vout[i * ch + 4];
             float tg[3];  // m1m0 = m1 / m0 in float32 (:172)
             for (int k = 0; k < 3; ++k) tg[k] = k < dim ? __fdiv_rn(m1[k], m0) : 0.f;
             const double m0m0 = (double)m0 / ((double)m0 + c);       // :173
@@ -598,6 +603,173 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
     if (threadIdx.x < kFrComp)
         part[(int64_t)blockIdx.x * kFrComp + threadIdx.x] =
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// point-to-plane M-step terms (filterreg.py:183-186 -> cc/point_to_plane.cc:6-32): per point with m0 != 0
+//   v = t_source (float32), t = m1/m0, n = nx/m0, w = sqrt(m0m0/sigma2) (float32),
+//   residual = n.(t - v), jac = [v x n, n]:  ata += w jac jac^T (21 upper entries), atb += w residual jac,
+//   r_sum += w^2 residual^2.  comps: [0..20] ata, [21..26] atb, [27] r_sum, [28] sigma2 numerator, [29] m0m0, [30] count
+__global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restrict__ vout, const double* __restrict__ ts,
+                                                           int64_t m, double c, const double* __restrict__ state,
+                                                           double* __restrict__ part) {
+    __shared__ double sh[4][kFrComp];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double a[kFrComp];
+#pragma unroll
+    for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
+    const double sigma2 = state[12];
+    if (i < m) {
+        const float m0 = vout[i * 8];
+        if (m0 != 0.f) {
+            const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
+            double v[3], t[3], n[3];
+            double zz = 0.0, zm1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float m1 = vout[i * 8 + 1 + k];
+                v[k] = (double)(float)z[k];
+                t[k] = (double)__fdiv_rn(m1, m0);
+                n[k] = (double)__fdiv_rn(vout[i * 8 + 5 + k], m0);
+                zz += z[k] * z[k];
+                zm1 += z[k] * (double)m1;
+            }
+            const double m0m0 = (double)m0 / ((double)m0 + c);
+            const double w = (double)(float)sqrt(m0m0 / sigma2);
+            const double residual = n[0] * (t[0] - v[0]) + n[1] * (t[1] - v[1]) + n[2] * (t[2] - v[2]);
+            const double jac[6] = {v[1] * n[2] - v[2] * n[1], v[2] * n[0] - v[0] * n[2], v[0] * n[1] - v[1] * n[0],
+                                   n[0], n[1], n[2]};
+            int idx = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r)
+#pragma unroll
+                for (int q = r; q < 6; ++q) a[idx++] = w * jac[r] * jac[q];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) a[21 + r] = w * residual * jac[r];
+            a[27] = w * w * residual * residual;
+            a[28] = ((double)m0 * zz - 2.0 * zm1 + (double)vout[i * 8 + 4]) / ((double)m0 + c);
+            a[29] = m0m0;
+            a[30] = 1.0;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kFrComp; ++k) {
+        const double s = wave_sum(a[k]);
+        if (lane == 0) sh[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kFrComp)
+        part[(int64_t)blockIdx.x * kFrComp + threadIdx.x] =
+            sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+// 6 x 6 SPD solve (the reference uses Eigen's LDLT on the upper triangle), twist -> Rodrigues rotation
+// (se3_op.py:21-56), composition with the previous transform, optional sigma2 update.  One workgroup.
+__global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __restrict__ part, int nblk,
+                                                            int update_sigma2, double* __restrict__ state) {
+    __shared__ double sh[8][32];
+    __shared__ double mom[32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double s = 0.0;
+    for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * kFrComp + c];
+    sh[slice][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x];
+        mom[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    state[14] = mom[30];
+    if (mom[30] == 0.0) {
+        state[13] = nan("");
+        state[16] = 0.0;
+        return;
+    }
+    state[16] = 1.0;
+    // Cholesky solve of ata tw = atb (static indices)
+    double A[6][6], bvec[6], tw[6];
+    {
+        int idx = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int q = r; q < 6; ++q) { A[r][q] = mom[idx]; A[q][r] = mom[idx]; ++idx; }
+#pragma unroll
+        for (int r = 0; r < 6; ++r) bvec[r] = mom[21 + r];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d -= (k < j) ? A[j][k] * A[j][k] : 0.0;
+        d = sqrt(fmax(d, 1e-300));
+        A[j][j] = d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i <= j) continue;
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t -= (k < j) ? A[i][k] * A[j][k] : 0.0;
+            A[i][j] = t / d;
+        }
+    }
+    double yv[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double t = bvec[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t -= (k < i) ? A[i][k] * yv[k] : 0.0;
+        yv[i] = t / A[i][i];
+    }
+#pragma unroll
+    for (int ii = 0; ii < 6; ++ii) {
+        const int i = 5 - ii;
+        double t = yv[i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t -= (k > i) ? A[k][i] * tw[k] : 0.0;
+        tw[i] = t / A[i][i];
+    }
+    // twist -> (rotation, translation), se3_op.py:21-41
+    double tr[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    const double twd = sqrt(tw[0] * tw[0] + tw[1] * tw[1] + tw[2] * tw[2]);
+    if (twd != 0.0) {
+        const double n0 = tw[0] / twd, n1 = tw[1] / twd, n2 = tw[2] / twd;
+        const double cc = cos(twd), ss = sin(twd), oc = 1.0 - cc;
+        tr[0][0] = cc + oc * n0 * n0;      tr[0][1] = oc * n0 * n1 - ss * n2; tr[0][2] = oc * n0 * n2 + ss * n1;
+        tr[1][0] = oc * n1 * n0 + ss * n2; tr[1][1] = cc + oc * n1 * n1;      tr[1][2] = oc * n1 * n2 - ss * n0;
+        tr[2][0] = oc * n2 * n0 - ss * n1; tr[2][1] = oc * n2 * n1 + ss * n0; tr[2][2] = cc + oc * n2 * n2;
+    }
+    // rot = tr @ rot_p ; t = t_p @ tr^T + tw[3:]   (se3_op.py:44-56)
+    double rp[3][3], tp[3], rn[3][3], tn[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        tp[i] = state[9 + i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rp[i][j] = state[3 * i + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double tt = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double r = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) r += tr[i][k] * rp[k][j];
+            rn[i][j] = r;
+            tt += tr[i][j] * tp[j];
+        }
+        tn[i] = tt + tw[3 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        state[9 + i] = tn[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) state[3 * i + j] = rn[i][j];
+    }
+    state[13] = mom[27];  // q = r_sum
+    state[15] = update_sigma2 ? mom[28] / (3.0 * mom[29]) : state[12];
 }
 
 // weighted Kabsch from moments (cc/kabsch.cc:6-109): mom[0] sw, [1..3] sw*model, [4..6] sw*target, [7] sw2,
@@ -861,7 +1033,7 @@ int prg_fr_destroy(prg_filterreg* h) {
     (void)hipStreamSynchronize(h->L.stream);
     lat_free(&h->L);
     for (void* p : {(void*)h->src, (void*)h->tgt, (void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->state,
-                    (void*)h->part})
+                    (void*)h->part, (void*)h->nrm})
         if (p) (void)hipFree(p);
     delete h;
     return PRG_OK;
@@ -874,12 +1046,13 @@ static int fr_alloc(prg_filterreg* h) {
         if (p) (void)hipFree(p);
     h->ts = nullptr; h->vin = nullptr; h->vout = nullptr; h->part = nullptr; h->L.feat = nullptr;
     PRG_HIP(hipMalloc((void**)&h->ts, (size_t)h->M * 3 * sizeof(double)));
-    PRG_HIP(hipMalloc((void**)&h->vin, (size_t)tot * 5 * sizeof(float)));
-    PRG_HIP(hipMalloc((void**)&h->vout, (size_t)h->M * 5 * sizeof(float)));
+    PRG_HIP(hipMalloc((void**)&h->vin, (size_t)tot * 8 * sizeof(float)));
+    PRG_HIP(hipMalloc((void**)&h->vout, (size_t)h->M * 8 * sizeof(float)));
     h->part_blocks = prg::ceil_div(h->M, kBlock);
     PRG_HIP(hipMalloc((void**)&h->part, (size_t)h->part_blocks * kFrComp * sizeof(double)));
     PRG_HIP(hipMalloc((void**)&h->L.feat, (size_t)tot * h->D * sizeof(float)));
-    k_fr_values<<<(unsigned)prg::ceil_div(tot, kBlock), kBlock, 0, h->L.stream>>>(h->tgt, h->M, h->N, h->D, h->vin);
+    k_fr_values<<<(unsigned)prg::ceil_div(tot, kBlock), kBlock, 0, h->L.stream>>>(h->tgt, h->nrm, h->M, h->N, h->D,
+                                                                                  h->ch, h->vin);
     PRG_HIP(hipGetLastError());
     return PRG_OK;
 }
@@ -917,6 +1090,9 @@ int prg_fr_set_target(prg_filterreg* h, const double* target_hd, int64_t n, int 
     h->D = dim;
     h->have_tgt = true;
     h->have_estep = false;
+    if (h->nrm) (void)hipFree(h->nrm);  // normals belong to the previous target
+    h->nrm = nullptr;
+    h->ch = 5;
     return fr_alloc(h);
 }
 
@@ -951,7 +1127,7 @@ int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_bl
     }
     // one fused 5-channel pass: channels 0 (m0) and 4 (m2) are single-channel filters in the reference
     // (seqCompute arithmetic), channels 1..3 (m1) its 3-channel filter (sseCompute arithmetic)
-    PRG_TRY(lat_filter(&h->L, h->vin, 5, h->M, h->M, 0x11u, h->vout));
+    PRG_TRY(lat_filter(&h->L, h->vin, h->ch, h->M, h->M, 0x11u, h->vout));  // normals (ch 5..7): 3-channel filter
     if (lattice_size) *lattice_size = h->L.size;
     if (with_blur) *with_blur = blur;
     h->have_estep = true;
@@ -962,7 +1138,7 @@ int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd)
     PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_fr_get_estep: no E-step has been run");
     prg::DeviceGuard g(h->L.device);
     hipStream_t st = h->L.stream;
-    const size_t pitch = 5 * sizeof(float);
+    const size_t pitch = (size_t)h->ch * sizeof(float);
     if (m0_hd) PRG_HIP(hipMemcpy2DAsync(m0_hd, sizeof(float), h->vout, pitch, sizeof(float), h->M, hipMemcpyDefault, st));
     if (m1_hd)
         PRG_HIP(hipMemcpy2DAsync(m1_hd, h->D * sizeof(float), h->vout + 1, pitch, h->D * sizeof(float), h->M,
@@ -983,8 +1159,55 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host
     // c = w/(1-w) * n/m * (2 sigma2 pi)^(dim/2)   (filterreg.py:164)
     const double c = w / (1.0 - w) * (double)h->N / (double)h->M * pow(2.0 * sigma2 * M_PI, h->D / 2.0);
     const int nblk = (int)h->part_blocks;
-    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, h->D, c, h->state, h->part);
+    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, c, h->state, h->part);
     k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, h->state);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_host, h->state, 17 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+int prg_fr_set_target_normals(prg_filterreg* h, const double* normals_hd) {
+    PRG_REQUIRE(h && h->have_tgt, PRG_ERR_STATE, "prg_fr_set_target_normals: target not set");
+    PRG_REQUIRE(h->D == 3 || !normals_hd, PRG_ERR_INVALID, "prg_fr_set_target_normals: point-to-plane needs 3-D clouds");
+    prg::DeviceGuard g(h->L.device);
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    if (h->nrm) (void)hipFree(h->nrm);
+    h->nrm = nullptr;
+    h->ch = 5;
+    if (normals_hd) {
+        PRG_HIP(hipMalloc((void**)&h->nrm, (size_t)h->N * 3 * sizeof(double)));
+        PRG_HIP(hipMemcpyAsync(h->nrm, normals_hd, (size_t)h->N * 3 * sizeof(double), hipMemcpyDefault, h->L.stream));
+        PRG_HIP(hipStreamSynchronize(h->L.stream));
+        h->ch = 8;
+    }
+    h->have_estep = false;
+    return fr_alloc(h);
+}
+
+int prg_fr_get_nx(prg_filterreg* h, float* nx_hd) {
+    PRG_REQUIRE(h && h->have_estep && h->ch == 8 && nx_hd, PRG_ERR_STATE,
+                "prg_fr_get_nx: needs target normals and an E-step");
+    prg::DeviceGuard g(h->L.device);
+    PRG_HIP(hipMemcpy2DAsync(nx_hd, 3 * sizeof(float), h->vout + 5, 8 * sizeof(float), 3 * sizeof(float), h->M,
+                             hipMemcpyDefault, h->L.stream));
+    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    return PRG_OK;
+}
+
+int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double* out_host) {
+    PRG_REQUIRE(h && h->have_estep && out_host, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: run prg_fr_estep first");
+    PRG_REQUIRE(h->ch == 8, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: target normals have not been set");
+    PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep_pt2pl: w must be in [0, 1) (got %g)", w);
+    prg::DeviceGuard g(h->L.device);
+    hipStream_t st = h->L.stream;
+    double sigma2 = 0.0;
+    PRG_HIP(hipMemcpyAsync(&sigma2, h->state + 12, sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    const double c = w / (1.0 - w) * (double)h->N / (double)h->M * pow(2.0 * sigma2 * M_PI, h->D / 2.0);
+    const int nblk = (int)h->part_blocks;
+    k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, c, h->state, h->part);
+    k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>(h->part, nblk, update_sigma2, h->state);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipMemcpyAsync(out_host, h->state, 17 * sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));

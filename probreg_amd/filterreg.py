@@ -6,8 +6,8 @@ The E-step (lattice build over [t_source; target]/sigma, the three Gaussian filt
 ``FilterReg.registration`` (filterreg.py:120-147) line by line, including its quirks: with the defaults
 sigma2 is never updated, the returned ``sigma2`` is the un-clamped one, and the driver stops with the
 previous ``q`` when every ``m0`` is zero.
-Out of scope here: ``objective_type='pt2pl'``, ``feature_fn`` other than identity,
-``DeformableKinematicFilterReg``.
+Point-to-plane (``objective_type='pt2pl'``, filterreg.py:183-186 + cc/point_to_plane.cc) is built as well.
+Out of scope here: ``feature_fn`` other than identity, ``DeformableKinematicFilterReg``.
 """
 import abc
 import ctypes
@@ -85,9 +85,24 @@ class _Plan(object):
         check(lib.prg_fr_get_estep(self._h, ptr(m0), ptr(m1), ptr(m2) if want_m2 else None))
         return m0, m1, m2
 
-    def mstep(self, w, update_sigma2):
+    def set_normals(self, normals):
+        if normals is None:
+            check(lib.prg_fr_set_target_normals(self._h, None))
+        else:
+            a = np.ascontiguousarray(normals, dtype=np.float64)
+            if a.shape != (self.n, 3):
+                raise ValueError("target_normals must be an (n, 3) array matching the target.")
+            check(lib.prg_fr_set_target_normals(self._h, ptr(a)))
+
+    def get_nx(self):
+        nx = np.empty((self.m, 3), dtype=np.float32)
+        check(lib.prg_fr_get_nx(self._h, ptr(nx)))
+        return nx
+
+    def mstep(self, w, update_sigma2, objective_type="pt2pt"):
         out = np.zeros(17)
-        check(lib.prg_fr_mstep(self._h, float(w), 1 if update_sigma2 else 0, ptr(out)))
+        fn = lib.prg_fr_mstep_pt2pl if objective_type == "pt2pl" else lib.prg_fr_mstep
+        check(fn(self._h, float(w), 1 if update_sigma2 else 0, ptr(out)))
         return out
 
     def close(self):
@@ -142,9 +157,7 @@ class FilterReg(abc.ABC):
     def expectation_step(self, t_source, target, y, sigma2, update_sigma2, objective_type="pt2pt", alpha=0.015):
         """Expectation step (reference filterreg.py:78-108) on explicit arrays; returns float32 m0, m1, m2."""
         assert t_source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
-        if objective_type != "pt2pt":
-            if objective_type == "pt2pl":
-                raise NotImplementedError("objective_type 'pt2pl' is a next-row (SURVEY.md 8f), not built yet.")
+        if objective_type not in ("pt2pt", "pt2pl"):
             raise ValueError("Unknown objective_type: %s." % objective_type)
         if y is not target and not np.array_equal(np.asarray(y), np.asarray(target)):
             raise NotImplementedError("feature-space lattices (y != target) are a next-row (SURVEY.md 8f).")
@@ -152,21 +165,24 @@ class FilterReg(abc.ABC):
         try:
             plan.set_source(t_source)
             plan.set_target(target)
+            if objective_type == "pt2pl":
+                plan.set_normals(self._target_normals)
             plan.set_state(np.identity(t_source.shape[1]), np.zeros(t_source.shape[1]), sigma2)
             plan.estep(alpha)
             m0, m1, m2 = plan.get_estep(update_sigma2)
+            nx = plan.get_nx() if objective_type == "pt2pl" else None
         finally:
             plan.close()
-        return EstepResult(m0, m1, m2, None)
+        return EstepResult(m0, m1, m2, nx)
 
     def registration(self, target, w=0.0, objective_type="pt2pt", maxiter=50, tol=0.001, min_sigma2=1.0e-4,
                      feature_fn=_identity):
         """EM driver (reference filterreg.py:120-147)."""
         assert self._tf_type is not None, "transformation type is None."
-        if objective_type != "pt2pt":
-            if objective_type == "pt2pl":
-                raise NotImplementedError("objective_type 'pt2pl' is a next-row (SURVEY.md 8f), not built yet.")
+        if objective_type not in ("pt2pt", "pt2pl"):
             raise ValueError("Unknown objective_type: %s." % objective_type)
+        if objective_type == "pt2pl" and self._target_normals is None:
+            raise ValueError("objective_type 'pt2pl' needs target_normals.")
         if feature_fn is not _identity:
             probe = np.asarray(feature_fn(self._source[:2]))
             if probe.shape != self._source[:2].shape or not np.array_equal(probe, self._source[:2]):
@@ -178,12 +194,13 @@ class FilterReg(abc.ABC):
         if self._sigma2 is None:
             self._sigma2 = max(mu.squared_kernel_sum(self._source, target), min_sigma2)
         plan = self._ensure_plan(target)
+        plan.set_normals(self._target_normals if objective_type == "pt2pl" else None)
         dim = target.shape[1]
         res = MstepResult(self._tf_result, self._sigma2, None)
         for i in range(maxiter):
             plan.set_state(self._tf_result.rot, self._tf_result.t, self._sigma2)
             plan.estep()
-            out = plan.mstep(w, self._update_sigma2)
+            out = plan.mstep(w, self._update_sigma2, objective_type)
             if out[16] == 0.0:  # every m0 == 0 (filterreg.py:167-168, :136-138)
                 res = MstepResult(self._tf_result, self._sigma2, q)
                 break
@@ -224,11 +241,11 @@ def registration_filterreg(source, target, target_normals=None, sigma2=None, upd
     Args:
         source (numpy.ndarray): Source point cloud data.
         target (numpy.ndarray): Target point cloud data.
-        target_normals (numpy.ndarray, optional): Normal vectors of target point cloud (pt2pl: not built).
+        target_normals (numpy.ndarray, optional): Normal vectors of target point cloud (needed for pt2pl).
         sigma2 (float, optional): Variance of GMM. If `sigma2` is `None`, it is initialised automatically.
         update_sigma2 (bool, optional): update sigma2 every iteration.
         w (float, optional): Weight of the uniform distribution, 0 < `w` < 1.
-        objective_type (str, optional): only 'pt2pt' is built.
+        objective_type (str, optional): The type of objective function selected by 'pt2pt' or 'pt2pl'.
         maxitr (int, optional): Maximum number of iterations to EM algorithm.
         tol (float, optional): Tolerance for termination.
         min_sigma2 (float, optional): Minimum variance of GMM.

@@ -18,6 +18,23 @@ def surface(n, seed):
     return np.stack([x, y, z], axis=1)
 
 
+def surface_with_normals(n, seed):
+    """Same surface as :func:`surface` plus its unit normals (cross product of the analytic tangents)."""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(0.0, 2.0 * np.pi, n)
+    v = rng.uniform(-1.0, 1.0, n)
+    a, b = 1.0 + 0.3 * np.cos(3.0 * u), 1.0 - 0.3 * v * v
+    pts = np.stack([a * np.cos(u) * b, 0.6 * (1.0 + 0.2 * np.sin(2.0 * u)) * np.sin(u), 0.4 * v + 0.15 * np.sin(2.0 * u + v)],
+                   axis=1)
+    du = np.stack([(-0.9 * np.sin(3.0 * u) * np.cos(u) - a * np.sin(u)) * b,
+                   0.6 * (0.4 * np.cos(2.0 * u) * np.sin(u) + (1.0 + 0.2 * np.sin(2.0 * u)) * np.cos(u)),
+                   0.3 * np.cos(2.0 * u + v)], axis=1)
+    dv = np.stack([a * np.cos(u) * (-0.6 * v), np.zeros(n), 0.4 + 0.15 * np.cos(2.0 * u + v)], axis=1)
+    nrm = np.cross(du, dv)
+    nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    return pts, nrm
+
+
 def rot_zx(deg_z, deg_x):
     a, b = np.deg2rad(deg_z), np.deg2rad(deg_x)
     rz = np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
@@ -60,6 +77,20 @@ def nonrigid_pair(n, m=None, noise=0.003, seed=0):
     rng = np.random.default_rng(seed + 2)
     tgt = tgt + disp + rng.normal(0.0, noise, tgt.shape)
     return src.astype(np.float32).astype(np.float64), tgt.astype(np.float32).astype(np.float64)
+
+
+def pt2pl_pair(n, m=None, noise=0.003, seed=0):
+    """Point-to-plane FilterReg case: rigidly moved surface sample with its (moved) analytic normals."""
+    m = n if m is None else m
+    src = surface(m, seed)
+    tgt, nrm = surface_with_normals(n, seed + 1)
+    r = rot_zx(12.0, -6.0)
+    t = np.array([0.04, 0.03, -0.02])
+    rng = np.random.default_rng(seed + 2)
+    tgt = tgt @ r.T + t + rng.normal(0.0, noise, tgt.shape)
+    nrm = nrm @ r.T
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    return f(src), f(tgt), f(nrm), (r, t)
 
 
 def filterreg_pair(n, m=None, outlier_frac=0.05, noise=0.005, seed=0):

@@ -181,6 +181,21 @@ def main_filterreg():
     add("fish2d_k10", fish_s, fish_t, update_sigma2=True, maxiter=10, tol=-1.0,
         tf_init_params={"rot": np.identity(2), "t": np.zeros(2)})
 
+    # point-to-plane objective (filterreg.py:183-186): analytic normals of the synthetic surface
+    s, t, nrm, _ = synthetic.pt2pl_pair(4000, m=3000, seed=6)
+    for name, kw in (("pt2pl_synth_k6", dict(update_sigma2=True, maxiter=6, tol=-1.0)),
+                     ("pt2pl_synth_w005_fixed_k4", dict(sigma2=2.0e-3, w=0.05, maxiter=4, tol=-1.0))):
+        niter = [0]
+        res = ref.filterreg.registration_filterreg(s.copy(), t.copy(), target_normals=nrm.copy(), objective_type="pt2pl",
+                                                   callbacks=[lambda tr: niter.__setitem__(0, niter[0] + 1)], **kw)
+        pre = "pt2pl/%s/" % name
+        flat[pre + "source"], flat[pre + "target"], flat[pre + "normals"] = s, t, nrm
+        flat[pre + "out_rot"], flat[pre + "out_t"] = np.asarray(res.transformation.rot), np.asarray(res.transformation.t)
+        flat[pre + "out_sigma2"], flat[pre + "out_q"] = np.asarray(float(res.sigma2)), np.asarray(float(res.q))
+        for k, v in kw.items():
+            flat[pre + "arg_" + k] = np.asarray(v)
+        print("filterreg %-30s niter=%3d sigma2=%.9e q=%.9e" % (name, niter[0], res.sigma2, res.q))
+
     # lattice unit vectors straight from the vendored permutohedral.cpp (init + compute)
     rng = np.random.default_rng(11)
     for d in (1, 2, 3):

@@ -89,3 +89,18 @@ def test_kabsch_restatement_properties():
     assert np.allclose(r2, r[:2, :2], atol=2e-6)
     r0, t0 = fo.kabsch_f32(a, b, np.zeros(400))
     assert np.array_equal(r0, np.identity(3)) and np.array_equal(t0, np.zeros(3))
+
+
+def test_pt2pl_registration_matches_reference(fr_golden):
+    """Point-to-plane objective: filterreg.py:183-186 over the restated cc/point_to_plane.cc + se3_op.twist_mul."""
+    for name in fr_golden.group("pt2pl"):
+        c = fr_golden.case("pt2pl/" + name)
+        kw = {k[4:]: c[k] for k in c if k.startswith("arg_")}
+        if "maxiter" in kw:
+            kw["maxiter"] = int(kw["maxiter"])
+        if "update_sigma2" in kw:
+            kw["update_sigma2"] = bool(kw["update_sigma2"])
+        rot, t, s2, q, _ = fo.registration(c["source"], c["target"], target_normals=c["normals"], objective_type="pt2pl", **kw)
+        assert np.max(np.abs(rot - c["out_rot"])) < 1e-6 and np.max(np.abs(t - c["out_t"])) < 1e-6, name
+        assert abs(s2 - c["out_sigma2"]) <= 1e-6 * abs(c["out_sigma2"]), name
+        assert abs(q - c["out_q"]) <= 1e-6 * abs(c["out_q"]), name
