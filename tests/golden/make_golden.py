@@ -183,7 +183,9 @@ def main_filterreg():
 
     # point-to-plane objective (filterreg.py:183-186): analytic normals of the synthetic surface
     s, t, nrm, _ = synthetic.pt2pl_pair(4000, m=3000, seed=6)
-    for name, kw in (("pt2pl_synth_k6", dict(update_sigma2=True, maxiter=6, tol=-1.0)),
+    # (with sigma2 left to the automatic initialiser the reference's pt2pl iteration diverges on this data - its
+    # own pt2pl test is skipped as well - so the fixtures start from a sensible sigma2)
+    for name, kw in (("pt2pl_synth_update_k8", dict(sigma2=1.0e-2, update_sigma2=True, maxiter=8, tol=-1.0)),
                      ("pt2pl_synth_w005_fixed_k4", dict(sigma2=2.0e-3, w=0.05, maxiter=4, tol=-1.0))):
         niter = [0]
         res = ref.filterreg.registration_filterreg(s.copy(), t.copy(), target_normals=nrm.copy(), objective_type="pt2pl",
