@@ -133,7 +133,7 @@ class CoherentPointDrift(abc.ABC):
         if not getattr(self, "_source_uploaded", False):
             plan.set_source(source - cy)
         plan.set_target(target[lo:hi] - cx, n_global=target.shape[0])
-        mom = plan.moments_tensor() if world > 1 else None
+        mom = plan.moments_tensor() if pdist.initialized() else None
         plan.init_sums()
         if mom is not None:
             pdist.all_reduce_sum_(mom)
@@ -344,8 +344,7 @@ class NonRigidCPD(CoherentPointDrift):
 
     def _all_reduce_moments(self, plan):
         super(NonRigidCPD, self)._all_reduce_moments(plan)
-        rank, world = pdist.world()
-        if world > 1:
+        if pdist.initialized():
             self._all_reduce_rowacc(plan)
 
     def _all_reduce_rowacc(self, plan):

@@ -20,6 +20,16 @@ def world():
     return 0, 1
 
 
+def initialized():
+    """True when torch.distributed has a process group (even a single-rank one)."""
+    try:
+        import torch.distributed as dist
+
+        return bool(dist.is_available() and dist.is_initialized())
+    except ImportError:  # pragma: no cover
+        return False
+
+
 def shard_bounds(n, rank, world_size):
     """Contiguous near-equal split of ``n`` rows: rows [lo, hi) belong to ``rank``."""
     if not (0 <= rank < world_size):
@@ -34,7 +44,7 @@ def all_reduce_sum_(tensor):
     """In-place SUM all-reduce of a torch tensor (device tensor -> RCCL over xGMI, CPU tensor -> gloo)."""
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():  # also with one rank: keeps the collective path exercised
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
 

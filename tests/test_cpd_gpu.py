@@ -569,3 +569,30 @@ def test_compute_l2_dist_vs_direct_formula():
     want_grad = (phi_s[:, None] * phi_j_e[:, None] * mu_s - phi_s[:, None] * phi_mu) / (2.0 * sigma ** 2)
     assert abs(val - want_val) < 1e-5 * abs(want_val)
     assert np.max(np.abs(grad - want_grad)) < 1e-5 * np.max(np.abs(want_grad))
+
+
+def test_single_rank_process_group_exercises_the_collective_path():
+    """One-rank NCCL (RCCL) process group on this GPU: target 'sharding' over 1 rank, the moment block bound to a
+    torch tensor and all-reduced every iteration on the plan's stream - the multi-GPU code path minus the peers."""
+    import os
+    import torch
+    import torch.distributed as tdist
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    if tdist.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    tdist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        src, tgt, _ = synthetic.rigid_pair(3000, m=2500, seed=71)
+        res = cpd.registration_cpd(src, tgt, "rigid", w=0.1, maxiter=6, tol=-1.0)
+        p, s2, q, _ = co.registration("rigid", src, tgt, w=0.1, maxiter=6, tol=-1.0, closed_form_init=True)
+        _check_rigid(res, p["rot"], p["t"], p["scale"], s2)
+        src, tgt = synthetic.nonrigid_pair(900, m=800, seed=72)
+        res = cpd.registration_cpd(src, tgt, "nonrigid", maxiter=3, tol=-1.0)
+        p, s2, q, _ = co.registration("nonrigid", src, tgt, maxiter=3, tol=-1.0, closed_form_init=True)
+        assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
+    finally:
+        tdist.destroy_process_group()
