@@ -122,12 +122,12 @@ def bench_filterreg(args, n, desc):
     state = {"rot": np.identity(3), "t": np.zeros(3), "sigma2": max(mu.squared_kernel_sum(src, tgt), 1e-4)}
     sizes = []
 
+    plan.set_state(state["rot"], state["t"], state["sigma2"])  # once: the M-step kernel advances the device state
+
     def step():
-        plan.set_state(state["rot"], state["t"], state["sigma2"])
         size, _blur = plan.estep()
-        out = plan.mstep(0.05, True)
-        state["rot"], state["t"] = out[:9].reshape(3, 3).copy(), out[9:12].copy()
-        state["sigma2"] = max(out[15], 1e-4)
+        out = plan.mstep(0.05, True, "pt2pt", 1e-4)
+        state["rot"], state["t"], state["sigma2"] = out[:9].reshape(3, 3).copy(), out[9:12].copy(), out[12]
         sizes.append(size)
 
     for _ in range(args.warmup):

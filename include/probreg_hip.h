@@ -216,11 +216,13 @@ int prg_fr_set_state(prg_filterreg* h, const double* rot9, const double* t3, dou
 int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_blur);
 /* m0 [m], m1 [m x dim], m2 [m] of the last E-step (float32; any pointer may be NULL). */
 int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd);
-/* M-step (weighted Kabsch + composition + optional sigma2 update).  out_host[17]: [0..8] rot, [9..11] t,
- * [12] sigma2 used, [13] q, [14] number of points with m0 != 0, [15] new sigma2, [16] 1 if a transform
- * was estimated (0 = every m0 was zero: the reference returns q = None, filterreg.py:167-168).
+/* M-step (weighted Kabsch + composition + optional sigma2 update).  out_host[18]: [0..8] rot, [9..11] t,
+ * [12] sigma2 of the NEXT iteration, [13] q, [14] number of points with m0 != 0, [15] new (un-clamped) sigma2,
+ * [16] 1 if a transform was estimated (0 = every m0 was zero: the reference returns q = None,
+ * filterreg.py:167-168), [17] sigma2 this step used.  min_sigma2 > 0 advances the device state like the driver
+ * (`self._sigma2 = max(res.sigma2, min_sigma2)`, filterreg.py:140) so the loop needs no upload per iteration.
  * Replaces: RigidFilterReg._maximization_step filterreg.py:158-196 + cc/kabsch.cc:6-109. */
-int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host);
+int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host);
 
 /* Point-to-plane objective (filterreg.py:101-105, 183-186): target normals (n x 3 float64, NULL clears) add a
  * 3-channel filter `nx` to the E-step; prg_fr_mstep_pt2pl solves the 6 x 6 twist system
@@ -228,7 +230,7 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host
  * [13] q = sum w^2 residual^2. */
 int prg_fr_set_target_normals(prg_filterreg* h, const double* normals_hd);
 int prg_fr_get_nx(prg_filterreg* h, float* nx_hd);
-int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double* out_host);
+int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host);
 
 /* Weighted Kabsch on float32 clouds: centroids weighted by w, covariance by w^2; rot_host dim x dim
  * row-major, t_host dim.  Replaces: _kabsch.kabsch / kabsch2d (cc/kabsch_py.cc, cc/kabsch.cc:6-109). */

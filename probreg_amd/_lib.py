@@ -94,10 +94,10 @@ SIGNATURES = {
     "prg_fr_set_state": [_vp, _vp, _vp, _d],
     "prg_fr_estep": [_vp, _d, _c.POINTER(_i), _c.POINTER(_i)],
     "prg_fr_get_estep": [_vp, _vp, _vp, _vp],
-    "prg_fr_mstep": [_vp, _d, _i, _vp],
+    "prg_fr_mstep": [_vp, _d, _i, _d, _vp],
     "prg_fr_set_target_normals": [_vp, _vp],
     "prg_fr_get_nx": [_vp, _vp],
-    "prg_fr_mstep_pt2pl": [_vp, _d, _i, _vp],
+    "prg_fr_mstep_pt2pl": [_vp, _d, _i, _d, _vp],
     "prg_kabsch_weighted": [_i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
 }
 

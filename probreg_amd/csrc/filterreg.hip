@@ -548,8 +548,13 @@ __global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__
 }
 
 // per-point M-step terms (filterreg.py:163-182, 190-195) -> block partials [nblk][kFrComp]
+// c = w/(1-w) * n/m * (2 sigma2 pi)^(dim/2)   (filterreg.py:164), evaluated on the device: no host round trip
+__device__ __forceinline__ double fr_uniform_c(double wfac, int dim, double sigma2) {
+    return wfac * pow(2.0 * sigma2 * M_PI, dim * 0.5);
+}
+
 __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout, int ch,
-                                                     const double* __restrict__ ts, int64_t m, int dim, double c,
+                                                     const double* __restrict__ ts, int64_t m, int dim, double wfac,
                                                      const double* __restrict__ state, double* __restrict__ part) {
     __shared__ double sh[4][kFrComp];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -557,6 +562,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
 #pragma unroll
     for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
     const double sigma2 = state[12];
+    const double c = fr_uniform_c(wfac, dim, sigma2);
     if (i < m) {
         const float m0 = vout[i * ch];
         if (m0 != 0.f) {
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
 //   residual = n.(t - v), jac = [v x n, n]:  ata += w jac jac^T (21 upper entries), atb += w residual jac,
 //   r_sum += w^2 residual^2.  comps: [0..20] ata, [21..26] atb, [27] r_sum, [28] sigma2 numerator, [29] m0m0, [30] count
 __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restrict__ vout, const double* __restrict__ ts,
-                                                           int64_t m, double c, const double* __restrict__ state,
+                                                           int64_t m, double wfac, const double* __restrict__ state,
                                                            double* __restrict__ part) {
     __shared__ double sh[4][kFrComp];
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restri
 #pragma unroll
     for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
     const double sigma2 = state[12];
+    const double c = fr_uniform_c(wfac, 3, sigma2);
     if (i < m) {
         const float m0 = vout[i * 8];
         if (m0 != 0.f) {
@@ -666,7 +673,8 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restri
 // 6 x 6 SPD solve (the reference uses Eigen's LDLT on the upper triangle), twist -> Rodrigues rotation
 // (se3_op.py:21-56), composition with the previous transform, optional sigma2 update.  One workgroup.
 __global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __restrict__ part, int nblk,
-                                                            int update_sigma2, double* __restrict__ state) {
+                                                            int update_sigma2, double min_sigma2,
+                                                            double* __restrict__ state) {
     __shared__ double sh[8][32];
     __shared__ double mom[32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -769,7 +777,9 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __rest
         for (int j = 0; j < 3; ++j) state[3 * i + j] = rn[i][j];
     }
     state[13] = mom[27];  // q = r_sum
+    state[17] = state[12];
     state[15] = update_sigma2 ? mom[28] / (3.0 * mom[29]) : state[12];
+    if (min_sigma2 > 0.0) state[12] = fmax(state[15], min_sigma2);
 }
 
 // weighted Kabsch from moments (cc/kabsch.cc:6-109): mom[0] sw, [1..3] sw*model, [4..6] sw*target, [7] sw2,
@@ -825,7 +835,8 @@ __device__ void kabsch_from_moments(const double* mom, int dim, double (&dr)[3][
 
 // weighted Kabsch from the moments (cc/kabsch.cc:6-109) + composition (filterreg.py:180) - one workgroup
 __global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__ part, int nblk, int dim,
-                                                      int update_sigma2, double* __restrict__ state) {
+                                                      int update_sigma2, double min_sigma2,
+                                                      double* __restrict__ state) {
     __shared__ double sh[8][32];
     __shared__ double mom[32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -871,7 +882,9 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__
         for (int j = 0; j < 3; ++j) state[3 * i + j] = rn[i][j];
     }
     state[13] = mom[23];
+    state[17] = state[12];                                               // sigma2 this step was computed with
     state[15] = update_sigma2 ? mom[24] / (3.0 * mom[25]) : state[12];  // :192-195 (3.0 hard-coded there)
+    if (min_sigma2 > 0.0) state[12] = fmax(state[15], min_sigma2);      // self._sigma2 = max(res.sigma2, min_sigma2), :140
 }
 
 // stand-alone Kabsch: moments of (model, target, weight) float32 clouds -> partials [nblk][kFrComp]
@@ -1148,21 +1161,17 @@ int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd)
     return PRG_OK;
 }
 
-int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double* out_host) {
+int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host) {
     PRG_REQUIRE(h && h->have_estep && out_host, PRG_ERR_STATE, "prg_fr_mstep: run prg_fr_estep first");
     PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep: w must be in [0, 1) (got %g)", w);
     prg::DeviceGuard g(h->L.device);
     hipStream_t st = h->L.stream;
-    double sigma2 = 0.0;
-    PRG_HIP(hipMemcpyAsync(&sigma2, h->state + 12, sizeof(double), hipMemcpyDeviceToHost, st));
-    PRG_HIP(hipStreamSynchronize(st));
-    // c = w/(1-w) * n/m * (2 sigma2 pi)^(dim/2)   (filterreg.py:164)
-    const double c = w / (1.0 - w) * (double)h->N / (double)h->M * pow(2.0 * sigma2 * M_PI, h->D / 2.0);
+    const double wfac = w / (1.0 - w) * (double)h->N / (double)h->M;
     const int nblk = (int)h->part_blocks;
-    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, c, h->state, h->part);
-    k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, h->state);
+    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, wfac, h->state, h->part);
+    k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
-    PRG_HIP(hipMemcpyAsync(out_host, h->state, 17 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipMemcpyAsync(out_host, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
     return PRG_OK;
 }
@@ -1195,21 +1204,18 @@ int prg_fr_get_nx(prg_filterreg* h, float* nx_hd) {
     return PRG_OK;
 }
 
-int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double* out_host) {
+int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host) {
     PRG_REQUIRE(h && h->have_estep && out_host, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: run prg_fr_estep first");
     PRG_REQUIRE(h->ch == 8, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: target normals have not been set");
     PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep_pt2pl: w must be in [0, 1) (got %g)", w);
     prg::DeviceGuard g(h->L.device);
     hipStream_t st = h->L.stream;
-    double sigma2 = 0.0;
-    PRG_HIP(hipMemcpyAsync(&sigma2, h->state + 12, sizeof(double), hipMemcpyDeviceToHost, st));
-    PRG_HIP(hipStreamSynchronize(st));
-    const double c = w / (1.0 - w) * (double)h->N / (double)h->M * pow(2.0 * sigma2 * M_PI, h->D / 2.0);
+    const double wfac = w / (1.0 - w) * (double)h->N / (double)h->M;
     const int nblk = (int)h->part_blocks;
-    k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, c, h->state, h->part);
-    k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>(h->part, nblk, update_sigma2, h->state);
+    k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, wfac, h->state, h->part);
+    k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>(h->part, nblk, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
-    PRG_HIP(hipMemcpyAsync(out_host, h->state, 17 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipMemcpyAsync(out_host, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
     return PRG_OK;
 }

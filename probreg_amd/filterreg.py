@@ -99,10 +99,10 @@ class _Plan(object):
         check(lib.prg_fr_get_nx(self._h, ptr(nx)))
         return nx
 
-    def mstep(self, w, update_sigma2, objective_type="pt2pt"):
-        out = np.zeros(17)
+    def mstep(self, w, update_sigma2, objective_type="pt2pt", min_sigma2=0.0):
+        out = np.zeros(18)
         fn = lib.prg_fr_mstep_pt2pl if objective_type == "pt2pl" else lib.prg_fr_mstep
-        check(fn(self._h, float(w), 1 if update_sigma2 else 0, ptr(out)))
+        check(fn(self._h, float(w), 1 if update_sigma2 else 0, float(min_sigma2), ptr(out)))
         return out
 
     def close(self):
@@ -197,10 +197,11 @@ class FilterReg(abc.ABC):
         plan.set_normals(self._target_normals if objective_type == "pt2pl" else None)
         dim = target.shape[1]
         res = MstepResult(self._tf_result, self._sigma2, None)
+        # the transform and sigma2 live on the device: uploaded once, advanced by the M-step kernel
+        plan.set_state(self._tf_result.rot, self._tf_result.t, self._sigma2)
         for i in range(maxiter):
-            plan.set_state(self._tf_result.rot, self._tf_result.t, self._sigma2)
             plan.estep()
-            out = plan.mstep(w, self._update_sigma2, objective_type)
+            out = plan.mstep(w, self._update_sigma2, objective_type, min_sigma2)
             if out[16] == 0.0:  # every m0 == 0 (filterreg.py:167-168, :136-138)
                 res = MstepResult(self._tf_result, self._sigma2, q)
                 break

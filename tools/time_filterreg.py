@@ -20,15 +20,13 @@ def main():
     plan = reg._ensure_plan(tgt)
     rot, t = np.identity(3), np.zeros(3)
     torch.cuda.synchronize()
+    plan.set_state(rot, t, sigma2)
     for it in range(iters):
         t0 = time.perf_counter()
-        plan.set_state(rot, t, sigma2)
         size, blur = plan.estep()
         t1 = time.perf_counter()
-        out = plan.mstep(0.05, True)
+        out = plan.mstep(0.05, True, "pt2pt", 1e-4)
         t2 = time.perf_counter()
-        rot, t = out[:9].reshape(3, 3), out[9:12]
-        sigma2 = max(out[15], 1e-4)
         print("iter %2d: estep %.3f ms (lattice %d vertices, blur=%d)  mstep %.3f ms  sigma2=%.5e q=%.5e"
               % (it, (t1 - t0) * 1e3, size, blur, (t2 - t1) * 1e3, out[15], out[13]))
 
