@@ -769,8 +769,8 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     }
     if (cap != h->Mcap || !h->zmeta) {
         PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
-        PRG_TRY(ensure_exact(&h->zsmeta, (size_t)(cap / prg::kSuper + 1) * 8));
-        PRG_HIP(hipMemsetAsync(h->zsmeta, 0, (size_t)(cap / prg::kSuper + 1) * 8 * sizeof(float), h->stream));
+        PRG_TRY(ensure_exact(&h->zsmeta, (size_t)(cap / prg::kSuper + 4) * 8));
+        PRG_HIP(hipMemsetAsync(h->zsmeta, 0, (size_t)(cap / prg::kSuper + 4) * 8 * sizeof(float), h->stream));
         if (!h->motion) {
             PRG_TRY(ensure_exact(&h->motion, 2));
             PRG_HIP(hipMemsetAsync(h->motion, 0, 2 * sizeof(unsigned), h->stream));
@@ -819,8 +819,8 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     }
     if (cap != h->Ncap || !h->tmeta) {
         PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
-        PRG_TRY(ensure_exact(&h->tsmeta, (size_t)(cap / prg::kSuper + 1) * 8));
-        PRG_HIP(hipMemsetAsync(h->tsmeta, 0, (size_t)(cap / prg::kSuper + 1) * 8 * sizeof(float), h->stream));
+        PRG_TRY(ensure_exact(&h->tsmeta, (size_t)(cap / prg::kSuper + 4) * 8));
+        PRG_HIP(hipMemsetAsync(h->tsmeta, 0, (size_t)(cap / prg::kSuper + 4) * 8 * sizeof(float), h->stream));
         PRG_TRY(ensure_exact(&h->colmin, (size_t)cap));
         PRG_HIP(hipMemsetAsync(h->colmin, 0, (size_t)cap * sizeof(float), h->stream));
     }

@@ -198,6 +198,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; };
+struct alignas(32) Meta4 { GroupMeta m[4]; };
 
 // squared distance between two axis-aligned boxes (0 if they overlap)
 __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&ahi)[3], const GroupMeta& g) {
@@ -325,10 +326,15 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
     const GroupMeta* __restrict__ gp = tmeta + base / prg::kGroup;
     const GroupMeta* __restrict__ sp = tsmeta + base / prg::kSuper;
     const int nsuper = seg_len / prg::kSuper;
-    GroupMeta sm = sp[0];
-    for (int sg = 0; sg < nsuper; ++sg) {
-        const GroupMeta cur = sm;
-        sm = sp[sg + 1];  // prefetch
+    // super-group boxes are fetched four at a time (128 B, two s_load_dwordx16): a wave that skips everything
+    // is bound by the latency of these dependent scalar loads, so fewer, wider fetches matter
+    for (int sg4 = 0; sg4 < nsuper; sg4 += 4) {
+      const Meta4 m4 = *reinterpret_cast<const Meta4*>(sp + sg4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int sg = sg4 + s4;
+        if (sg >= nsuper) break;
+        const GroupMeta cur = m4.m[s4];
         // cur.aux = max b_n, cur.pad = min b_n over the 256 points
         if (__builtin_amdgcn_readfirstlane((int)(fmaf(box_dist2(lo, hi, cur), kk, cur.aux) < kCullLog2))) continue;
         const bool all = fmaf(box_maxdist2(lo, hi, cur), kk, cur.pad) > kCullLog2;  // every P is non-zero
@@ -358,6 +364,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
                 cq = nq;
             }
         }
+      }
     }
     float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
     *reinterpret_cast<float2*>(o) = make_float2(p1.x, p1.y);
