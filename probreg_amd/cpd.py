@@ -24,12 +24,11 @@ from .log import log
 
 EstepResult = namedtuple("EstepResult", ["pt1", "p1", "px", "n_p"])
 MstepResult = namedtuple("MstepResult", ["transformation", "sigma2", "q"])
-MstepResult.__doc__ = """Result of Maximization step.
+MstepResult.__doc__ = """What an M-step (and ``registration``) hands back - same 3-tuple as the reference (cpd.py:18).
 
-    Attributes:
-        transformation (tf.Transformation): Transformation from source to target.
-        sigma2 (float): Variance of Gaussian distribution.
-        q (float): Result of likelihood.
+    transformation : the estimated source -> target map (a ``probreg_amd.transformation`` object)
+    sigma2         : current isotropic variance of the GMM components
+    q              : value of the objective the convergence test looks at
 """
 
 
@@ -53,12 +52,12 @@ def _params_block(linear, t, scale, dim, delta=None):
 
 
 class CoherentPointDrift(abc.ABC):
-    """Coherent Point Drift algorithm (abstract; reference cpd.py:29-120).
+    """Base class of the three CPD flavours (reference cpd.py:29-120): owns the GPU plan and the EM driver,
+    subclasses supply the initialisation and the M-step.
 
-    Args:
-        source (numpy.ndarray, optional): Source point cloud data.
-        use_cuda (bool, optional): accepted for compatibility, ignored.
-        device (int, optional): GPU index (default: the process's current torch device).
+    source   : (M, D) array, the cloud that gets moved (may also be given later through ``set_source``)
+    use_cuda : kept so existing call sites run unchanged; the engine is always the HIP one
+    device   : GPU index; defaults to the calling process's current torch device
     """
 
     _kind = None
@@ -185,13 +184,11 @@ class CoherentPointDrift(abc.ABC):
 
 
 class RigidCPD(CoherentPointDrift):
-    """Coherent Point Drift for rigid transformation (reference cpd.py:123-192).
+    """Rigid (rotation, translation, optional isotropic scale) CPD - reference cpd.py:123-192.
 
-    Args:
-        source (numpy.ndarray, optional): Source point cloud data.
-        update_scale (bool, optional): If this flag is True, compute the scale parameter.
-        tf_init_params (dict, optional): Parameters to initialize transformation.
-        use_cuda (bool, optional): accepted for compatibility, ignored.
+    update_scale   : estimate the scale as well (True, the reference's default) or pin it to 1
+    tf_init_params : optional starting transform, keys ``rot`` / ``t`` / ``scale`` as in
+                     ``RigidTransformation``
     """
 
     _kind = _lib.PRG_TF_RIGID
@@ -234,7 +231,8 @@ class RigidCPD(CoherentPointDrift):
 
 
 class AffineCPD(CoherentPointDrift):
-    """Coherent Point Drift for affine transformation (reference cpd.py:195-244)."""
+    """Affine CPD: full D x D matrix ``b`` plus translation - reference cpd.py:195-244.  ``tf_init_params`` may hold
+    ``b`` / ``t`` to start from."""
 
     _kind = _lib.PRG_TF_AFFINE
 
@@ -296,13 +294,12 @@ def _mstep_from_arrays(obj, source, target, estep_res, kind, update_scale):
 
 
 class NonRigidCPD(CoherentPointDrift):
-    """Coherent Point Drift for nonrigid transformation (reference cpd.py:247-303).
+    """Non-rigid CPD (motion coherence): displacement field ``G W`` over the source points - reference
+    cpd.py:247-303.
 
-    Args:
-        source (numpy.ndarray, optional): Source point cloud data.
-        beta (float, optional): Parameter of RBF kernel.
-        lmd (float, optional): Parameter for regularization term.
-        use_cuda (bool, optional): accepted for compatibility, ignored.
+    beta : width parameter of the Gaussian kernel ``G = exp(-d^2 / (2 beta))`` (note: beta, not beta^2)
+    lmd  : weight of the smoothness regulariser
+    The M x M kernel is built on the GPU when the source is set and stays there.
     """
 
     _kind = _lib.PRG_TF_NONRIGID
@@ -414,26 +411,17 @@ class ConstrainedNonRigidCPD(NonRigidCPD):
 
 def registration_cpd(source, target, tf_type_name="rigid", w=0.0, maxiter=50, tol=0.001, callbacks=[],
                      use_cuda=False, **kwargs):
-    """CPD Registraion (reference cpd.py:407-456).
+    """One-call CPD registration with the reference's signature (cpd.py:407-456).
 
-    Args:
-        source (numpy.ndarray): Source point cloud data.
-        target (numpy.ndarray): Target point cloud data.
-        tf_type_name (str, optional): Transformation type('rigid', 'affine', 'nonrigid', 'nonrigid_constrained')
-        w (float, optional): Weight of the uniform distribution, 0 < `w` < 1.
-        maxitr (int, optional): Maximum number of iterations to EM algorithm.
-        tol (float, optional): Tolerance for termination.
-        callback (:obj:`list` of :obj:`function`, optional): Called after each iteration.
-            `callback(probreg.Transformation)`
-        use_cuda (bool, optional): accepted for compatibility, ignored (always the HIP engine).
-
-    Keyword Args:
-        update_scale (bool, optional): If this flag is true and tf_type is rigid transformation,
-            then the scale is treated. The default is true.
-        tf_init_params (dict, optional): Parameters to initialize transformation (for rigid or affine).
-
-    Returns:
-        MstepResult: Result of the registration (transformation, sigma2, q)
+    source, target : (n, 2|3) arrays or Open3D point clouds (anything with a ``.points`` attribute)
+    tf_type_name   : 'rigid' | 'affine' | 'nonrigid' | 'nonrigid_constrained'
+    w              : mass of the uniform outlier component, in [0, 1)
+    maxiter, tol   : EM stops after ``maxiter`` iterations or when |q - q_prev| < tol (use tol < 0 for a fixed count)
+    callbacks      : callables invoked with the current transformation after every iteration
+    use_cuda       : ignored (kept for drop-in compatibility)
+    **kwargs       : forwarded to the class: ``update_scale`` / ``tf_init_params`` (rigid, affine), ``beta`` / ``lmd``
+                     (non-rigid), ``alpha`` / ``idx_source`` / ``idx_target`` (constrained)
+    Returns ``MstepResult(transformation, sigma2, q)``.  Under torchrun the target is sharded over the ranks.
     """
     if tf_type_name == "rigid":
         cpd = RigidCPD(_as_points(source), use_cuda=use_cuda, **kwargs)

@@ -791,6 +791,9 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
                                                        0.f, h->perm_src);
     k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, m, dim, h->z4, cap, prg::kSrcPad, 0.f,
                                                        h->perm_src);
+    // boxes of the whole padded array once; the per-iteration transform kernel refreshes the blocks with real points
+    k_group_meta<<<grid1(cap / prg::kGroup), kBlock, 0, h->stream>>>(h->z4, cap / prg::kGroup, h->zmeta);
+    k_super_meta<<<grid1(cap / prg::kSuper), kBlock, 0, h->stream>>>(h->zmeta, cap / prg::kSuper, h->zsmeta);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));  // the caller's buffer may be pageable host memory
     h->have_colmin = false;
@@ -953,8 +956,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (h->nonrigid)
         PRG_TRY(prg::nonrigid_transform(h));
     else  // one fused kernel: transform, source motion, group / super-group boxes of the transformed cloud
-        k_transform_linear<<<(unsigned)(h->Mcap / kBlock), kBlock, 0, h->stream>>>(h->src4, h->z4, h->M, h->params,
-                                                                                  h->motion, slot, h->zmeta, h->zsmeta);
+        k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
+            h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->zsmeta);  // pad-only blocks are static
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, h->have_colmin);

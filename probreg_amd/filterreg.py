@@ -24,13 +24,7 @@ from .log import log
 
 EstepResult = namedtuple("EstepResult", ["m0", "m1", "m2", "nx"])
 MstepResult = namedtuple("MstepResult", ["transformation", "sigma2", "q"])
-MstepResult.__doc__ = """Result of Maximization step.
-
-    Attributes:
-        transformation (tf.Transformation): Transformation from source to target.
-        sigma2 (float): Variance of Gaussian distribution.
-        q (float): Result of likelihood.
-"""
+MstepResult.__doc__ = """(transformation, sigma2, q) of one FilterReg M-step / of the whole registration (reference filterreg.py:28)."""
 
 
 def _as_points(x):
@@ -118,14 +112,12 @@ class _Plan(object):
 
 
 class FilterReg(abc.ABC):
-    """FilterReg (reference filterreg.py:45-147).
+    """Gaussian-filter based EM registration, driver part (reference filterreg.py:45-147).
 
-    Args:
-        source (numpy.ndarray, optional): Source point cloud data.
-        target_normals (numpy.ndarray, optional): Normals of target points (pt2pl only - not built).
-        sigma2 (Float, optional): Variance parameter. If this variable is None,
-            the variance is initialised from the mean squared distance.
-        update_sigma2 (bool, optional): If this variable is True, Update sigma2 in the registration iteration.
+    source         : (M, D) array that gets moved
+    target_normals : (N, 3) unit normals of the target, only for ``objective_type='pt2pl'``
+    sigma2         : kernel variance; ``None`` = mean squared source-target distance (clamped to ``min_sigma2``)
+    update_sigma2  : re-estimate sigma2 in every M-step (off by default, as in the reference)
     """
 
     def __init__(self, source=None, target_normals=None, sigma2=None, update_sigma2=False):
@@ -237,27 +229,16 @@ class RigidFilterReg(FilterReg):
 def registration_filterreg(source, target, target_normals=None, sigma2=None, update_sigma2=False, w=0,
                            objective_type="pt2pt", maxiter=50, tol=0.001, min_sigma2=1.0e-4, feature_fn=_identity,
                            callbacks=[], **kwargs):
-    """FilterReg registration (reference filterreg.py:269-317).
+    """One-call rigid FilterReg with the reference's signature (filterreg.py:269-317).
 
-    Args:
-        source (numpy.ndarray): Source point cloud data.
-        target (numpy.ndarray): Target point cloud data.
-        target_normals (numpy.ndarray, optional): Normal vectors of target point cloud (needed for pt2pl).
-        sigma2 (float, optional): Variance of GMM. If `sigma2` is `None`, it is initialised automatically.
-        update_sigma2 (bool, optional): update sigma2 every iteration.
-        w (float, optional): Weight of the uniform distribution, 0 < `w` < 1.
-        objective_type (str, optional): The type of objective function selected by 'pt2pt' or 'pt2pl'.
-        maxitr (int, optional): Maximum number of iterations to EM algorithm.
-        tol (float, optional): Tolerance for termination.
-        min_sigma2 (float, optional): Minimum variance of GMM.
-        feature_fn (function, optional): Feature function (identity only).
-        callback (:obj:`list` of :obj:`function`, optional): Called after each iteration.
-
-    Keyword Args:
-        tf_init_params (dict, optional): Parameters to initialize transformation (for rigid).
-
-    Returns:
-        MstepResult: Result of the registration (transformation, sigma2, q)
+    source, target  : (n, 2|3) arrays or Open3D point clouds
+    target_normals  : (N, 3) normals, required for ``objective_type='pt2pl'``
+    sigma2          : kernel variance (None = automatic); update_sigma2 re-estimates it every iteration
+    w               : outlier mass in [0, 1); objective_type 'pt2pt' (Kabsch) or 'pt2pl' (twist)
+    maxiter, tol    : stop after maxiter iterations or when |q - q_prev| < tol; min_sigma2 clamps the variance
+    feature_fn      : only the identity is supported; callbacks get the transformation after every iteration
+    **kwargs        : ``tf_init_params`` for the starting rigid transform
+    Returns ``MstepResult(transformation, sigma2, q)``.
     """
     frg = RigidFilterReg(_as_points(source), _as_points(target_normals), sigma2, update_sigma2, **kwargs)
     frg.set_callbacks(callbacks)

@@ -47,7 +47,8 @@ class Direct(object):
 
 
 class GaussTransform(object):
-    """Calculate Gauss Transform (signature of reference gauss_transform.py:28-60)."""
+    """``GaussTransform(source, h).compute(target, weights)`` as in reference gauss_transform.py:28-60: weights may be
+    one row (S) or several (C x S); ``eps`` and ``sw_h`` only mattered for the reference's IFGT switch."""
 
     def __init__(self, source, h, eps=1.0e-4, sw_h=0.01):
         self._m = source.shape[0]
