@@ -168,6 +168,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    if os.environ.get("PROBREG_SHARE_GPU") == "1":  # test rig only: N ranks on one GPU (use with PROBREG_DIST_BACKEND=gloo)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1 or os.environ.get("PROBREG_FORCE_DIST") == "1":
         import torch.distributed as dist
@@ -176,7 +178,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PROBREG_DIST_BACKEND", "nccl")  # nccl = RCCL; gloo only for the shared-GPU test rig
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from probreg_amd import _lib, cpd, synthetic
 

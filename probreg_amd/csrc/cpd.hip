@@ -271,12 +271,25 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     const double sigma2 = params[13];
     const float kkf = (float)(-kLog2e / (2.0 * sigma2));
     const double kk = (double)kkf;
+    // online (min, sum) merge, 8 segment partials in flight per lane; the rescale factors are <= 1 and go through
+    // v_exp_f32 like the sweeps' own (their 1-ulp error is far below the fp32 sums they multiply), sums in fp64
     float gmin = INFINITY;
-    for (int s = 0; s < nseg; ++s) gmin = fminf(gmin, colpart[(int64_t)s * ncap + i].x);
     double ssum = 0.0;
-    for (int s = 0; s < nseg; ++s) {
-        const float2 p = colpart[(int64_t)s * ncap + i];
-        if (p.y != 0.f) ssum += (double)p.y * exp2(kk * ((double)p.x - (double)gmin));  // culled segments are empty
+    for (int s0 = 0; s0 < nseg; s0 += 8) {
+        float2 p[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            p[k] = (s0 + k < nseg) ? colpart[(int64_t)(s0 + k) * ncap + i] : make_float2(INFINITY, 0.f);
+        float cm = p[0].x;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) cm = fminf(cm, p[k].x);
+        if (cm < gmin) {
+            ssum *= (double)__builtin_amdgcn_exp2f(kkf * (gmin - cm));  // first chunk: 0 * exp2(-inf) = 0
+            gmin = cm;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)  // culled segments are empty (sum 0, min = their seed bound)
+            if (p[k].y != 0.f) ssum += (double)(p[k].y * __builtin_amdgcn_exp2f(kkf * (p[k].x - gmin)));
     }
     const double den = ssum * exp2(kk * (double)gmin);  // underflows to 0 exactly where fp64 exp() does
     double c = pow(2.0 * M_PI * sigma2, dim * 0.5);
@@ -336,20 +349,49 @@ __device__ __forceinline__ void row_moment_terms(double (&a)[kMomComp], double p
 __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict__ rowpart, int nseg, int64_t mcap,
                                                         int64_t m, const float4* __restrict__ src4,
                                                         const float4* __restrict__ z4, double* __restrict__ rowacc,
-                                                        double* __restrict__ mompart) {
+                                                        double* __restrict__ mompart,
+                                                        const unsigned char* __restrict__ rowflag) {
     double a[kMomComp];
 #pragma unroll
     for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
     // grid-stride over the rows: few workgroups -> few partials for the single-block final reduction
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double p1 = 0, u[3] = {0, 0, 0}, e = 0;
-        for (int s = 0; s < nseg; ++s) {
+        // (128-row wave block, segment) partials the culled row pass never touched are absent (neither written nor
+        // read): the wave fetches its block's 64 flag bytes once and walks the set bits (<= 64 segments)
+        uint64_t live = nseg >= 64 ? ~0ull : ((1ull << nseg) - 1ull);
+        if (rowflag) {
+            const int wb = __builtin_amdgcn_readfirstlane((int)(i >> 7));
+            const uint4* __restrict__ f = reinterpret_cast<const uint4*>(rowflag + (int64_t)wb * 64);
+            uint64_t bits = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = f[q];
+                const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb)
+                        bits |= (uint64_t)((w4[k] >> (8 * bb)) & 1u) << (q * 16 + k * 4 + bb);
+            }
+            live &= bits;
+        }
+        while (live) {
+            // two live segments per trip: ten independent loads in flight
+            const int s = __builtin_ctzll(live);
+            live &= live - 1;
+            const int s2 = live ? __builtin_ctzll(live) : s;
+            const double k2 = live ? 1.0 : 0.0;
+            live &= live - 1;
             const float* __restrict__ o = rowpart + (int64_t)s * 5 * mcap + i;
-            p1 += o[0];
-            u[0] += o[mcap];
-            u[1] += o[2 * mcap];
-            u[2] += o[3 * mcap];
-            e += o[4 * mcap];
+            const float* __restrict__ o2 = rowpart + (int64_t)s2 * 5 * mcap + i;
+            const float v0 = o[0], v1 = o[mcap], v2 = o[2 * mcap], v3 = o[3 * mcap], v4 = o[4 * mcap];
+            const float w0 = o2[0], w1 = o2[mcap], w2 = o2[2 * mcap], w3 = o2[3 * mcap], w4 = o2[4 * mcap];
+            p1 += (double)v0 + k2 * (double)w0;
+            u[0] += (double)v1 + k2 * (double)w1;
+            u[1] += (double)v2 + k2 * (double)w2;
+            u[2] += (double)v3 + k2 * (double)w3;
+            e += (double)v4 + k2 * (double)w4;
         }
         const float4 zf = z4[i], yf = src4[i];
         const double z[3] = {zf.x, zf.y, zf.z};
@@ -947,7 +989,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_REQUIRE((int64_t)SA * segA + prg::kOverRead <= h->Mcap && (int64_t)SB * segB + prg::kOverRead <= h->Ncap,
                 PRG_ERR_STATE, "prg_cpd_estep: internal segmenting failure");
     PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)SA * h->Ncap));
-    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)SB * 5 * h->Mcap));
+    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)SB * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
 
     if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
@@ -979,7 +1021,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
     const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
     k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
-                                                  h->mompart);
+                                                  h->mompart,
+                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)SB * 5 * h->Mcap)
+                                                           : nullptr);
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());

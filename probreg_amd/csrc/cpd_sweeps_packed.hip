@@ -311,10 +311,12 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
                                                          const GroupMeta* __restrict__ tmeta,
                                                          const GroupMeta* __restrict__ tsmeta, int seg_len,
                                                          const double* __restrict__ params,
-                                                         float* __restrict__ rowpart, int64_t mcap) {
+                                                         float* __restrict__ rowpart, int64_t mcap,
+                                                         unsigned char* __restrict__ rowflag) {
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const int64_t m0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
     const float4 a = z4[m0], b = z4[m0 + 1];
+    bool touched = false;  // wave-uniform: did this wave evaluate any pair of its (128 rows x segment) block?
     const f2 zx = {a.x, b.x}, zy = {a.y, b.y}, zz = {a.z, b.z};
     f2 p1 = splat(0.f), ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), e = splat(0.f);
     float lo[3], hi[3];
@@ -345,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
                 const GroupMeta gm = gp[g];
                 if (__builtin_amdgcn_readfirstlane((int)(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2))) continue;
             }
+            touched = true;
             const Quad* __restrict__ q = tp + g * 8;
             Quad cq = q[0];
 #pragma unroll
@@ -366,6 +369,10 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
         }
       }
     }
+    // k_row_moments skips the partials of untouched (wave, segment) blocks: they are neither written nor read
+    if ((threadIdx.x & 63) == 0)
+        rowflag[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + blockIdx.y] = touched ? 1 : 0;  // [wave block][segment]
+    if (!touched) return;
     float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
     *reinterpret_cast<float2*>(o) = make_float2(p1.x, p1.y);
     *reinterpret_cast<float2*>(o + mcap) = make_float2(-ux.x, -ux.y);
@@ -389,7 +396,8 @@ void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->M, kBlock * 2), (unsigned)S);
     k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta),
                                                    reinterpret_cast<const GroupMeta*>(h->tsmeta), seg_len, h->params,
-                                                   h->rowpart, h->Mcap);
+                                                   h->rowpart, h->Mcap,
+                                                   reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)S * 5 * h->Mcap));
 }
 
 }  // namespace prg
