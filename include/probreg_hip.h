@@ -169,6 +169,28 @@ int prg_cpd_rowacc_ptr(prg_cpd* h, double** rowacc_dev, int64_t* count);
  * Replaces: NonRigidCPD._maximization_step, cpd.py:284-303. */
 int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd);
 
+/* ---- Bayesian CPD -------------------------------------------------- */
+/* Per-source weights of the E-step: P_mn = a_m e_mn / (c + sum_m a_m e_mn), e_mn = exp(-|x_n - z_m|^2 / 2 sigma2),
+ * with a_m = exp(log_weights[m]), log_weights <= 0 ([m] float64, host or device, caller's point order); NULL
+ * clears them.  `uniform_ratio` > 0 replaces M/N in the outlier constant c = (2 pi sigma2)^(D/2) w/(1-w) * ratio.
+ * BCPD's E-step (bcpd.py:53-72) is this with a_m = alpha_m exp(-s^2 D Sigma_mm / 2 sigma2) and ratio = 1/N
+ * (both rescaled by max a_m on the host); nu' = pt1, nu = p1, px come from prg_cpd_get_estep as for CPD.
+ * Replaces: BayesianCoherentPointDrift.expectation_step, bcpd.py:53-72 (the M x N `pmat`, its `np.kron`
+ * products :69-70 and the Python list comprehension :57). */
+int prg_cpd_set_source_weights(prg_cpd* h, const double* log_weights_hd, double uniform_ratio);
+/* G = inverse multiquadric kernel 1/sqrt(|y_i - y_j|^2 + c) of the source in float32 (cc/math_utils.cc:32-34,
+ * bcpd.py:107) and BCPD mode: the transform becomes z = s R (y + v_hat) + t (CombinedTransformation) with the
+ * v_hat of the last prg_cpd_bcpd_solve (0 before the first). */
+int prg_cpd_bcpd_build_g(prg_cpd* h, double c);
+/* Core of CombinedBCPD._maximization_step (bcpd.py:123-133) for nu = nu_hd ([m] float64, caller's order) or, when
+ * nu_hd is NULL, the p1 of the last E-step:
+ *   Sigma = (lmd G^-1 + cfac diag(nu))^-1,  v_hat = cfac * Sigma * diag(nu) * resid   (resid = T^-1(x_hat) - y),
+ * returned as v_hat [m x dim] and diag(Sigma) [m] (float64, caller's point order); v_hat also stays on the
+ * device for the next transform.  Woodbury form on S = (lmd/cfac) I + D^1/2 G D^1/2 - no G^-1, no M x M inverse:
+ * fp64 Cholesky + a triangular solve with M right-hand sides on the matrix cores (4/3 M^3 flop). */
+int prg_cpd_bcpd_solve(prg_cpd* h, double lmd, double cfac, const double* nu_hd, const double* resid_hd,
+                       double* vhat_hd, double* sigma_diag_hd);
+
 /* ---- direct Gauss transform ------------------------------------------------------------ */
 /* out[c*t + i] = sum_j weights[c*s + j] * exp(-|target_i - source_j|^2 / h^2), float64 out.
  * Replaces: gauss_transform._gauss_transform_direct / Direct.compute / GaussTransform.compute
@@ -184,6 +206,14 @@ int prg_squared_kernel_sum(int device, void* hip_stream, const float* x_hd, int6
 /* Dense K = exp(-|x_i-y_j|^2/(2*beta)) float32 (rows = x). Replaces mu.rbf_kernel, math_utils.py:36-37. */
 int prg_rbf_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd,
                    int64_t n, int dim, double beta, float* out_hd);
+/* Dense K = 1/sqrt(|x_i-y_j|^2 + c) float32 (rows = x).  Replaces mu.inverse_multiquadric_kernel,
+ * math_utils.py:50-51 -> cc/math_utils.cc:32-34 (BCPD's coherence kernel, bcpd.py:107). */
+int prg_inverse_multiquadric_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd,
+                                    int64_t n, int dim, double c, float* out_hd);
+/* mean_i min_j |a_i - b_j| by brute force on the GPU (float32 distances, float64 mean).
+ * Replaces mu.compute_rmse, math_utils.py:32-33 (cKDTree query; BCPD's convergence criterion bcpd.py:93). */
+int prg_nn_mean_distance(int device, void* hip_stream, const float* a_hd, int64_t m, const float* b_hd, int64_t n,
+                         int dim, double* out_host);
 
 /* ---- permutohedral lattice (Gaussian filtering) --------------------------------------------- */
 /* Replaces the pybind class probreg._permutohedral_lattice.Permutohedral

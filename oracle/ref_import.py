@@ -10,8 +10,8 @@ small stand-ins into ``sys.modules`` for exactly those names and then lets
 
 Stand-ins and what pins them:
   ``open3d``                  only used for ``isinstance`` (cpd.py:444, transformation.py:23-24)
-  ``probreg._math``           fp32 restatement of cc/math_utils.cc:5-19 (kernelBase, squaredKernel,
-                              rbfKernel - note ``2*beta`` not ``2*beta**2``); pinned by the
+  ``probreg._math``           fp32 restatement of cc/math_utils.cc:5-19, 32-34 (kernelBase, squaredKernel,
+                              rbfKernel - note ``2*beta`` not ``2*beta**2`` -, inverseMultiQuadricKernel); pinned by the
                               reference test tests/test_math_utils.py:7-16
   ``probreg._kabsch``         fp32 restatement of cc/kabsch.cc:6-109 (weights squared in H,
                               unsquared in the centroids)
@@ -59,9 +59,15 @@ def _math_standin():
         d2 = _sqdist_f32(x, y)
         return np.exp(-d2 / np.float32(2.0 * beta)).astype(np.float32)
 
+    def inverse_multiquadric_kernel(x, y, c):
+        # cc/math_utils.cc:32-34: 1.0 / sqrt(d2 + c) on the float32 array (the scalars are cast to float)
+        d2 = _sqdist_f32(x, y)
+        return (np.float32(1.0) / np.sqrt(d2 + np.float32(c))).astype(np.float32)
+
     m.squared_kernel = squared_kernel
     m.rbf_kernel = rbf_kernel
-    m.tps_kernel_2d = m.tps_kernel_3d = m.inverse_multiquadric_kernel = None
+    m.inverse_multiquadric_kernel = inverse_multiquadric_kernel
+    m.tps_kernel_2d = m.tps_kernel_3d = None
     return m
 
 
@@ -99,6 +105,12 @@ def _permutohedral_standin():
 
 
 _loaded = {}
+
+
+def load_bcpd():
+    """The reference's ``probreg.bcpd`` module (needs scipy, six - both installed - and the _math stand-in)."""
+    load(with_filterreg=False)
+    return importlib.import_module("probreg.bcpd")
 
 
 def load(with_filterreg=False):

@@ -12,7 +12,7 @@ import importlib
 from .version import __version__
 
 _SUBMODULES = ("cpd", "filterreg", "transformation", "math_utils", "gauss_transform", "gaussian_filtering",
-               "cost_functions", "dist", "engine", "synthetic")
+               "cost_functions", "dist", "engine", "synthetic", "bcpd")
 
 
 def __getattr__(name):

@@ -79,9 +79,14 @@ SIGNATURES = {
     "prg_cpd_nonrigid_set_priors": [_vp, _vp, _vp, _d],
     "prg_cpd_rowacc_ptr": [_vp, _pp, _c.POINTER(_i64)],
     "prg_cpd_mstep_nonrigid": [_vp, _d],
+    "prg_cpd_set_source_weights": [_vp, _vp, _d],
+    "prg_cpd_bcpd_build_g": [_vp, _d],
+    "prg_cpd_bcpd_solve": [_vp, _d, _d, _vp, _vp, _vp, _vp],
     "prg_gauss_transform_direct": [_i, _vp, _vp, _i64, _vp, _i64, _i, _vp, _i, _d, _vp],
     "prg_squared_kernel_sum": [_i, _vp, _vp, _i64, _vp, _i64, _i, _c.POINTER(_d)],
     "prg_rbf_kernel": [_i, _vp, _vp, _i64, _vp, _i64, _i, _d, _vp],
+    "prg_inverse_multiquadric_kernel": [_i, _vp, _vp, _i64, _vp, _i64, _i, _d, _vp],
+    "prg_nn_mean_distance": [_i, _vp, _vp, _i64, _vp, _i64, _i, _c.POINTER(_d)],
     "prg_ph_create": [_pp, _i, _vp],
     "prg_ph_destroy": [_vp],
     "prg_ph_init": [_vp, _vp, _i64, _i, _i],

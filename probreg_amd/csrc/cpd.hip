@@ -188,7 +188,9 @@ __device__ __forceinline__ void block_group_meta(float x, float y, float z, floa
 __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __restrict__ src4, float4* __restrict__ z4,
                                                              int64_t m, const double* __restrict__ params,
                                                              unsigned* __restrict__ motion, int slot,
-                                                             float* __restrict__ gmeta, float* __restrict__ smeta) {
+                                                             float* __restrict__ gmeta, float* __restrict__ smeta,
+                                                             const float* __restrict__ srcw,
+                                                             const double* __restrict__ disp) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     float moved = 0.f;
     float4 o;
@@ -196,10 +198,16 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
         const double s = params[12];
         float4 y = src4[i];
         double yx = y.x, yy = y.y, yz = y.z;
+        if (disp) {  // BCPD: z = s R (y + v_hat) + t  (CombinedTransformation, transformation.py)
+            yx += disp[i * 3];
+            yy += disp[i * 3 + 1];
+            yz += disp[i * 3 + 2];
+        }
         o.x = (float)(s * (params[0] * yx + params[1] * yy + params[2] * yz) + params[9]);
         o.y = (float)(s * (params[3] * yx + params[4] * yy + params[5] * yz) + params[10]);
         o.z = (float)(s * (params[6] * yx + params[7] * yy + params[8] * yz) + params[11]);
-        o.w = 0.f;
+        // weight a_m as an extra squared distance: a_m exp(-d2 / 2 sigma2) = exp(-(d2 + q_m) / 2 sigma2)
+        o.w = srcw ? (float)(-2.0 * params[13] * (double)srcw[i]) : 0.f;
         const float4 old = z4[i];
         const float dx = o.x - old.x, dy = o.y - old.y, dz = o.z - old.z;
         moved = sqrtf(dx * dx + dy * dy + dz * dz) * 1.000001f;
@@ -597,6 +605,12 @@ __global__ __launch_bounds__(kBlock) void k_scatter_double(const double* __restr
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i < n) out[perm ? perm[i] : i] = in[i];
 }
+// srcw[i] = (float) lw[perm[i]]  (sorted position i holds original point perm[i])
+__global__ __launch_bounds__(kBlock) void k_gather_weights(const double* __restrict__ lw, int64_t m,
+                                                           const int* __restrict__ perm, float* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) out[i] = (float)lw[perm ? perm[i] : i];
+}
 __global__ __launch_bounds__(kBlock) void k_pack_px(const double* __restrict__ rowacc, int64_t mcap, int64_t m,
                                                     int dim, double* __restrict__ out, const int* __restrict__ perm) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -641,7 +655,7 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion, (void*)h->zsmeta, (void*)h->tsmeta})
+                    (void*)h->motion, (void*)h->zsmeta, (void*)h->tsmeta, (void*)h->srcw})
         if (q) (void)hipFree(q);
     h->perm_src = h->perm_tgt = nullptr;
     h->zmeta = h->tmeta = h->colmin = h->zsmeta = h->tsmeta = nullptr;
@@ -842,6 +856,38 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     h->have_source = true;
     h->have_estep = false;
     prg::nonrigid_free(h);
+    if (h->srcw) (void)hipFree(h->srcw);  // weights belong to the previous source
+    h->srcw = nullptr;
+    h->uniform_ratio = 0.0;
+    return PRG_OK;
+}
+
+int prg_cpd_set_source_weights(prg_cpd* h, const double* log_weights_hd, double uniform_ratio) {
+    PRG_REQUIRE(h && h->have_source, PRG_ERR_STATE, "prg_cpd_set_source_weights: source not set");
+    PRG_REQUIRE(uniform_ratio >= 0.0, PRG_ERR_INVALID, "prg_cpd_set_source_weights: uniform_ratio must be >= 0");
+    prg::DeviceGuard g(h->device);
+    h->uniform_ratio = uniform_ratio;
+    if (!log_weights_hd) {
+        PRG_HIP(hipStreamSynchronize(h->stream));
+        if (h->srcw) (void)hipFree(h->srcw);
+        h->srcw = nullptr;
+        return PRG_OK;
+    }
+    hipPointerAttribute_t attr;
+    const bool on_host = hipPointerGetAttributes(&attr, log_weights_hd) != hipSuccess || attr.type != hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (on_host)  // a_m > 1 would make q_m negative and break the cull bounds: normalise by the largest weight first
+        for (int64_t i = 0; i < h->M; ++i)
+            PRG_REQUIRE(log_weights_hd[i] <= 0.0, PRG_ERR_INVALID,
+                        "prg_cpd_set_source_weights: log-weight %lld is %g, must be <= 0 (and not NaN)", (long long)i,
+                        log_weights_hd[i]);
+    if (!h->srcw) PRG_HIP(hipMalloc((void**)&h->srcw, (size_t)h->Mcap * sizeof(float)));
+    PRG_TRY(prg::ensure_stage(h, (size_t)h->M * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(h->stage, log_weights_hd, (size_t)h->M * sizeof(double), hipMemcpyDefault, h->stream));
+    k_gather_weights<<<grid1(h->M), kBlock, 0, h->stream>>>((const double*)h->stage, h->M, h->perm_src, h->srcw);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipStreamSynchronize(h->stream));
+    h->have_colmin = false;
     return PRG_OK;
 }
 
@@ -999,17 +1045,18 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         PRG_TRY(prg::nonrigid_transform(h));
     else  // one fused kernel: transform, source motion, group / super-group boxes of the transformed cloud
         k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
-            h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->zsmeta);  // pad-only blocks are static
+            h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->zsmeta, h->srcw,
+            h->bcpd ? h->W : nullptr);  // pad-only blocks are static
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_cull)
-        prg::launch_colpass_cull(h, SA, segA, h->have_colmin);
+        prg::launch_colpass_cull(h, SA, segA, h->have_colmin && !h->srcw);  // the seed bound assumes unweighted distances
     else if (ra < 0)
         prg::launch_colpass_scalar(h, RA, SA, segA);
     else
         prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
-                                                      (double)h->M / (double)h->Nglobal, h->D, h->colmin,
+                                                      h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
                                                       use_cull ? h->tmeta : nullptr, h->tsmeta);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (use_cull)

@@ -19,6 +19,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // G[i][j] = exp(-|y_i - y_j|^2 / (2 beta)) in float32: squared distance in float32 without FMA
 // contraction (as the reference's Eigen expression), exponential in fp64 rounded once.
+// KIND 1: inverse multiquadric 1 / sqrt(d2 + c), all float32 (cc/math_utils.cc:32-34; BCPD's kernel, bcpd.py:107).
+template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_build_g(const float4* __restrict__ src4, int64_t m, float two_beta,
                                                     float* __restrict__ g) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -29,7 +31,10 @@ __global__ __launch_bounds__(kBlock) void k_build_g(const float4* __restrict__ s
         const float4 yi = src4[i];  // wave-uniform -> scalar load
         const float dx = __fsub_rn(yi.x, yj.x), dy = __fsub_rn(yi.y, yj.y), dz = __fsub_rn(yi.z, yj.z);
         const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-        g[i * m + j] = (float)exp((double)__fdiv_rn(-d2, two_beta));
+        if (KIND == 0)
+            g[i * m + j] = (float)exp((double)__fdiv_rn(-d2, two_beta));
+        else  // two_beta carries c
+            g[i * m + j] = __fdiv_rn(1.f, __fsqrt_rn(__fadd_rn(d2, two_beta)));
     }
 }
 
@@ -150,6 +155,23 @@ int nonrigid_gw(prg_cpd* h, const double* w3, double* out3) {
     return PRG_OK;
 }
 
+int build_kernel_matrix(prg_cpd* h, int kind, double param) {
+    nonrigid_free(h);
+    const int64_t m = h->M;
+    PRG_HIP(hipMalloc((void**)&h->G, (size_t)m * m * sizeof(float)));
+    PRG_HIP(hipMalloc((void**)&h->W, (size_t)m * 3 * sizeof(double)));
+    h->nr_work_bytes = (size_t)m * 16 * sizeof(double);
+    PRG_HIP(hipMalloc((void**)&h->nr_work, h->nr_work_bytes));
+    PRG_HIP(hipMemsetAsync(h->W, 0, (size_t)m * 3 * sizeof(double), h->stream));
+    dim3 grid((unsigned)prg::ceil_div(m, kBlock), (unsigned)prg::ceil_div(m, 16));
+    if (kind == 0)
+        k_build_g<0><<<grid, kBlock, 0, h->stream>>>(h->src4, m, (float)(2.0 * param), h->G);
+    else
+        k_build_g<1><<<grid, kBlock, 0, h->stream>>>(h->src4, m, (float)param, h->G);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
 int nonrigid_free(prg_cpd* h) {
     for (hipEvent_t e : h->nr_events) (void)hipEventDestroy(e);
     h->nr_events.clear();
@@ -169,6 +191,7 @@ int nonrigid_free(prg_cpd* h) {
     h->nr_work = nullptr;
     h->nr_work_bytes = 0;
     h->nonrigid = false;
+    h->bcpd = false;
     return PRG_OK;
 }
 
@@ -180,18 +203,19 @@ int prg_cpd_nonrigid_build_g(prg_cpd* h, double beta) {
     PRG_REQUIRE(h && h->have_source, PRG_ERR_STATE, "prg_cpd_nonrigid_build_g: source not set");
     PRG_REQUIRE(beta > 0.0, PRG_ERR_INVALID, "prg_cpd_nonrigid_build_g: beta must be > 0 (got %g)", beta);
     prg::DeviceGuard g(h->device);
-    prg::nonrigid_free(h);
-    const int64_t m = h->M;
-    PRG_HIP(hipMalloc((void**)&h->G, (size_t)m * m * sizeof(float)));
-    PRG_HIP(hipMalloc((void**)&h->W, (size_t)m * 3 * sizeof(double)));
-    h->nr_work_bytes = (size_t)m * 16 * sizeof(double);
-    PRG_HIP(hipMalloc((void**)&h->nr_work, h->nr_work_bytes));
-    PRG_HIP(hipMemsetAsync(h->W, 0, (size_t)m * 3 * sizeof(double), h->stream));
-    dim3 grid((unsigned)prg::ceil_div(m, kBlock), (unsigned)prg::ceil_div(m, 16));
-    k_build_g<<<grid, kBlock, 0, h->stream>>>(h->src4, m, (float)(2.0 * beta), h->G);
-    PRG_HIP(hipGetLastError());
+    PRG_TRY(prg::build_kernel_matrix(h, 0, beta));
     h->beta = beta;
     h->nonrigid = true;
+    return PRG_OK;
+}
+
+int prg_cpd_bcpd_build_g(prg_cpd* h, double c) {
+    PRG_REQUIRE(h && h->have_source, PRG_ERR_STATE, "prg_cpd_bcpd_build_g: source not set");
+    PRG_REQUIRE(c > 0.0, PRG_ERR_INVALID, "prg_cpd_bcpd_build_g: c must be > 0 (got %g)", c);
+    prg::DeviceGuard g(h->device);
+    PRG_TRY(prg::build_kernel_matrix(h, 1, c));
+    h->beta = c;
+    h->bcpd = true;  // the linear transform kernel adds the displacement W (= v_hat) before s R . + t
     return PRG_OK;
 }
 

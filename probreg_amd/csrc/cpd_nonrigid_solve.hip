@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void k_build_s(const float* __restrict__ g,
                                                     double lmd, double* __restrict__ s) {
     const int by = blockIdx.y, bx = blockIdx.x;
     if (bx > by) return;
-    const double c = lmd * params[13];
+    const double c = params ? lmd * params[13] : lmd;  // params == nullptr: lmd carries c itself (BCPD)
     const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;  // 128 columns x 2 rows per pass
     const int64_t j = (int64_t)bx * NB + tx;
     const double spj = j < m ? sp[j] : 0.0;
@@ -269,10 +269,10 @@ __global__ __launch_bounds__(kBlock, 2) void k_gemm_nt_f64(const double* abase, 
                                                         int64_t lda, int64_t ldb, double* cbase, int64_t ldc,
                                                         int kdim) {
     int by, bx;
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 3) {  // MODE 3: rectangular C -= A B^T, every tile (triangular solve with many RHS)
         by = blockIdx.x;
         bx = blockIdx.y;
-        if (bx > by) return;
+        if (MODE == 2 && bx > by) return;
     } else if (MODE == 1) {
         const int t = blockIdx.x;
         by = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -500,45 +500,11 @@ __global__ void k_nonrigid_finish(const double* __restrict__ part, int nblk, con
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
-}  // namespace
-
-extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
-    PRG_REQUIRE(h && h->G && h->W && h->have_estep, PRG_ERR_STATE,
-                "prg_cpd_mstep_nonrigid: needs build_g and an E-step first");
-    PRG_REQUIRE(lmd > 0.0, PRG_ERR_INVALID, "prg_cpd_mstep_nonrigid: lmd must be > 0 (got %g)", lmd);
-    prg::DeviceGuard g(h->device);
-    const int64_t m = h->M, mp = prg::round_up(m, NB), nblk = mp / NB;
-    // workspace: S [mp*mp] | Linv [nblk*128*128] | b3, gb, v, sp (each <= 3 mp) | trace partials | info
-    const size_t n_s = (size_t)mp * mp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)mp * 3;
-    const int tr_blk = (int)prg::ceil_div(m, kBlock);
-    const size_t need = (n_s + n_linv + 6 * n_vec + 2 * (size_t)tr_blk + 16) * sizeof(double);
-    if (h->nr_solve_bytes < need) {
-        if (h->nr_solve) (void)hipFree(h->nr_solve);
-        h->nr_solve = nullptr;
-        h->nr_solve_bytes = 0;
-        PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
-        h->nr_solve_bytes = need;
-        PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, NB * LDP * (int)sizeof(double)));
-    }
-    double* S = h->nr_solve;
-    double* linv = S + n_s;
-    double* b3 = linv + n_linv;
-    double* gb = b3 + n_vec;
-    double* v = gb + n_vec;
-    double* sp = v + n_vec;
-    double* r3 = sp + n_vec;
-    double* dw = r3 + n_vec;
-    double* trpart = dw + n_vec;
-    int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
+// blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128; the inverses
+// of the diagonal blocks go to linv.  Enqueued on the plan stream (+ the side stream of the look-ahead); on
+// return the plan stream waits for everything.
+int cholesky_lookahead(prg_cpd* h, double* S, int64_t mp, double* linv, int* info) {
     hipStream_t st = h->stream;
-
-    PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
-    k_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, mp, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
-                                        h->nr_alpha, h->params, b3, sp);
-    k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
-
-    // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128.
     // Look-ahead over two streams: the trailing update of outer panel J is split into U1 (the 512 columns of
     // the next panel, plan stream) and U2 (everything to the right, side stream), so the latency-bound panel
     // factorisation J+1 (potrf + panel solves) runs underneath U2(J) instead of leaving the GPU idle.
@@ -592,6 +558,49 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
         last_u2 = (r2 > 0) ? J : -1;
     }
     if (last_u2 >= 0) PRG_HIP(hipStreamWaitEvent(st, h->nr_events[2 * last_u2 + 1], 0));
+    return PRG_OK;
+}
+
+
+}  // namespace
+
+extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
+    PRG_REQUIRE(h && h->G && h->W && h->have_estep, PRG_ERR_STATE,
+                "prg_cpd_mstep_nonrigid: needs build_g and an E-step first");
+    PRG_REQUIRE(lmd > 0.0, PRG_ERR_INVALID, "prg_cpd_mstep_nonrigid: lmd must be > 0 (got %g)", lmd);
+    prg::DeviceGuard g(h->device);
+    const int64_t m = h->M, mp = prg::round_up(m, NB), nblk = mp / NB;
+    // workspace: S [mp*mp] | Linv [nblk*128*128] | b3, gb, v, sp (each <= 3 mp) | trace partials | info
+    const size_t n_s = (size_t)mp * mp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)mp * 3;
+    const int tr_blk = (int)prg::ceil_div(m, kBlock);
+    const size_t need = (n_s + n_linv + 6 * n_vec + 2 * (size_t)tr_blk + 16) * sizeof(double);
+    if (h->nr_solve_bytes < need) {
+        if (h->nr_solve) (void)hipFree(h->nr_solve);
+        h->nr_solve = nullptr;
+        h->nr_solve_bytes = 0;
+        PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
+        h->nr_solve_bytes = need;
+        PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, NB * LDP * (int)sizeof(double)));
+    }
+    double* S = h->nr_solve;
+    double* linv = S + n_s;
+    double* b3 = linv + n_linv;
+    double* gb = b3 + n_vec;
+    double* v = gb + n_vec;
+    double* sp = v + n_vec;
+    double* r3 = sp + n_vec;
+    double* dw = r3 + n_vec;
+    double* trpart = dw + n_vec;
+    int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
+    hipStream_t st = h->stream;
+
+    PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    k_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, mp, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
+                                        h->nr_alpha, h->params, b3, sp);
+    k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
+
+    PRG_TRY(cholesky_lookahead(h, S, mp, linv, info));
     // w = (rhs - D^1/2 S^-1 D^1/2 (G rhs)) / c with the factor above: two blocked triangular sweeps, 3 RHS
     auto solve_with_factor = [&](const double* rhs, double* wout) -> int {
         PRG_TRY(prg::nonrigid_gw(h, rhs, gb));                    // G rhs
@@ -632,5 +641,177 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
     PRG_HIP(hipStreamSynchronize(st));
     PRG_REQUIRE(host_info == 0, PRG_ERR_STATE,
                 "prg_cpd_mstep_nonrigid: S is not positive definite at pivot %d (sigma2 or lmd <= 0?)", host_info - 1);
+    return PRG_OK;
+}
+
+// =================================================================================================
+// BCPD M-step core (reference bcpd.py:123-133): with nu = row sums of P, c = s^2 / sigma2_prev^2,
+//     Sigma = (lmd G^-1 + c diag(nu))^-1,   v_hat = c Sigma diag(nu) R,   R = T^-1(x_hat) - y.
+// The reference inverts G and then the M x M sum explicitly.  Here G^-1 never appears: by Woodbury, with
+// D = diag(nu) and the SPD matrix S = (lmd / c) I + D^1/2 G D^1/2 = L L^T,
+//     Sigma = (G - B^T S^-1 B) / lmd,   B = D^1/2 G,
+// so  diag(Sigma)_m = (g_mm - |L^-1 B e_m|^2) / lmd   (a triangular solve with M right-hand sides, on the
+// matrix cores, M^3 flop) and  v_hat = (c / lmd) (G b - B^T S^-1 B b),  b = D R  (3 right-hand sides).
+// The form stays finite for nu_m -> 0 (points without support), where Sigma_mm -> g_mm / lmd.
+// =================================================================================================
+namespace {
+
+__global__ __launch_bounds__(kBlock) void k_bcpd_rhs(const double* __restrict__ rowacc, const double* __restrict__ nu_ext,
+                                                     const double* __restrict__ resid, const int* __restrict__ perm,
+                                                     int64_t m, int64_t mp, int dim, double* __restrict__ b3,
+                                                     double* __restrict__ sp) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= mp) return;
+    double nu = 0.0, r[3] = {0.0, 0.0, 0.0};
+    if (i < m) {
+        const int64_t j = perm ? perm[i] : i;
+        nu = fmax(nu_ext ? nu_ext[j] : rowacc[i], 0.0);  // nu_ext is in the caller's order, rowacc in kernel order
+        for (int k = 0; k < dim; ++k) r[k] = resid[j * dim + k];
+    }
+    b3[i * 3] = nu * r[0];
+    b3[i * 3 + 1] = nu * r[1];
+    b3[i * 3 + 2] = nu * r[2];
+    sp[i] = sqrt(nu);
+}
+
+// Wt[c][j] = g[c][j] * sp[j]  (= (D^1/2 G)^T, G symmetric); zero in the pad
+__global__ __launch_bounds__(kBlock) void k_build_bt(const float* __restrict__ g, int64_t m, int64_t mp,
+                                                     const double* __restrict__ sp, double* __restrict__ wt) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (j >= mp) return;
+    const double spj = j < m ? sp[j] : 0.0;
+    for (int64_t c = blockIdx.y; c < mp; c += gridDim.y)
+        wt[c * mp + j] = (c < m && j < m) ? (double)g[c * m + j] * spj : 0.0;
+}
+
+// diag[i] = (g_ii - sum_j Wt[i][j]^2) / lmd ; one wave per row
+__global__ __launch_bounds__(kBlock) void k_sigma_diag(const double* __restrict__ wt, const float* __restrict__ g,
+                                                       int64_t m, int64_t mp, double lmd, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    const double* row = wt + i * mp;
+    double a = 0.0;
+    for (int64_t j = lane * 2; j < mp; j += 128) {
+        const double2 v = *reinterpret_cast<const double2*>(row + j);
+        a += v.x * v.x + v.y * v.y;
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[i] = ((double)g[i * m + i] - a) / lmd;
+}
+
+__global__ __launch_bounds__(kBlock) void k_bcpd_vhat(const double* __restrict__ gb, const double* __restrict__ gt,
+                                                      int64_t m, double f, double* __restrict__ v) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m * 3) v[i] = f * (gb[i] - gt[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_unsort_rows(const double* __restrict__ in, int stride_in, int dim,
+                                                        int64_t m, const int* __restrict__ perm,
+                                                        double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const int64_t j = perm ? perm[i] : i;
+    for (int k = 0; k < dim; ++k) out[j * dim + k] = in[i * stride_in + k];
+}
+
+}  // namespace
+
+extern "C" int prg_cpd_bcpd_solve(prg_cpd* h, double lmd, double cfac, const double* nu_hd, const double* resid_hd,
+                                  double* vhat_hd, double* sigma_diag_hd) {
+    PRG_REQUIRE(h && h->bcpd && h->G && h->W, PRG_ERR_STATE, "prg_cpd_bcpd_solve: needs prg_cpd_bcpd_build_g first");
+    PRG_REQUIRE(nu_hd || h->have_estep, PRG_ERR_STATE, "prg_cpd_bcpd_solve: no E-step has run and no nu was given");
+    PRG_REQUIRE(resid_hd && vhat_hd && sigma_diag_hd, PRG_ERR_INVALID, "prg_cpd_bcpd_solve: NULL argument");
+    PRG_REQUIRE(lmd > 0.0 && cfac > 0.0, PRG_ERR_INVALID, "prg_cpd_bcpd_solve: lmd and c must be > 0 (got %g, %g)", lmd,
+                cfac);
+    prg::DeviceGuard g(h->device);
+    const int64_t m = h->M, mp = prg::round_up(m, NB), nblk = mp / NB;
+    const size_t n_s = (size_t)mp * mp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)mp * 3;
+    const size_t need = (2 * n_s + n_linv + 6 * n_vec + (size_t)mp + 16) * sizeof(double);
+    if (h->nr_solve_bytes < need) {
+        if (h->nr_solve) (void)hipFree(h->nr_solve);
+        h->nr_solve = nullptr;
+        h->nr_solve_bytes = 0;
+        PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
+        h->nr_solve_bytes = need;
+        PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, NB * LDP * (int)sizeof(double)));
+    }
+    double* S = h->nr_solve;
+    double* wt = S + n_s;
+    double* linv = wt + n_s;
+    double* b3 = linv + n_linv;
+    double* gb = b3 + n_vec;
+    double* v = gb + n_vec;
+    double* sp = v + n_vec;
+    double* gt = sp + n_vec;
+    double* tv = gt + n_vec;
+    double* diag = tv + n_vec;
+    int* info = reinterpret_cast<int*>(diag + mp);
+    hipStream_t st = h->stream;
+
+    PRG_TRY(prg::ensure_stage(h, (size_t)m * 4 * sizeof(double)));
+    double* nu_dev = nullptr;
+    PRG_HIP(hipMemcpyAsync(h->stage, resid_hd, (size_t)m * h->D * sizeof(double), hipMemcpyDefault, st));
+    if (nu_hd) {
+        nu_dev = (double*)h->stage + (size_t)m * 3;
+        PRG_HIP(hipMemcpyAsync(nu_dev, nu_hd, (size_t)m * sizeof(double), hipMemcpyDefault, st));
+    }
+    PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    k_bcpd_rhs<<<grid1(mp), kBlock, 0, st>>>(h->rowacc, nu_dev, (const double*)h->stage, h->perm_src, m, mp, h->D, b3,
+                                            sp);
+    k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, nullptr, lmd / cfac, S);
+    k_build_bt<<<dim3((unsigned)prg::ceil_div(mp, kBlock), (unsigned)std::min<int64_t>(mp, 32768)), kBlock, 0, st>>>(h->G, m, mp, sp, wt);
+    PRG_TRY(cholesky_lookahead(h, S, mp, linv, info));
+
+    // Wt <- Wt L^-T, left-looking over 512-column panels: one K-deep rectangular update with everything to the
+    // left of the panel, then four (update inside the panel, multiply by the inverted diagonal block) steps
+    constexpr int64_t NBO = 512;
+    for (int64_t K0 = 0; K0 < mp; K0 += NBO) {
+        const int64_t kend = std::min<int64_t>(K0 + NBO, mp);
+        if (K0 > 0)
+            k_gemm_nt_f64<3><<<dim3((unsigned)nblk, (unsigned)((kend - K0) / NB)), kBlock, 0, st>>>(
+                wt, S + K0 * mp, mp, mp, wt + K0, mp, (int)K0);
+        for (int64_t k0 = K0; k0 < kend; k0 += NB) {
+            if (k0 > K0)
+                k_gemm_nt_f64<3><<<dim3((unsigned)nblk, 1u), kBlock, 0, st>>>(wt + K0, S + k0 * mp + K0, mp, mp, wt + k0, mp,
+                                                                             (int)(k0 - K0));
+            k_gemm_nt_f64<0><<<(unsigned)nblk, kBlock, 0, st>>>(wt + k0, linv + (size_t)(k0 / NB) * NB * NB, mp, NB,
+                                                               wt + k0, mp, NB);
+        }
+    }
+    k_sigma_diag<<<(unsigned)prg::ceil_div(m, 4), kBlock, 0, st>>>(wt, h->G, m, mp, lmd, diag);
+
+    // v_hat = (c / lmd) (G b - G D^1/2 S^-1 D^1/2 G b)
+    PRG_TRY(prg::nonrigid_gw(h, b3, gb));
+    k_scale_rows<<<grid1(m), kBlock, 0, st>>>(sp, gb, m, v);
+    if (mp > m) PRG_HIP(hipMemsetAsync(v + m * 3, 0, (size_t)(mp - m) * 3 * sizeof(double), st));
+    for (int64_t kb = 0; kb < nblk; ++kb) {
+        const int64_t k0 = kb * NB;
+        k_diag_solve<0><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+        const int64_t rows = mp - k0 - NB;
+        if (rows > 0) k_fwd_update<<<(unsigned)prg::ceil_div(rows, 64), kBlock, 0, st>>>(S, mp, k0, mp, v);
+    }
+    for (int64_t kb = nblk - 1; kb >= 0; --kb) {
+        const int64_t k0 = kb * NB;
+        k_diag_solve<1><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+        if (k0 > 0) k_bwd_update<<<grid1(k0), kBlock, 0, st>>>(S, mp, k0, v);
+    }
+    k_scale_rows<<<grid1(m), kBlock, 0, st>>>(sp, v, m, tv);
+    PRG_TRY(prg::nonrigid_gw(h, tv, gt));
+    k_bcpd_vhat<<<grid1(m * 3), kBlock, 0, st>>>(gb, gt, m, cfac / lmd, h->W);
+
+    // results back in the caller's point order
+    double* stage = (double*)h->stage;
+    k_unsort_rows<<<grid1(m), kBlock, 0, st>>>(h->W, 3, h->D, m, h->perm_src, stage);
+    PRG_HIP(hipMemcpyAsync(vhat_hd, stage, (size_t)m * h->D * sizeof(double), hipMemcpyDefault, st));
+    k_unsort_rows<<<grid1(m), kBlock, 0, st>>>(diag, 1, 1, m, h->perm_src, gb);
+    PRG_HIP(hipMemcpyAsync(sigma_diag_hd, gb, (size_t)m * sizeof(double), hipMemcpyDefault, st));
+    PRG_HIP(hipGetLastError());
+    int host_info = 0;
+    PRG_HIP(hipMemcpyAsync(&host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    PRG_REQUIRE(host_info == 0, PRG_ERR_STATE, "prg_cpd_bcpd_solve: S is not positive definite at pivot %d",
+                host_info - 1);
     return PRG_OK;
 }

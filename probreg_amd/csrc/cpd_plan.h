@@ -69,6 +69,12 @@ struct prg_cpd {
     hipStream_t nr_stream2 = nullptr;      // side stream of the look-ahead Cholesky
     std::vector<hipEvent_t> nr_events;
 
+    // per-source log-weights (BCPD E-step, bcpd.py:53-72): srcw[m] = ln a_m <= 0 in kernel (sorted) order; the
+    // transform kernel turns it into the additive squared distance q_m = -2 sigma2 ln a_m carried in z4.w
+    float* srcw = nullptr;
+    double uniform_ratio = 0.0;  // > 0: replaces M / N in the outlier constant of cpd.py:78-79
+    bool bcpd = false;           // G is the inverse multiquadric kernel, W holds the displacement v_hat
+
     bool have_source = false, have_target = false, have_estep = false;
     double last_w = 0.0;
 };
@@ -79,4 +85,5 @@ int ensure_stage(prg_cpd* h, size_t bytes);
 int nonrigid_transform(prg_cpd* h);          // z4 = y + G W
 int nonrigid_gw(prg_cpd* h, const double* w3, double* out3);  // out3[m][3] = G * w3[m][3] (fp64)
 int nonrigid_free(prg_cpd* h);
+int build_kernel_matrix(prg_cpd* h, int kind, double param);  // kind 0: rbf(beta), 1: inverse multiquadric(c)
 }  // namespace prg

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
 #pragma unroll
             for (int p = 0; p < RP; ++p) {
                 const f2 dx = x[p] - splat(cur.q[c].x), dy = y[p] - splat(cur.q[c].y), dz = z[p] - splat(cur.q[c].z);
-                d2[c][p] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                d2[c][p] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(cur.q[c].w))));
             }
         const Quad nx1 = zp[m + 2];  // prefetch for the next trip (pads make the over-read safe)
 #pragma unroll
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
 #pragma unroll
             for (int p = 0; p < RP; ++p) {
                 const f2 dx = x[p] - splat(nx0.q[c].x), dy = y[p] - splat(nx0.q[c].y), dz = z[p] - splat(nx0.q[c].z);
-                d2[4 + c][p] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                d2[4 + c][p] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(nx0.q[c].w))));
             }
         cur = nx1;
         bool lower = false;
@@ -106,13 +106,14 @@ __global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z
     constexpr int R = 2 * RP;
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const int64_t m0 = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
-    f2 zx[RP], zy[RP], zz[RP], p1[RP], ux[RP], uy[RP], uz[RP], e[RP];
+    f2 zx[RP], zy[RP], zz[RP], zq[RP], p1[RP], ux[RP], uy[RP], uz[RP], e[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
         const float4 a = z4[m0 + (2 * p) * kBlock], b = z4[m0 + (2 * p + 1) * kBlock];
         zx[p] = (f2){a.x, b.x};
         zy[p] = (f2){a.y, b.y};
         zz[p] = (f2){a.z, b.z};
+        zq[p] = (f2){a.w, b.w};  // q_m >= 0: per-source weight as an additive squared distance (0 for plain CPD)
         p1[p] = ux[p] = uy[p] = uz[p] = e[p] = splat(0.f);
     }
     const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + (int64_t)blockIdx.y * seg_len);
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z
             for (int p = 0; p < RP; ++p) {
                 const f2 dx = zx[p] - splat(cur.q[c].x), dy = zy[p] - splat(cur.q[c].y),
                          dz = zz[p] - splat(cur.q[c].z);
-                const f2 d = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                const f2 d = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, zq[p])));
                 const f2 pr = exp2v(fmav(d, splat(kk), splat(cur.q[c].w)));
                 p1[p] += pr;
                 ux[p] = fmav(pr, dx, ux[p]);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z
             o[mcap + m] = -ux[p][hh];  // u = sum P (x - z) = -sum P (z - x)
             o[2 * mcap + m] = -uy[p][hh];
             o[3 * mcap + m] = -uz[p][hh];
-            o[4 * mcap + m] = e[p][hh];
+            o[4 * mcap + m] = fmaf(-zq[p][hh], p1[p][hh], e[p][hh]);  // e accumulated d2 + q: take q p1 back out
         }
     }
 }
@@ -280,13 +281,13 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
-                    d2[c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                    d2[c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qa.q[c].w))));
                 }
                 if (t < 3) qa = q[2 * t + 2];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
-                    d2[4 + c] = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                    d2[4 + c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qb.q[c].w))));
                 }
                 f2 cm = d2[0];
 #pragma unroll
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
     const int64_t m0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
     const float4 a = z4[m0], b = z4[m0 + 1];
     bool touched = false;  // wave-uniform: did this wave evaluate any pair of its (128 rows x segment) block?
-    const f2 zx = {a.x, b.x}, zy = {a.y, b.y}, zz = {a.z, b.z};
+    const f2 zx = {a.x, b.x}, zy = {a.y, b.y}, zz = {a.z, b.z}, zq = {a.w, b.w};  // zq: weight term, 0 for plain CPD
     f2 p1 = splat(0.f), ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), e = splat(0.f);
     float lo[3], hi[3];
     lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f2 dx = zx - splat(cq.q[c].x), dy = zy - splat(cq.q[c].y), dz = zz - splat(cq.q[c].z);
-                    const f2 d = fmav(dz, dz, fmav(dy, dy, dx * dx));
+                    const f2 d = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, zq)));
                     const f2 pr = exp2v(fmav(d, splat(kk), splat(cq.q[c].w)));
                     p1 += pr;
                     ux = fmav(pr, dx, ux);
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
     *reinterpret_cast<float2*>(o + mcap) = make_float2(-ux.x, -ux.y);
     *reinterpret_cast<float2*>(o + 2 * mcap) = make_float2(-uy.x, -uy.y);
     *reinterpret_cast<float2*>(o + 3 * mcap) = make_float2(-uz.x, -uz.y);
-    *reinterpret_cast<float2*>(o + 4 * mcap) = make_float2(e.x, e.y);
+    *reinterpret_cast<float2*>(o + 4 * mcap) = make_float2(fmaf(-zq.x, p1.x, e.x), fmaf(-zq.y, p1.y, e.y));
 }
 
 }  // namespace

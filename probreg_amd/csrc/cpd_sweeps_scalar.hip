@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float dx = x[r] - q.x, dy = y[r] - q.y, dz = z[r] - q.z;
-                float d = dx * dx;
+                float d = fmaf(dx, dx, q.w);  // q.w = per-source weight term (0 for plain CPD)
                 d = fmaf(dy, dy, d);
                 d = fmaf(dz, dz, d);
                 d2[c][r] = d;
@@ -86,11 +86,11 @@ __global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z
                                                     float* __restrict__ rowpart, int64_t mcap) {
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const int64_t m0 = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
-    float zx[R], zy[R], zz[R], p1[R], ux[R], uy[R], uz[R], e[R];
+    float zx[R], zy[R], zz[R], zq[R], p1[R], ux[R], uy[R], uz[R], e[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float4 v = z4[m0 + r * kBlock];
-        zx[r] = v.x; zy[r] = v.y; zz[r] = v.z;
+        zx[r] = v.x; zy[r] = v.y; zz[r] = v.z; zq[r] = v.w;
         p1[r] = ux[r] = uy[r] = uz[r] = e[r] = 0.f;
     }
     const float4* __restrict__ tp = tgt4 + (int64_t)blockIdx.y * seg_len;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float dx = zx[r] - q.x, dy = zy[r] - q.y, dz = zz[r] - q.z;
-                float d = dx * dx;
+                float d = fmaf(dx, dx, zq[r]);
                 d = fmaf(dy, dy, d);
                 d = fmaf(dz, dz, d);
                 const float p = fast_exp2(fmaf(d, kk, q.w));
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass(const float4* __restrict__ z
         o[mcap + m] = -ux[r];  // u = sum P (x - z) = -sum P (z - x)
         o[2 * mcap + m] = -uy[r];
         o[3 * mcap + m] = -uz[r];
-        o[4 * mcap + m] = e[r];
+        o[4 * mcap + m] = fmaf(-zq[r], p1[r], e[r]);
     }
 }
 

@@ -119,12 +119,72 @@ __global__ __launch_bounds__(kBlock) void k_pack_weighted(const float* __restric
         v.x = s[i * dim];
         v.y = s[i * dim + 1];
         v.z = dim > 2 ? s[i * dim + 2] : 0.f;
-        v.w = (float)w[i];
+        v.w = w ? (float)w[i] : 0.f;
     } else {
         v.x = v.y = v.z = prg::kSrcPad;
         v.w = 0.f;
     }
     out[i] = v;
+}
+
+// K[i][j] = 1 / sqrt(|x_i - y_j|^2 + c), all float32 (cc/math_utils.cc:32-34)
+__global__ __launch_bounds__(kBlock) void k_imq(const float* __restrict__ x, int64_t m, const float* __restrict__ y,
+                                                int64_t n, int dim, float c, float* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * 16;
+    if (j >= n) return;
+    const float yx = y[j * dim], yy = y[j * dim + 1], yz = dim > 2 ? y[j * dim + 2] : 0.f;
+    for (int64_t i = i0; i < i0 + 16 && i < m; ++i) {
+        const float dx = __fsub_rn(x[i * dim], yx), dy = __fsub_rn(x[i * dim + 1], yy),
+                    dz = dim > 2 ? __fsub_rn(x[i * dim + 2], yz) : 0.f;
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        out[i * n + j] = __fdiv_rn(1.f, __fsqrt_rn(__fadd_rn(d2, c)));
+    }
+}
+
+// Brute-force nearest neighbour: dmin[i] = min_j |a_i - b_j|^2 over the b segment of blockIdx.y, merged across
+// segments with atomicMin on the float bits (non-negative floats order like unsigned integers).
+__global__ __launch_bounds__(kBlock) void k_nn_min(const float* __restrict__ a, int64_t m, int dim,
+                                                   const float4* __restrict__ b4, int seg_len,
+                                                   unsigned* __restrict__ dmin) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    if (i < m) {
+        ax = a[i * dim];
+        ay = a[i * dim + 1];
+        az = dim > 2 ? a[i * dim + 2] : 0.f;
+    }
+    const float4* __restrict__ bp = b4 + (int64_t)blockIdx.y * seg_len;
+    float best = INFINITY;
+    for (int j = 0; j < seg_len; j += 4) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 q = bp[j + c];  // wave-uniform address: scalar loads
+            const float dx = ax - q.x, dy = ay - q.y, dz = az - q.z;
+            best = fminf(best, fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        }
+    }
+    if (i < m) atomicMin(dmin + i, __float_as_uint(best));
+}
+
+__global__ __launch_bounds__(kBlock) void k_nn_fill(unsigned* __restrict__ dmin, int64_t m) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) dmin[i] = 0x7f800000u;
+}
+
+// out[0] = mean_i sqrt(dmin[i]) ; one workgroup
+__global__ __launch_bounds__(kBlock) void k_nn_mean(const unsigned* __restrict__ dmin, int64_t m,
+                                                    double* __restrict__ out) {
+    __shared__ double sh[kBlock];
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < m; i += kBlock) acc += sqrt((double)__uint_as_float(dmin[i]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0] / (double)m;
 }
 
 struct TmpBuf {
@@ -201,6 +261,61 @@ int prg_rbf_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, c
                                    (float*)bo.p);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipMemcpyAsync(out_hd, bo.p, (size_t)m * n * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+int prg_inverse_multiquadric_kernel(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd,
+                                    int64_t n, int dim, double c, float* out_hd) {
+    PRG_REQUIRE(x_hd && y_hd && out_hd, PRG_ERR_INVALID, "prg_inverse_multiquadric_kernel: NULL argument");
+    PRG_REQUIRE(m > 0 && n > 0 && (dim == 2 || dim == 3) && c > 0, PRG_ERR_INVALID,
+                "prg_inverse_multiquadric_kernel: need m, n > 0, dim in {2,3}, c > 0");
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_inverse_multiquadric_kernel: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    TmpBuf bx, by, bo;
+    PRG_HIP(hipMalloc(&bx.p, (size_t)m * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&by.p, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bo.p, (size_t)m * n * sizeof(float)));
+    PRG_HIP(hipMemcpyAsync(bx.p, x_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(by.p, y_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+    dim3 grid((unsigned)prg::ceil_div(n, kBlock), (unsigned)prg::ceil_div(m, 16));
+    k_imq<<<grid, kBlock, 0, st>>>((const float*)bx.p, m, (const float*)by.p, n, dim, (float)c, (float*)bo.p);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_hd, bo.p, (size_t)m * n * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
+int prg_nn_mean_distance(int device, void* hip_stream, const float* a_hd, int64_t m, const float* b_hd, int64_t n,
+                         int dim, double* out_host) {
+    PRG_REQUIRE(a_hd && b_hd && out_host, PRG_ERR_INVALID, "prg_nn_mean_distance: NULL argument");
+    PRG_REQUIRE(m > 0 && n > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID,
+                "prg_nn_mean_distance: need m, n > 0 and dim in {2,3}");
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_nn_mean_distance: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    // enough (a block, b segment) workgroups to fill 256 CUs even for a few thousand points
+    const int64_t nbx = prg::ceil_div(m, kBlock);
+    int nseg = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / nbx), prg::ceil_div(n, 256));
+    const int seg_len = (int)prg::round_up(prg::ceil_div(n, nseg), 4);
+    const int64_t cap = (int64_t)seg_len * nseg;
+    TmpBuf ba, bb, b4, bd;
+    PRG_HIP(hipMalloc(&ba.p, (size_t)m * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&bb.p, (size_t)n * dim * sizeof(float)));
+    PRG_HIP(hipMalloc(&b4.p, (size_t)cap * sizeof(float4)));
+    PRG_HIP(hipMalloc(&bd.p, (size_t)m * sizeof(unsigned) + sizeof(double) * 2));
+    PRG_HIP(hipMemcpyAsync(ba.p, a_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bb.p, b_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+    double* res = reinterpret_cast<double*>((char*)bd.p + prg::round_up((int64_t)m * sizeof(unsigned), 8));
+    k_pack_weighted<<<(unsigned)prg::ceil_div(cap, kBlock), kBlock, 0, st>>>((const float*)bb.p, nullptr, n, dim, cap,
+                                                                            (float4*)b4.p);
+    k_nn_fill<<<(unsigned)nbx, kBlock, 0, st>>>((unsigned*)bd.p, m);
+    k_nn_min<<<dim3((unsigned)nbx, (unsigned)nseg), kBlock, 0, st>>>((const float*)ba.p, m, dim, (const float4*)b4.p,
+                                                                    seg_len, (unsigned*)bd.p);
+    k_nn_mean<<<1, kBlock, 0, st>>>((const unsigned*)bd.p, m, res);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_host, res, sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
     return PRG_OK;
 }

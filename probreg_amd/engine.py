@@ -189,6 +189,31 @@ class CpdPlan(object):
         check(lib.prg_cpd_nonrigid_apply(self._h, ptr(out)))
         return out
 
+    # -- Bayesian CPD --------------------------------------------------------------------------
+    def set_source_weights(self, log_weights, uniform_ratio=0.0):
+        """ln a_m <= 0 per source point (None clears); ``uniform_ratio`` > 0 replaces M/N in the outlier constant."""
+        if log_weights is None:
+            check(lib.prg_cpd_set_source_weights(self._h, None, float(uniform_ratio)))
+            return
+        a = np.ascontiguousarray(log_weights, dtype=np.float64)
+        assert a.shape == (self.m,)
+        check(lib.prg_cpd_set_source_weights(self._h, ptr(a), float(uniform_ratio)))
+
+    def bcpd_build_g(self, c=1.0):
+        check(lib.prg_cpd_bcpd_build_g(self._h, float(c)))
+
+    def bcpd_solve(self, lmd, cfac, resid, nu=None):
+        """(v_hat [m x dim], diag(Sigma) [m]) for ``nu`` (default: the p1 of the last E-step) - prg_cpd_bcpd_solve."""
+        r = np.ascontiguousarray(resid, dtype=np.float64)
+        assert r.shape == (self.m, self.dim)
+        v = np.empty((self.m, self.dim), dtype=np.float64)
+        d = np.empty(self.m, dtype=np.float64)
+        nu_a = None if nu is None else np.ascontiguousarray(nu, dtype=np.float64)
+        assert nu_a is None or nu_a.shape == (self.m,)
+        check(lib.prg_cpd_bcpd_solve(self._h, float(lmd), float(cfac), None if nu_a is None else ptr(nu_a), ptr(r),
+                                     ptr(v), ptr(d)))
+        return v, d
+
     def synchronize(self):
         # a host read-back of the parameter block synchronises the plan's stream
         self.get_params()

@@ -61,6 +61,19 @@ class AffineTransformation(Transformation):
         return np.dot(points, self.b.T) + self.t
 
 
+class CombinedTransformation(Transformation):
+    """x -> scale * rot @ (x + v) + t : non-rigid displacement first, similarity second (reference
+    transformation.py:105-121, the result type of BCPD).  ``v`` is one row per point (or 0)."""
+
+    def __init__(self, rot=np.identity(3), t=np.zeros(3), scale=1.0, v=0.0):
+        super(CombinedTransformation, self).__init__()
+        self.rigid_trans = RigidTransformation(rot, t, scale)
+        self.v = v
+
+    def _transform(self, points):
+        return self.rigid_trans._transform(points + self.v)
+
+
 class NonRigidTransformation(Transformation):
     """y_m -> y_m + (G W)_m on the control points it was built with (reference transformation.py:81-102).
 

@@ -256,7 +256,98 @@ def main_constrained():
     print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
 
 
+def bcpd_grid_pair(seed, nx=4, ny=4, nz=3, spacing=3.0, extra=10):
+    """Well-separated points (jittered grid, spacing 3): the float32 G^-1 of the reference (bcpd.py:108) is only
+    meaningful while the inverse-multiquadric kernel matrix is well conditioned."""
+    rng = np.random.default_rng(seed)
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), axis=-1).reshape(-1, 3)
+    src = g * spacing + rng.uniform(-0.6, 0.6, g.shape)
+    src -= src.mean(axis=0)
+    disp = 0.35 * np.sin(0.5 * src[:, [1, 2, 0]])
+    r = rot_z(12.0)
+    tgt = 1.05 * (src + disp) @ r.T + np.array([0.8, -0.5, 0.3]) + rng.normal(0.0, 0.05, src.shape)
+    lo, hi = tgt.min(axis=0), tgt.max(axis=0)
+    tgt = np.concatenate([tgt, rng.uniform(lo, hi, (extra, 3))], axis=0)
+    rng.shuffle(tgt, axis=0)
+    return src, tgt
+
+
+def main_bcpd():
+    """BCPD fixtures (bcpd.py): E-step on explicit inputs, one M-step, whole registrations."""
+    bc = ref_import.load_bcpd()
+    ref = ref_import.load(with_filterreg=False)
+    flat = {}
+    rng = np.random.default_rng(5)
+
+    # --- E-step (bcpd.py:53-72) ---------------------------------------------------------------------
+    def add_estep(name, t_source, target, scale, alpha, sigma_diag, sigma2, w):
+        reg = bc.CombinedBCPD(t_source.copy())
+        es = reg.expectation_step(t_source, target, scale, alpha, np.diag(sigma_diag), sigma2, w)
+        pre = "estep/%s/" % name
+        flat[pre + "t_source"], flat[pre + "target"] = t_source, target
+        flat[pre + "scale"], flat[pre + "alpha"] = np.asarray(scale), np.asarray(alpha)
+        flat[pre + "sigma_diag"], flat[pre + "sigma2"], flat[pre + "w"] = sigma_diag, np.asarray(sigma2), np.asarray(w)
+        flat[pre + "out_nu_d"], flat[pre + "out_nu"], flat[pre + "out_px"] = es.nu_d, es.nu, es.px
+        flat[pre + "out_x_hat"] = es.x_hat
+        print("bcpd estep %-22s n_p=%.6f" % (name, es.n_p))
+
+    s, t, _ = synthetic.rigid_pair(420, m=300, seed=21)
+    m = s.shape[0]
+    add_estep("uniform_alpha_w0", s, t, 1.0, 1.0 / m, np.ones(m), 0.05, 0.0)
+    al = rng.dirichlet(np.full(m, 2.0))
+    sd = rng.uniform(1e-4, 2e-2, m)
+    add_estep("alpha_vec_w0.1", s, t, 1.1, al, sd, 0.01, 0.1)
+    add_estep("small_sigma2_w0.3", s, t, 0.9, al, sd * 0.1, 4e-4, 0.3)
+    s2, t2 = s[:, :2].copy(), t[:, :2].copy()
+    add_estep("planar_w0.05", s2, t2, 1.0, al, sd, 0.02, 0.05)
+
+    # --- one M-step (bcpd.py:119-151) and registrations on well-conditioned G ---------------------------
+    def add_reg(name, src, tgt, **kw):
+        reg_kw = {k: kw.pop(k) for k in ("lmd", "k", "gamma") if k in kw}
+        reg = bc.CombinedBCPD(src.copy(), **reg_kw)
+        hist = []
+        reg.set_callbacks([lambda tr: hist.append(tr)])
+        trans = reg.registration(tgt.copy(), **kw)
+        pre = "reg/%s/" % name
+        flat[pre + "source"], flat[pre + "target"] = src, tgt
+        for k2, v in list(kw.items()) + list(reg_kw.items()):
+            flat[pre + "arg_" + k2] = np.asarray(v)
+        flat[pre + "out_rot"], flat[pre + "out_t"] = trans.rigid_trans.rot, trans.rigid_trans.t
+        flat[pre + "out_scale"], flat[pre + "out_v"] = np.asarray(trans.rigid_trans.scale), trans.v
+        flat[pre + "out_tsource"] = trans.transform(src)
+        flat[pre + "out_niter"] = np.asarray(len(hist))
+        flat[pre + "cond_g"] = np.asarray(np.linalg.cond(reg.gmat.astype(np.float64)))
+        print("bcpd reg   %-22s niter=%3d scale=%.8f cond(G)=%.1f" % (name, len(hist), trans.rigid_trans.scale,
+                                                                     flat[pre + "cond_g"]))
+
+    src, tgt = bcpd_grid_pair(31)
+    add_reg("grid48_default", src, tgt)
+    add_reg("grid48_w0.1_k5", src, tgt, w=0.1, maxiter=5, tol=-1.0)
+    add_reg("grid48_lmd20_k1", src, tgt, w=0.05, maxiter=8, tol=-1.0, lmd=20.0, k=1.0, gamma=0.5)
+    src, tgt = bcpd_grid_pair(32, nx=6, ny=5, nz=4, extra=25)
+    add_reg("grid120_w0.05_k6", src, tgt, w=0.05, maxiter=6, tol=-1.0)
+
+    reg = bc.CombinedBCPD(src.copy())
+    init = reg._initialize(tgt)
+    es = reg.expectation_step(src, tgt, 1.0, init.alpha, init.sigma_mat, init.sigma2, 0.05)
+    ms = reg.maximization_step(tgt, init.transformation.rigid_trans, es, init.sigma2)
+    pre = "mstep/grid120/"
+    flat[pre + "source"], flat[pre + "target"] = src, tgt
+    flat[pre + "nu_d"], flat[pre + "nu"], flat[pre + "px"], flat[pre + "x_hat"] = es.nu_d, es.nu, es.px, es.x_hat
+    flat[pre + "sigma2_p"] = np.asarray(init.sigma2)
+    flat[pre + "out_rot"], flat[pre + "out_t"] = ms.transformation.rigid_trans.rot, ms.transformation.rigid_trans.t
+    flat[pre + "out_scale"], flat[pre + "out_v"] = np.asarray(ms.transformation.rigid_trans.scale), ms.transformation.v
+    flat[pre + "out_sigma_diag"], flat[pre + "out_alpha"] = np.diag(ms.sigma_mat), ms.alpha
+    flat[pre + "out_sigma2"] = np.asarray(ms.sigma2)
+    out = os.path.join(HERE, "bcpd_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "bcpd":
+        main_bcpd()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "constrained":
         main_constrained()
         sys.exit(0)
