@@ -218,9 +218,18 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
     z4[i] = o;
     // non-negative floats order like their bit patterns: one atomicMax per wave into this E-step's slot; the other
     // slot (next E-step's) is cleared here - nobody touches it until the next launch of this kernel
+    // (one atomic per workgroup: ~1600 same-address atomics from every wave cost more than the rest of the kernel)
+    __shared__ float wave_moved[kBlock / 64];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) moved = fmaxf(moved, __shfl_xor(moved, off, 64));
-    if ((threadIdx.x & 63) == 0 && moved > 0.f) atomicMax(motion + slot, __float_as_uint(moved));
+    if ((threadIdx.x & 63) == 0) wave_moved[threadIdx.x >> 6] = moved;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float mv = wave_moved[0];
+#pragma unroll
+        for (int k = 1; k < kBlock / 64; ++k) mv = fmaxf(mv, wave_moved[k]);
+        if (mv > 0.f) atomicMax(motion + slot, __float_as_uint(mv));
+    }
     if (i == 0) motion[slot ^ 1] = 0u;
     block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta, smeta);
 }

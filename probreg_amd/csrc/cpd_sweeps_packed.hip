@@ -179,13 +179,15 @@ void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len) {
 // Culled sweeps.  Clouds are Morton-sorted at upload, so the 128 points a wave owns
 // and every group of 32 streamed points are spatially compact.  Per group one axis-aligned bounding box
 // (plus max b_n for the row pass) is fetched through SGPRs; if EVERY pair of the (wave, group) block is
-// provably an exact zero in fp32 - exp2 argument below -150 - the whole group is skipped.  Skipped terms are
-// exactly 0 (row pass) or below 2^-150 of a sum that is >= 1 (column pass), so the results are those of the
-// dense sweeps; what changes is that late EM iterations (small sigma) touch ~1 % of the pairs.
+// provably an exact zero - exp2 argument below -127 - the whole group is skipped.  v_exp_f32 (the sweeps call it
+// raw) flushes every result below 2^-126 to 0 (measured: tools/exp_denormal_probe.py, exp2(-126) already returns
+// 0), so the dense kernels produce exactly 0 for these pairs too; the extra unit absorbs the fp32 rounding of the
+// bound itself.  Skipped terms are exactly 0 (row pass) or below 2^-127 of a sum that is >= 1 (column pass), so
+// the results are those of the dense sweeps; what changes is that late EM iterations touch ~1 % of the pairs.
 // =============================================================================================
 namespace {
 
-constexpr float kCullLog2 = -150.0f;
+constexpr float kCullLog2 = -127.0f;
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -230,7 +232,7 @@ __device__ __forceinline__ float box_maxdist2(const float (&alo)[3], const float
 // Column pass with culling.  Lane owns the 2 adjacent columns n0 + 2*tid, +1.  `colmin_prev` (may be null) holds
 // min_m d^2 of every column from the previous E-step and `motion` the largest displacement any source point made
 // since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle inequality), which is
-// what makes a far group's contribution provably < 2^-150 of the final column sum.
+// what makes a far group's contribution provably < 2^-127 of the final column sum.
 __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
                                                          const GroupMeta* __restrict__ zmeta,
                                                          const GroupMeta* __restrict__ zsmeta, int seg_len,
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
         const float delta = __uint_as_float(*motion);
         const float r0 = sqrtf(colmin_prev[n0]) + delta, r1 = sqrtf(colmin_prev[n0 + 1]) + delta;
         const float seed = wave_max(fmaxf(r0 * r0, r1 * r1)) * 1.00001f;
-        thr = seed + kCullLog2 / kk;  // kk < 0: kk * (d2 - seed) < -150  <=>  d2 > seed + 150 / |kk|
+        thr = seed + kCullLog2 / kk;  // kk < 0: kk * (d2 - seed) < -127  <=>  d2 > seed + 127 / |kk|
     }
     const int64_t base = (int64_t)blockIdx.y * seg_len;
     const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + base);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
 }
 
 // Row pass with culling.  Lane owns the 2 adjacent rows m0 + 2*tid, +1; a group is skipped when
-// kk * dist2(boxes) + max_n b_n < -150, i.e. every P of the block is exactly 0 in fp32.
+// kk * dist2(boxes) + max_n b_n < -127, i.e. every P of the block comes out of v_exp_f32 as exactly 0.
 __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
                                                          const GroupMeta* __restrict__ tmeta,
                                                          const GroupMeta* __restrict__ tsmeta, int seg_len,
