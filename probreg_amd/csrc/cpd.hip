@@ -287,10 +287,11 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     if (i < n) {
     const double sigma2 = params[13];
     const float kkf = (float)(-kLog2e / (2.0 * sigma2));
-    const double kk = (double)kkf;
-    // online (min, sum) merge, 8 segment partials in flight per lane; the rescale factors are <= 1 and go through
-    // v_exp_f32 like the sweeps' own (their 1-ulp error is far below the fp32 sums they multiply), sums in fp64
-    float gmin = INFINITY;
+    // Online merge of the segment partials (dmin_s, sum_s), 8 in flight per lane.  sum_s is relative to the
+    // exponent offset off_s = col_offset(kk, dmin_s) the column pass used (reproduced bit for bit), i.e. the true
+    // segment sum is sum_s * 2^(-off_s).  The rescale factors are <= 1 and go through v_exp_f32 like the sweeps'
+    // own (their 1-ulp error is far below the fp32 sums they multiply); the running sum is fp64.
+    float gmin = INFINITY, goff = INFINITY;  // goff = smallest offset seen = offset of the column minimum
     double ssum = 0.0;
     for (int s0 = 0; s0 < nseg; s0 += 8) {
         float2 p[8];
@@ -301,14 +302,16 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
 #pragma unroll
         for (int k = 1; k < 8; ++k) cm = fminf(cm, p[k].x);
         if (cm < gmin) {
-            ssum *= (double)__builtin_amdgcn_exp2f(kkf * (gmin - cm));  // first chunk: 0 * exp2(-inf) = 0
+            const float noff = prg::col_offset(kkf, cm);
+            ssum *= (double)__builtin_amdgcn_exp2f(noff - goff);  // first chunk: 0 * exp2(-inf) = 0
             gmin = cm;
+            goff = noff;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k)  // culled segments are empty (sum 0, min = their seed bound)
-            if (p[k].y != 0.f) ssum += (double)(p[k].y * __builtin_amdgcn_exp2f(kkf * (p[k].x - gmin)));
+        for (int k = 0; k < 8; ++k)  // culled segments are empty (sum 0, min = inf or their seed bound)
+            if (p[k].y != 0.f) ssum += (double)(p[k].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, p[k].x)));
     }
-    const double den = ssum * exp2(kk * (double)gmin);  // underflows to 0 exactly where fp64 exp() does
+    const double den = ssum * exp2(-(double)goff);  // underflows to 0 exactly where fp64 exp() does
     double c = pow(2.0 * M_PI * sigma2, dim * 0.5);
     c *= w / (1.0 - w) * m_over_n;
     float p;

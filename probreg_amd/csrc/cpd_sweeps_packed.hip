@@ -19,6 +19,12 @@ constexpr int kBlock = prg::kSweepBlock;
 
 __device__ __forceinline__ f2 splat(float a) { return (f2){a, a}; }
 __device__ __forceinline__ f2 exp2v(f2 a) { return (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+// Exponent offset of the running column sums: s = sum exp2(kk d2 + off) with off = -kk * run (>= 0), so a term
+// costs one FMA + one exp; k_colfinal recomputes the offset bit for bit from the stored minimum
+// (prg::col_offset in cpd_sweeps.h).
+__device__ __forceinline__ f2 col_offset2(float kk, f2 run) {
+    return (f2){prg::col_offset(kk, run.x), prg::col_offset(kk, run.y)};
+}
 __device__ __forceinline__ f2 fmav(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 minv(f2 a, f2 b) { return __builtin_elementwise_min(a, b); }
 
@@ -31,7 +37,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
     constexpr int R = 2 * RP;
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const int64_t n0 = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
-    f2 x[RP], y[RP], z[RP], run[RP], s[RP];
+    f2 x[RP], y[RP], z[RP], run[RP], off[RP], s[RP];
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
         const float4 a = tgt4[n0 + (2 * p) * kBlock], b = tgt4[n0 + (2 * p + 1) * kBlock];
@@ -39,6 +45,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
         y[p] = (f2){a.y, b.y};
         z[p] = (f2){a.z, b.z};
         run[p] = splat(INFINITY);
+        off[p] = splat(INFINITY);
         s[p] = splat(0.f);
     }
     const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + (int64_t)blockIdx.y * seg_len);
@@ -77,15 +84,16 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
 #pragma unroll
             for (int p = 0; p < RP; ++p) {
                 const f2 nm = minv(run[p], cm[p]);
-                // first use: run == inf -> kk * inf = -inf -> exp2 = 0, and s == 0 anyway
-                s[p] *= exp2v(splat(kk) * (run[p] - nm));
+                const f2 noff = col_offset2(kk, nm);
+                s[p] *= exp2v(noff - off[p]);  // first use: off == +inf -> exp2(-inf) = 0, and s == 0 anyway
                 run[p] = nm;
+                off[p] = noff;
             }
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int p = 0; p < RP; ++p) s[p] += exp2v(splat(kk) * (d2[c][p] - run[p]));
+            for (int p = 0; p < RP; ++p) s[p] += exp2v(fmav(d2[c][p], splat(kk), off[p]));
     }
 #pragma unroll
     for (int p = 0; p < RP; ++p) {
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
     const int64_t n0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
     const float4 a = tgt4[n0], b = tgt4[n0 + 1];
     const f2 x = {a.x, b.x}, y = {a.y, b.y}, z = {a.z, b.z};
-    f2 run = splat(INFINITY), s = splat(0.f);
+    f2 run = splat(INFINITY), off = splat(INFINITY), s = splat(0.f);
     float lo[3], hi[3];
     lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
     lo[1] = wave_min(fminf(a.y, b.y)); hi[1] = wave_max(fmaxf(a.y, b.y));
@@ -296,11 +304,13 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
                 for (int c = 1; c < 8; ++c) cm = minv(cm, d2[c]);
                 if ((cm.x < run.x) | (cm.y < run.y)) {
                     const f2 nm = minv(run, cm);
-                    s *= exp2v(splat(kk) * (run - nm));
+                    const f2 noff = col_offset2(kk, nm);
+                    s *= exp2v(noff - off);
                     run = nm;
+                    off = noff;
                 }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) s += exp2v(splat(kk) * (d2[c] - run));
+                for (int c = 0; c < 8; ++c) s += exp2v(fmav(d2[c], splat(kk), off));
             }
         }
     }

@@ -22,12 +22,13 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
                                                     float2* __restrict__ colpart, int64_t ncap) {
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const int64_t n0 = (int64_t)blockIdx.x * (kBlock * R) + threadIdx.x;
-    float x[R], y[R], z[R], run[R], s[R];
+    float x[R], y[R], z[R], run[R], off[R], s[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const float4 v = tgt4[n0 + r * kBlock];
         x[r] = v.x; y[r] = v.y; z[r] = v.z;
         run[r] = INFINITY;
+        off[r] = INFINITY;
         s[r] = 0.f;
     }
     const float4* __restrict__ zp = z4 + (int64_t)blockIdx.y * seg_len;
@@ -59,15 +60,16 @@ __global__ __launch_bounds__(kBlock) void k_colpass(const float4* __restrict__ t
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const float nm = fminf(run[r], cm[r]);
-                // run == inf on first use: kk*(inf - nm) = -inf -> exp2 = 0 and s == 0 anyway
-                s[r] *= fast_exp2(kk * (run[r] - nm));
+                const float noff = prg::col_offset(kk, nm);
+                s[r] *= fast_exp2(noff - off[r]);  // off == +inf on first use: exp2(-inf) = 0 and s == 0 anyway
                 run[r] = nm;
+                off[r] = noff;
             }
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) s[r] += fast_exp2(kk * (d2[c][r] - run[r]));
+            for (int r = 0; r < R; ++r) s[r] += fast_exp2(fmaf(d2[c][r], kk, off[r]));
         }
     }
 #pragma unroll
