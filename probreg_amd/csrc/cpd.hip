@@ -19,6 +19,7 @@
 
 #include "cpd_plan.h"
 #include "cpd_sweeps.h"
+#include "morton.h"
 #include "small_linalg.h"
 
 #include <numeric>
@@ -697,40 +698,11 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
 // capacity: the cloud + room for 64 segments each rounded up to a 256-point super-group + prefetch slack
 int cap_for(int64_t n) { return (int)prg::round_up(n + 64 * prg::kSuper + 1024, 1024); }
 
-// Morton (Z-curve) order of a cloud: sorted position -> original index.  One-off host work at upload
-// (std::sort over n 64-bit keys: ~10 ms per 100k points).
-static inline uint64_t spread21(uint64_t v) {  // 21 bits -> every third bit
-    v &= 0x1fffff;
-    v = (v | v << 32) & 0x1f00000000ffffull;
-    v = (v | v << 16) & 0x1f0000ff0000ffull;
-    v = (v | v << 8) & 0x100f00f00f00f00full;
-    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-    v = (v | v << 2) & 0x1249249249249249ull;
-    return v;
-}
-
+// Morton (Z-curve) order of a cloud: sorted position -> original index (morton.h), uploaded as the plan's permutation.
 int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev) {
     std::vector<float> host((size_t)n * dim);
     PRG_HIP(hipMemcpy(host.data(), pts_hd, host.size() * sizeof(float), hipMemcpyDefault));
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int64_t i = 0; i < n; ++i)
-        for (int k = 0; k < dim; ++k) {
-            lo[k] = std::min(lo[k], host[i * dim + k]);
-            hi[k] = std::max(hi[k], host[i * dim + k]);
-        }
-    float ext = 0.f;
-    for (int k = 0; k < dim; ++k) ext = std::max(ext, hi[k] - lo[k]);
-    const double scale = ext > 0.f ? 2097151.0 / ext : 0.0;  // one isotropic 21-bit grid
-    std::vector<uint64_t> key((size_t)n);
-    for (int64_t i = 0; i < n; ++i) {
-        uint64_t code = 0;
-        for (int k = 0; k < dim; ++k)
-            code |= spread21((uint64_t)((host[i * dim + k] - lo[k]) * scale)) << k;
-        key[i] = code;
-    }
-    std::vector<int> perm((size_t)n);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    const std::vector<int> perm = prg::morton_order(host.data(), n, dim);
     if (*perm_dev) (void)hipFree(*perm_dev);
     *perm_dev = nullptr;
     PRG_HIP(hipMalloc((void**)perm_dev, (size_t)n * sizeof(int)));
@@ -812,6 +784,7 @@ int prg_cpd_destroy(prg_cpd* h) {
     free_plan_buffers(h);
     prg::nonrigid_free(h);
     if (h->state) (void)hipFree(h->state);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     delete h;
     return PRG_OK;
 }
@@ -1129,8 +1102,12 @@ int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {
 int prg_cpd_get_params(prg_cpd* h, double* params_host) {
     PRG_REQUIRE(h && params_host, PRG_ERR_INVALID, "prg_cpd_get_params: NULL argument");
     prg::DeviceGuard g(h->device);
-    PRG_HIP(hipMemcpyAsync(params_host, h->params, PRG_NPARAMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    // through pinned memory: a device->host copy into pageable memory pays ~100 us of staging, and the EM driver
+    // reads the parameter block every iteration when it has a tolerance to test
+    if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
+    PRG_HIP(hipMemcpyAsync(h->pinned, h->params, PRG_NPARAMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < PRG_NPARAMS; ++i) params_host[i] = h->pinned[i];
     return PRG_OK;
 }
 

@@ -75,6 +75,8 @@ struct prg_cpd {
     double uniform_ratio = 0.0;  // > 0: replaces M / N in the outlier constant of cpd.py:78-79
     bool bcpd = false;           // G is the inverse multiquadric kernel, W holds the displacement v_hat
 
+    double* pinned = nullptr;    // 64 doubles of pinned host memory for the per-iteration parameter read-back
+
     bool have_source = false, have_target = false, have_estep = false;
     double last_w = 0.0;
 };

@@ -14,6 +14,10 @@
 // (float32 round-off only).  Everything here is HBM-latency / atomic bound integer and scatter work.
 #include <math.h>
 
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "morton.h"
 #include "prg_common.h"
 #include "small_linalg.h"
 
@@ -61,7 +65,10 @@ struct Lattice {
     int* nb = nullptr;                  // [2][d+1][size] blur neighbours (dense id or -1)
     int* count = nullptr;               // device counters: [0] vertices, [1] table overflow flag
     int64_t cap_used = 0;               // slots of the table in use for the current build (power of two <= cap)
-    int prev_size = 0;
+    int prev_size[2] = {0, 0};          // last lattice size without / with blur: sizes the next hash table
+    double* pinned = nullptr;           // 64 doubles of pinned host memory: small device->host read-backs (a copy
+                                        // into pageable memory costs ~100 us of staging, this one a few us)
+    bool built = false;                 // false after a decision-only build that stopped early (lat_build)
     float* vals = nullptr;              // [2][(size+1)][C] ping-pong value buffers
     int64_t vals_elems = 0;
     int64_t n_alloc = 0, nb_alloc = 0;
@@ -71,11 +78,11 @@ struct Lattice {
 
 // ---- embedding (permutohedral.cpp:186-276, SSE build) -------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, int64_t n, float s0, float s1,
-                                                  float s2, unsigned long long* __restrict__ tkeys,
+__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, int64_t first, int64_t n, float s0,
+                                                  float s1, float s2, unsigned long long* __restrict__ tkeys,
                                                   unsigned long long mask, int* __restrict__ pslot,
                                                   float* __restrict__ bary, int* __restrict__ overflow) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // points [first, n)
     if (i >= n) return;
     constexpr int D1 = D + 1;
     const float scale[3] = {s0, s1, s2};
@@ -160,16 +167,54 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
     }
 }
 
+// Dense vertex ids for the occupied slots.  One atomic per workgroup (wave ballot + LDS prefix): a lattice of a few
+// hundred thousand vertices otherwise serialises that many same-address atomics (~5 ns each).
 __global__ __launch_bounds__(kBlock) void k_compact(const unsigned long long* __restrict__ tkeys, int64_t cap,
                                                     int* __restrict__ slot_id, unsigned long long* __restrict__ dkeys,
                                                     int* __restrict__ count) {
+    __shared__ int wave_cnt[kBlock / 64];
+    __shared__ int block_base;
     const int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (s >= cap) return;
-    const unsigned long long k = tkeys[s];
-    if (k == kEmpty) return;
-    const int id = atomicAdd(count, 1);
-    slot_id[s] = id;
-    dkeys[id] = k;
+    const unsigned long long k = s < cap ? tkeys[s] : kEmpty;
+    const bool occ = k != kEmpty;
+    const unsigned long long bal = __ballot(occ);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            const int c = wave_cnt[w];
+            wave_cnt[w] = tot;
+            tot += c;
+        }
+        block_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (occ) {
+        const int id = block_base + wave_cnt[wv] + before;
+        slot_id[s] = id;
+        dkeys[id] = k;
+    }
+}
+
+// Number of occupied slots only (the with_blur decision of filterreg.py:90-91 needs nothing else).
+__global__ __launch_bounds__(kBlock) void k_count_occupied(const unsigned long long* __restrict__ tkeys, int64_t cap,
+                                                           int* __restrict__ count) {
+    __shared__ int wave_cnt[kBlock / 64];
+    int c = 0;
+    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (int64_t)gridDim.x * kBlock)
+        c += tkeys[s] != kEmpty;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kBlock / 64; ++w) tot += wave_cnt[w];
+        if (tot) atomicAdd(count, tot);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int64_t total,
@@ -340,6 +385,8 @@ int lat_free(Lattice* L) {
     L->n_alloc = L->nb_alloc = L->vals_elems = 0;
     L->io_bytes = 0;
     L->cap = 0;
+    if (L->pinned) (void)hipHostFree(L->pinned);
+    L->pinned = nullptr;
     return PRG_OK;
 }
 
@@ -355,7 +402,11 @@ int lat_ensure_io(Lattice* L, size_t bytes) {
 
 // Build the lattice over L->feat (device, n x d float32).  Synchronises (the vertex count is needed on the host,
 // as in the reference where get_lattice_size() drives the with_blur decision, filterreg.py:90-91).
-int lat_build(Lattice* L, int64_t n, int d, int with_blur) {
+// decide_above >= 0: the caller only wants this lattice if it has at most `decide_above` vertices.  The points are
+// then embedded in two stages (1/16 of them first): the vertices of a subset are a subset of the vertices, so as
+// soon as the count exceeds the threshold the answer is known and the build stops (L->built = false, L->size = a
+// lower bound > decide_above) - no compaction, no neighbour tables, 15/16 of the hashing saved.
+int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above = -1) {
     PRG_REQUIRE(d >= 1 && d <= kMaxD, PRG_ERR_INVALID, "permutohedral lattice: feature dimension %d not in [1, 3]", d);
     const int d1 = d + 1;
     hipStream_t st = L->stream;
@@ -381,35 +432,67 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur) {
     const float inv_std = with_blur ? (float)(sqrt(2.0 / 3.0) * d1) : (float)(sqrt(1.0 / 6.0) * d1);
     float sc[3] = {0.f, 0.f, 0.f};
     for (int i = 0; i < d; ++i) sc[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std);
-    // The table is sized from the previous lattice (x32 head room, the lattice at most doubles per EM iteration)
-    // so that clearing and compacting it costs microseconds; an overflow falls back to the worst-case size.
+    // The table is sized from the previous lattice of the same kind (x8..16 head room: the lattice at most doubles
+    // per EM iteration) so that clearing and compacting it costs microseconds; an overflow falls back to the
+    // worst-case size.
+    const int mode = with_blur ? 1 : 0;
     int64_t capu = L->cap;
-    if (L->prev_size > 0) {
+    if (L->prev_size[mode] > 0) {
         capu = 65536;
-        while (capu < 32 * (int64_t)L->prev_size) capu <<= 1;
+        while (capu < 8 * (int64_t)L->prev_size[mode]) capu <<= 1;
         if (capu > L->cap) capu = L->cap;
     }
+    auto embed = [&](int64_t first, int64_t last, unsigned long long mask) {
+        const unsigned nb = (unsigned)prg::ceil_div(last - first, kBlock);
+        if (nb == 0) return;
+        if (d == 1) k_embed<1><<<nb, kBlock, 0, st>>>(L->feat, first, last, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+        else if (d == 2) k_embed<2><<<nb, kBlock, 0, st>>>(L->feat, first, last, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+        else k_embed<3><<<nb, kBlock, 0, st>>>(L->feat, first, last, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+    };
+    L->built = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         L->cap_used = capu;
         PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, capu * sizeof(unsigned long long), st));
         PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
         const unsigned long long mask = (unsigned long long)capu - 1;
-        const unsigned nb = (unsigned)prg::ceil_div(n, kBlock);
-        if (d == 1) k_embed<1><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
-        else if (d == 2) k_embed<2><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
-        else k_embed<3><<<nb, kBlock, 0, st>>>(L->feat, n, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
-        k_compact<<<(unsigned)prg::ceil_div(capu, kBlock), kBlock, 0, st>>>(L->tkeys, capu, L->slot_id, L->dkeys,
-                                                                           L->count);
-        PRG_HIP(hipGetLastError());
-        int host[2] = {0, 0};
-        PRG_HIP(hipMemcpyAsync(host, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-        PRG_HIP(hipStreamSynchronize(st));
+        if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
+        volatile int* host = reinterpret_cast<volatile int*>(L->pinned);
+        host[0] = host[1] = 0;
+        int64_t done = 0;
+        if (decide_above >= 0 && n >= 4096) {  // stage 1: a sixteenth of the points, count only
+            done = n / 16;
+            embed(0, done, mask);
+            k_count_occupied<<<(unsigned)std::min<int64_t>(prg::ceil_div(capu, kBlock), 2048), kBlock, 0, st>>>(L->tkeys, capu, L->count);
+            PRG_HIP(hipGetLastError());
+            PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            PRG_HIP(hipStreamSynchronize(st));
+            if (host[1] == 0 && host[0] > decide_above) {
+                L->size = host[0];
+                if (getenv("PRG_DEBUG_LATTICE"))
+                    fprintf(stderr, "[lattice] decision after %lld of %lld points: >= %d vertices > %lld (blur %d)\n",
+                            (long long)done, (long long)n, host[0], (long long)decide_above, with_blur);
+                return PRG_OK;  // prev_size[mode] keeps the last full count
+            }
+            PRG_HIP(hipMemsetAsync(L->count, 0, sizeof(int), st));  // the vertex counter restarts for the compaction
+        }
+        if (host[1] == 0) {
+            embed(done, n, mask);
+            k_compact<<<(unsigned)prg::ceil_div(capu, kBlock), kBlock, 0, st>>>(L->tkeys, capu, L->slot_id, L->dkeys,
+                                                                               L->count);
+            PRG_HIP(hipGetLastError());
+            PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            PRG_HIP(hipStreamSynchronize(st));
+        }
         L->size = host[0];
+        if (getenv("PRG_DEBUG_LATTICE"))
+            fprintf(stderr, "[lattice] attempt %d capu %lld prev %d size %d overflow %d blur %d\n", attempt, (long long)capu,
+                    L->prev_size[mode], L->size, host[1], with_blur);
         if (host[1] == 0 && (int64_t)L->size * 2 <= capu) break;
         PRG_REQUIRE(capu < L->cap, PRG_ERR_STATE, "permutohedral lattice: hash table overflow at full capacity");
         capu = L->cap;
     }
-    L->prev_size = L->size;
+    L->built = true;
+    L->prev_size[mode] = L->size;
     const unsigned long long mask = (unsigned long long)L->cap_used - 1;
     k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id);
     PRG_HIP(hipGetLastError());
@@ -492,6 +575,7 @@ struct prg_filterreg {
     double* state = nullptr; // [64]: 0..8 rot, 9..11 t, 12 sigma2, 13 q, 14 nonzero count, 15 sigma2_new
     double* part = nullptr;  // block partials
     int64_t part_blocks = 0;
+    std::vector<int> tgt_order;  // Morton order of the target (kernel position -> caller's index); see prg_fr_set_target
     bool have_src = false, have_tgt = false, have_estep = false;
 };
 
@@ -670,6 +754,21 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restri
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
+// sum over the block partials of component c for this thread's slice (8 slices of 32 components): four independent
+// accumulators keep four loads in flight - a single dependent chain of ~250 loads costs ~60 us on its own
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int nblk, int slice, int c) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = slice;
+    for (; b + 24 < nblk; b += 32) {
+        s0 += part[(int64_t)b * kFrComp + c];
+        s1 += part[(int64_t)(b + 8) * kFrComp + c];
+        s2 += part[(int64_t)(b + 16) * kFrComp + c];
+        s3 += part[(int64_t)(b + 24) * kFrComp + c];
+    }
+    for (; b < nblk; b += 8) s0 += part[(int64_t)b * kFrComp + c];
+    return (s0 + s1) + (s2 + s3);
+}
+
 // 6 x 6 SPD solve (the reference uses Eigen's LDLT on the upper triangle), twist -> Rodrigues rotation
 // (se3_op.py:21-56), composition with the previous transform, optional sigma2 update.  One workgroup.
 __global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __restrict__ part, int nblk,
@@ -678,9 +777,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __rest
     __shared__ double sh[8][32];
     __shared__ double mom[32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    double s = 0.0;
-    for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * kFrComp + c];
-    sh[slice][c] = s;
+    sh[slice][c] = sum_partials(part, nblk, slice, c);
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
@@ -840,10 +937,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__
     __shared__ double sh[8][32];
     __shared__ double mom[32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    double s = 0.0;
-    if (c < kFrComp)
-        for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * kFrComp + c];
-    sh[slice][c] = s;
+    sh[slice][c] = sum_partials(part, nblk, slice, c);
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
@@ -928,10 +1022,7 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_finish(const double* __restri
     __shared__ double sh[8][32];
     __shared__ double mom[32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
-    double s = 0.0;
-    if (c < kFrComp)
-        for (int b = slice; b < nblk; b += 8) s += part[(int64_t)b * kFrComp + c];
-    sh[slice][c] = s;
+    sh[slice][c] = sum_partials(part, nblk, slice, c);
     __syncthreads();
     if (threadIdx.x < 32) {
         double t = 0.0;
@@ -1097,7 +1188,15 @@ int prg_fr_set_target(prg_filterreg* h, const double* target_hd, int64_t n, int 
     if (h->tgt) (void)hipFree(h->tgt);
     h->tgt = nullptr;
     PRG_HIP(hipMalloc((void**)&h->tgt, (size_t)n * dim * sizeof(double)));
-    PRG_HIP(hipMemcpyAsync(h->tgt, target_hd, (size_t)n * dim * sizeof(double), hipMemcpyDefault, h->L.stream));
+    // The target is stored in Morton order: the splat works on 2048 consecutive target points per workgroup, and
+    // spatially close points share lattice vertices, so the workgroup-private LDS table absorbs most updates and
+    // the flush touches few global vertices.  Every E-step output is per SOURCE point, so no order leaks out.
+    std::vector<double> host((size_t)n * dim), sorted((size_t)n * dim);
+    PRG_HIP(hipMemcpy(host.data(), target_hd, host.size() * sizeof(double), hipMemcpyDefault));
+    h->tgt_order = prg::morton_order(host.data(), n, dim);
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < dim; ++k) sorted[(size_t)i * dim + k] = host[(size_t)h->tgt_order[i] * dim + k];
+    PRG_HIP(hipMemcpyAsync(h->tgt, sorted.data(), (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
     PRG_HIP(hipStreamSynchronize(h->L.stream));
     h->N = n;
     h->D = dim;
@@ -1133,8 +1232,11 @@ int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_bl
                                                                                   h->L.feat + h->M * h->D);
     PRG_HIP(hipGetLastError());
     int blur = 1;
-    PRG_TRY(lat_build(&h->L, tot, h->D, 1));
-    if ((double)h->L.size > (double)h->N * alpha) {  // filterreg.py:90-91
+    // filterreg.py:90-91: the blurred lattice is used only if it has at most N * alpha vertices
+    const double thr = (double)h->N * alpha;
+    const int64_t decide = thr >= 0.0 && thr < 2.0e9 ? (int64_t)floor(thr) : -1;
+    PRG_TRY(lat_build(&h->L, tot, h->D, 1, decide));
+    if (!h->L.built || (double)h->L.size > thr) {
         blur = 0;
         PRG_TRY(lat_build(&h->L, tot, h->D, 0));
     }
@@ -1171,8 +1273,10 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma
     k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, wfac, h->state, h->part);
     k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
-    PRG_HIP(hipMemcpyAsync(out_host, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!h->L.pinned) PRG_HIP(hipHostMalloc((void**)&h->L.pinned, 64 * sizeof(double), hipHostMallocDefault));
+    PRG_HIP(hipMemcpyAsync(h->L.pinned, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 18; ++i) out_host[i] = h->L.pinned[i];
     return PRG_OK;
 }
 
@@ -1186,7 +1290,11 @@ int prg_fr_set_target_normals(prg_filterreg* h, const double* normals_hd) {
     h->ch = 5;
     if (normals_hd) {
         PRG_HIP(hipMalloc((void**)&h->nrm, (size_t)h->N * 3 * sizeof(double)));
-        PRG_HIP(hipMemcpyAsync(h->nrm, normals_hd, (size_t)h->N * 3 * sizeof(double), hipMemcpyDefault, h->L.stream));
+        std::vector<double> host((size_t)h->N * 3), sorted((size_t)h->N * 3);  // same order as the stored target
+        PRG_HIP(hipMemcpy(host.data(), normals_hd, host.size() * sizeof(double), hipMemcpyDefault));
+        for (int64_t i = 0; i < h->N; ++i)
+            for (int k = 0; k < 3; ++k) sorted[(size_t)i * 3 + k] = host[(size_t)h->tgt_order[i] * 3 + k];
+        PRG_HIP(hipMemcpyAsync(h->nrm, sorted.data(), (size_t)h->N * 3 * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
         PRG_HIP(hipStreamSynchronize(h->L.stream));
         h->ch = 8;
     }
@@ -1215,8 +1323,10 @@ int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min
     k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, wfac, h->state, h->part);
     k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>(h->part, nblk, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
-    PRG_HIP(hipMemcpyAsync(out_host, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (!h->L.pinned) PRG_HIP(hipHostMalloc((void**)&h->L.pinned, 64 * sizeof(double), hipHostMallocDefault));
+    PRG_HIP(hipMemcpyAsync(h->L.pinned, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 18; ++i) out_host[i] = h->L.pinned[i];
     return PRG_OK;
 }
 
