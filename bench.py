@@ -274,7 +274,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": desc, "target_sharding": "contiguous rows over %d rank(s)" % world,
+            "config": {"workload": desc, "target_sharding": "contiguous runs of the target's Morton order over %d rank(s)" % world,
                        "collective": "1 all-reduce of 32 fp64 per iteration" if world > 1 else "none",
                        "m": m_pts, "n_local": n_loc, "n_global": n},
             "roofline": {

@@ -125,13 +125,13 @@ class CoherentPointDrift(abc.ABC):
             raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
         rank, world = pdist.world()
         cy, cx = self._centres(source, target)
-        lo, hi = pdist.shard_bounds(target.shape[0], rank, world)
+        rows = pdist.spatial_shard(target, rank, world)
         plan = self._plan if self._plan is not None else CpdPlan(self._device)
         self._plan = plan
         self._cy, self._cx = cy, cx
         if not getattr(self, "_source_uploaded", False):
             plan.set_source(source - cy)
-        plan.set_target(target[lo:hi] - cx, n_global=target.shape[0])
+        plan.set_target(target[rows] - cx, n_global=target.shape[0])
         mom = plan.moments_tensor() if pdist.initialized() else None
         plan.init_sums()
         if mom is not None:

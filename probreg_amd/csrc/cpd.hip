@@ -644,17 +644,18 @@ __global__ __launch_bounds__(kBlock) void k_unpack_points(const float4* __restri
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
-// choose the segment count so that the grid has a few thousand blocks and segments stay long
-// Segment count for the streamed axis: ~1.5k streamed points per workgroup, at least ~1k workgroups in the
-// grid (4 per CU) as long as segments keep >= 256 points, at most 64 segments.  C1 on one GPU -> 64 segments
-// (12.5k workgroups: best both in the dense and in the culled regime, tools/cull_floor.py); an 8-way target
-// shard (12.5k local columns) -> 8.
-int auto_segments(int64_t nblk_x, int64_t stream_len) {
-    int64_t s = stream_len / 1536;
-    if (s < 1) s = 1;
-    while (s * nblk_x < 1024 && stream_len / (s + 1) >= 256) ++s;
-    if (s > 64) s = 64;
-    return (int)s;
+// Segment count for the streamed axis.  The grid should hold ~12.5k workgroups (~50k waves: enough to hide the
+// scalar-load latency of the streams and, in the culled regime, short enough per-wave chains) whatever the size
+// of the lane-owned cloud: C1 on one GPU -> 64 x 196 workgroups (best both dense and culled, tools/cull_floor.py);
+// an 8-way target shard (12.5k local columns, 25 workgroups wide) -> ~200 short column-pass segments instead of 8
+// long ones, which is what keeps a shard's E-step near 1/8 of the single-GPU time (tools/shard_profile2.py).
+// Large clouds keep segments of >= 2048 streamed points (one ballot of group tests), at most 64 of them.
+int auto_segments(int64_t nblk_x, int64_t stream_len, int quantum, int cap) {
+    int64_t target = std::max<int64_t>(prg::ceil_div(12544, std::max<int64_t>(nblk_x, 1)),
+                                       std::min<int64_t>(stream_len / 2048, 64));
+    target = std::min<int64_t>(std::max<int64_t>(target, 1), cap);
+    const int64_t seg = prg::round_up(prg::ceil_div(stream_len, target), quantum);
+    return (int)prg::ceil_div(stream_len, seg);
 }
 
 int free_plan_buffers(prg_cpd* h) {
@@ -1006,13 +1007,14 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int ra = h->r_col ? h->r_col : 2, rb = h->r_row ? h->r_row : 2;
     const int RA = ra < 0 ? -ra : ra, RB = rb < 0 ? -rb : rb;
     const int64_t nblkA = prg::ceil_div(h->N, kBlock * RA), nblkB = prg::ceil_div(h->M, kBlock * RB);
-    int SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M);
-    int SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N);
     // Culled sweeps need both clouds Morton-sorted (compact waves / groups); they walk the stream in groups of 32.
     const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;  // (segment counts stay tunable)
-    // segment lengths are multiples of the loop trip (8 points, or one 32-point group); the pads absorb the
+    // segment lengths are multiples of the loop trip (8 points, or one 256-point super-group); the pads absorb the
     // overshoot and the prefetch over-read of the last segment
     const int quantum = use_cull ? prg::kSuper : 8;
+    // (row pass: at most 64 segments - the touched flags are one byte per (128-row block, segment) in rows of 64)
+    int SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M, quantum, 512);
+    int SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N, quantum, 64);
     auto seg_of = [quantum](int64_t len, int s) { return (int)prg::round_up(prg::ceil_div(len, s), quantum); };
     int segA = seg_of(h->M, SA), segB = seg_of(h->N, SB);
     while (SA > 1 && (int64_t)SA * segA + prg::kOverRead > h->Mcap) --SA, segA = seg_of(h->M, SA);

@@ -209,7 +209,6 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; };
-struct alignas(32) Meta4 { GroupMeta m[4]; };
 
 // squared distance between two axis-aligned boxes (0 if they overlap)
 __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&ahi)[3], const GroupMeta& g) {
@@ -222,28 +221,19 @@ __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&
     return d2;
 }
 
-// largest squared distance between any two points of two boxes
-__device__ __forceinline__ float box_maxdist2(const float (&alo)[3], const float (&ahi)[3], const GroupMeta& g) {
-    float d2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float far = fmaxf(ahi[k] - g.lo[k], g.hi[k] - alo[k]);
-        d2 = fmaf(far, far, d2);
-    }
-    return d2;
-}
-
-// Two-level metadata: `smeta` holds one box per super-group of 256 streamed points (lo, hi, max aux, min aux),
-// `gmeta` one per group of 32.  A wave first tests the super-group (one scalar load, prefetched one trip ahead);
-// only if it cannot be skipped as a whole AND is not provably needed as a whole are the 8 group boxes consulted.
+// Which groups does a wave need?  Every lane tests ONE group of the segment against the wave's box (a 32-byte
+// vector load of the group's metadata, a few VALU ops) and a ballot turns the 64 verdicts into a bit mask - one
+// memory round trip for up to 2048 streamed points, where a scalar walk over super-group and group boxes paid a
+// dependent scalar load per box (late EM iterations were bound by exactly that latency chain).  The mask also
+// tells the wave which group comes NEXT, so the first quad of the next needed group is fetched while the current
+// one is still being evaluated.
 
 // Column pass with culling.  Lane owns the 2 adjacent columns n0 + 2*tid, +1.  `colmin_prev` (may be null) holds
 // min_m d^2 of every column from the previous E-step and `motion` the largest displacement any source point made
 // since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle inequality), which is
 // what makes a far group's contribution provably < 2^-127 of the final column sum.
 __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
-                                                         const GroupMeta* __restrict__ zmeta,
-                                                         const GroupMeta* __restrict__ zsmeta, int seg_len,
+                                                         const GroupMeta* __restrict__ zmeta, int seg_len,
                                                          const double* __restrict__ params,
                                                          const float* __restrict__ colmin_prev,
                                                          const unsigned* __restrict__ motion,
@@ -264,26 +254,24 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
         const float seed = wave_max(fmaxf(r0 * r0, r1 * r1)) * 1.00001f;
         thr = seed + kCullLog2 / kk;  // kk < 0: kk * (d2 - seed) < -127  <=>  d2 > seed + 127 / |kk|
     }
+    const int lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.y * seg_len;
     const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + base);
     const GroupMeta* __restrict__ gp = zmeta + base / prg::kGroup;
-    const GroupMeta* __restrict__ sp = zsmeta + base / prg::kSuper;
-    const int nsuper = seg_len / prg::kSuper;
-    GroupMeta sm = sp[0];
-    for (int sg = 0; sg < nsuper; ++sg) {
-        const GroupMeta cur = sm;
-        sm = sp[sg + 1];  // prefetch (the array has one spare entry)
-        if (__builtin_amdgcn_readfirstlane((int)(box_dist2(lo, hi, cur) > thr))) continue;
-        const bool all = box_maxdist2(lo, hi, cur) <= thr;  // no group of this super-group can be skipped
-#pragma unroll 1
-        for (int g8 = 0; g8 < 8; ++g8) {
-            const int g = sg * 8 + g8;
-            if (!__builtin_amdgcn_readfirstlane((int)all)) {
-                const GroupMeta gm = gp[g];
-                if (__builtin_amdgcn_readfirstlane((int)(box_dist2(lo, hi, gm) > thr))) continue;
-            }
-            const Quad* __restrict__ q = zp + g * 8;
-            Quad qa = q[0];
+    const int ngroups = seg_len / prg::kGroup;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        bool need = false;
+        if (g0 + lane < ngroups) need = !(box_dist2(lo, hi, gp[g0 + lane]) > thr);
+        unsigned long long mask = __ballot(need);
+        if (mask == 0) continue;
+        int g = g0 + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        Quad qa = zp[(int64_t)g * 8];
+        for (;;) {
+            const int gnext = mask ? g0 + __builtin_ctzll(mask) : -1;
+            mask &= mask - 1;  // (0 stays 0)
+            const Quad* __restrict__ q = zp + (int64_t)g * 8;
+            const Quad* __restrict__ qn = zp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const Quad qb = q[2 * t + 1];
@@ -293,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
                     const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
                     d2[c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qa.q[c].w))));
                 }
-                if (t < 3) qa = q[2 * t + 2];
+                qa = (t < 3) ? q[2 * t + 2] : qn[0];  // last trip: first quad of the next needed group
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
@@ -312,6 +300,8 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
 #pragma unroll
                 for (int c = 0; c < 8; ++c) s += exp2v(fmav(d2[c], splat(kk), off));
             }
+            if (gnext < 0) break;
+            g = gnext;
         }
     }
     float4* out = reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.y * ncap + n0);
@@ -321,8 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
 // Row pass with culling.  Lane owns the 2 adjacent rows m0 + 2*tid, +1; a group is skipped when
 // kk * dist2(boxes) + max_n b_n < -127, i.e. every P of the block comes out of v_exp_f32 as exactly 0.
 __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
-                                                         const GroupMeta* __restrict__ tmeta,
-                                                         const GroupMeta* __restrict__ tsmeta, int seg_len,
+                                                         const GroupMeta* __restrict__ tmeta, int seg_len,
                                                          const double* __restrict__ params,
                                                          float* __restrict__ rowpart, int64_t mcap,
                                                          unsigned char* __restrict__ rowflag) {
@@ -336,36 +325,31 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
     lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
     lo[1] = wave_min(fminf(a.y, b.y)); hi[1] = wave_max(fmaxf(a.y, b.y));
     lo[2] = wave_min(fminf(a.z, b.z)); hi[2] = wave_max(fmaxf(a.z, b.z));
+    const int lane = threadIdx.x & 63;
     const int64_t base = (int64_t)blockIdx.y * seg_len;
     const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + base);
     const GroupMeta* __restrict__ gp = tmeta + base / prg::kGroup;
-    const GroupMeta* __restrict__ sp = tsmeta + base / prg::kSuper;
-    const int nsuper = seg_len / prg::kSuper;
-    // super-group boxes are fetched four at a time (128 B, two s_load_dwordx16): a wave that skips everything
-    // is bound by the latency of these dependent scalar loads, so fewer, wider fetches matter
-    for (int sg4 = 0; sg4 < nsuper; sg4 += 4) {
-      const Meta4 m4 = *reinterpret_cast<const Meta4*>(sp + sg4);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        const int sg = sg4 + s4;
-        if (sg >= nsuper) break;
-        const GroupMeta cur = m4.m[s4];
-        // cur.aux = max b_n, cur.pad = min b_n over the 256 points
-        if (__builtin_amdgcn_readfirstlane((int)(fmaf(box_dist2(lo, hi, cur), kk, cur.aux) < kCullLog2))) continue;
-        const bool all = fmaf(box_maxdist2(lo, hi, cur), kk, cur.pad) > kCullLog2;  // every P is non-zero
-#pragma unroll 1
-        for (int g8 = 0; g8 < 8; ++g8) {
-            const int g = sg * 8 + g8;
-            if (!__builtin_amdgcn_readfirstlane((int)all)) {
-                const GroupMeta gm = gp[g];
-                if (__builtin_amdgcn_readfirstlane((int)(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2))) continue;
-            }
-            touched = true;
-            const Quad* __restrict__ q = tp + g * 8;
-            Quad cq = q[0];
+    const int ngroups = seg_len / prg::kGroup;
+    for (int g0 = 0; g0 < ngroups; g0 += 64) {
+        bool need = false;
+        if (g0 + lane < ngroups) {
+            const GroupMeta gm = gp[g0 + lane];  // gm.aux = max b_n over the 32 points
+            need = !(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2);
+        }
+        unsigned long long mask = __ballot(need);
+        if (mask == 0) continue;
+        touched = true;
+        int g = g0 + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        Quad cq = tp[(int64_t)g * 8];
+        for (;;) {
+            const int gnext = mask ? g0 + __builtin_ctzll(mask) : -1;
+            mask &= mask - 1;
+            const Quad* __restrict__ q = tp + (int64_t)g * 8;
+            const Quad* __restrict__ qn = tp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const Quad nq = q[t < 7 ? t + 1 : t];  // prefetch the next quad of this group
+                const Quad nq = (t < 7) ? q[t + 1] : qn[0];  // prefetch: next quad, or the next needed group's first
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f2 dx = zx - splat(cq.q[c].x), dy = zy - splat(cq.q[c].y), dz = zz - splat(cq.q[c].z);
@@ -379,11 +363,12 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
                 }
                 cq = nq;
             }
+            if (gnext < 0) break;
+            g = gnext;
         }
-      }
     }
     // k_row_moments skips the partials of untouched (wave, segment) blocks: they are neither written nor read
-    if ((threadIdx.x & 63) == 0)
+    if (lane == 0)
         rowflag[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + blockIdx.y] = touched ? 1 : 0;  // [wave block][segment]
     if (!touched) return;
     float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
@@ -400,15 +385,15 @@ namespace prg {
 
 void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
     dim3 grid((unsigned)ceil_div(h->N, kBlock * 2), (unsigned)S);
-    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
-                                                   reinterpret_cast<const GroupMeta*>(h->zsmeta), seg_len, h->params,
+    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta), seg_len,
+                                                   h->params,
                                                    use_seed ? h->colmin : nullptr, h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap);
 }
 
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->M, kBlock * 2), (unsigned)S);
-    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta),
-                                                   reinterpret_cast<const GroupMeta*>(h->tsmeta), seg_len, h->params,
+    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len,
+                                                   h->params,
                                                    h->rowpart, h->Mcap,
                                                    reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)S * 5 * h->Mcap));
 }

@@ -1,7 +1,8 @@
 """Target sharding across the GPUs of one node (one process per GPU, torch.distributed / RCCL).
 
 The reference is single-process; this is the new data-parallel layer of SURVEY.md section 8(e):
-every rank keeps the whole source cloud, owns a contiguous block of target rows and all-reduces
+every rank keeps the whole source cloud, owns a spatially compact block of target rows (a contiguous
+run of the target's Morton order) and all-reduces
 the 32-double moment block once per EM iteration (rigid / affine), or the per-point fp64 block
 (non-rigid).  With the ``gloo`` backend the same helpers work on CPU tensors (used by the tests).
 """
@@ -38,6 +39,46 @@ def shard_bounds(n, rank, world_size):
     lo = rank * base + min(rank, rem)
     hi = lo + base + (1 if rank < rem else 0)
     return lo, hi
+
+
+def _spread21(v):
+    """21 bits -> every third bit (numpy uint64), the interleave of a 3-D Morton code."""
+    v = v & np.uint64(0x1FFFFF)
+    v = (v | (v << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+    v = (v | (v << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+    v = (v | (v << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+    v = (v | (v << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+    v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+    return v
+
+
+def morton_order(points):
+    """Indices that sort ``points`` (n, 2|3) along the Z-curve of one isotropic 21-bit grid (deterministic)."""
+    p = np.asarray(points, dtype=np.float64)
+    lo = p.min(axis=0)
+    ext = float((p.max(axis=0) - lo).max())
+    scale = 2097151.0 / ext if ext > 0.0 else 0.0
+    q = ((p - lo) * scale).astype(np.uint64)
+    code = np.zeros(p.shape[0], dtype=np.uint64)
+    for k in range(p.shape[1]):
+        code |= _spread21(q[:, k]) << np.uint64(k)
+    return np.argsort(code, kind="stable")
+
+
+def spatial_shard(target, rank, world_size):
+    """Row indices of ``target`` owned by ``rank``: a contiguous run of the cloud's Morton order.
+
+    Every rank holds the whole target (the reference API passes full arrays), so all ranks derive the same order
+    and take their slice of it.  A shard is then a spatially compact patch: the culled sweeps of a rank skip
+    everything far from its patch, exactly as a single GPU does for one wave's points - a shard in the caller's
+    order would be spread over the whole object and lose most of the culling in late EM iterations.  With one
+    rank the order is left alone (the plan sorts on upload anyway).
+    """
+    n = np.asarray(target).shape[0]
+    lo, hi = shard_bounds(n, rank, world_size)
+    if world_size == 1:
+        return np.arange(lo, hi)
+    return morton_order(target)[lo:hi]
 
 
 def all_reduce_sum_(tensor):

@@ -81,3 +81,24 @@ def test_synthetic_generators_are_seeded():
     assert a.shape == (100, 3) and np.array_equal(a, a.astype(np.float32).astype(np.float64))
     s, t, _ = synthetic.filterreg_pair(1000, seed=1)
     assert t.shape == (1000, 3)
+
+
+def test_spatial_shards_partition_the_target_into_compact_patches():
+    """Every rank derives the same Morton order: the shards are a partition, near-equal in size, and each one is
+    spatially compact (its bounding box is a fraction of the cloud's) - what keeps the culled sweeps effective."""
+    from probreg_amd import synthetic
+
+    _, tgt, _ = synthetic.rigid_pair(4001, m=10, seed=3)
+    world = 8
+    shards = [dist.spatial_shard(tgt, r, world) for r in range(world)]
+    allrows = np.sort(np.concatenate(shards))
+    assert np.array_equal(allrows, np.arange(tgt.shape[0]))
+    assert max(len(s) for s in shards) - min(len(s) for s in shards) <= 1
+    whole = np.prod(tgt.max(axis=0) - tgt.min(axis=0))
+    vols = [np.prod(tgt[s].max(axis=0) - tgt[s].min(axis=0)) for s in shards]
+    assert np.median(vols) < 0.3 * whole
+    # one rank: the caller's order is kept (the plan sorts on upload)
+    assert np.array_equal(dist.spatial_shard(tgt, 0, 1), np.arange(tgt.shape[0]))
+    # the order is a pure function of the coordinates
+    assert np.array_equal(dist.morton_order(tgt), dist.morton_order(tgt.copy()))
+    assert np.array_equal(dist.morton_order(tgt[:, :2]), dist.morton_order(tgt[:, :2].copy()))
