@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libprobreg_hip.so")
+# PROBREG_HIP_LIB: an alternative build of the same library (instrumented / experimental), for tools only
+LIB_PATH = os.environ.get("PROBREG_HIP_LIB") or os.path.join(_HERE, "csrc", "libprobreg_hip.so")
 
 PRG_OK = 0
 PRG_ERR_INVALID = -1

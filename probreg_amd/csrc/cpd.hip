@@ -281,10 +281,11 @@ __global__ __launch_bounds__(kBlock) void k_super_meta(const float* __restrict__
 __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, const float2* __restrict__ colpart,
                                                      int nseg, int64_t ncap, int64_t n, float* __restrict__ pt1,
                                                      const double* __restrict__ params, double w, double m_over_n,
-                                                     int dim, float* __restrict__ colmin, float* __restrict__ gmeta,
-                                                     float* __restrict__ smeta) {
+                                                     int dim, float* __restrict__ colmin, float* __restrict__ colmin_g,
+                                                     float* __restrict__ gmeta, float* __restrict__ smeta) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     float b = 0.f;  // pads keep b = 0
+    float cmin = 0.f;  // pads do not widen the seed
     if (i < n) {
     const double sigma2 = params[13];
     const float kkf = (float)(-kLog2e / (2.0 * sigma2));
@@ -327,6 +328,12 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     reinterpret_cast<float*>(tgt4 + i)[3] = b;
     pt1[i] = p;
     colmin[i] = gmin;  // min_m |x_n - z_m|^2 of this E-step: seed of the next column pass' cull bound
+    cmin = gmin;
+    }
+    // per group of 32 columns: the largest of these minima - what a wave of the next column pass needs for its seed
+    {
+        const float gm = half_max(cmin);
+        if ((threadIdx.x & 31) == 0) colmin_g[(int64_t)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5)] = gm;
     }
     // refresh the b_n range of this workgroup's 8 groups / 1 super-group (their boxes are static)
     if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta, smeta);
@@ -898,8 +905,8 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
         PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
         PRG_TRY(ensure_exact(&h->tsmeta, (size_t)(cap / prg::kSuper + 4) * 8));
         PRG_HIP(hipMemsetAsync(h->tsmeta, 0, (size_t)(cap / prg::kSuper + 4) * 8 * sizeof(float), h->stream));
-        PRG_TRY(ensure_exact(&h->colmin, (size_t)cap));
-        PRG_HIP(hipMemsetAsync(h->colmin, 0, (size_t)cap * sizeof(float), h->stream));
+        PRG_TRY(ensure_exact(&h->colmin, (size_t)cap + (size_t)cap / prg::kGroup));  // + per-group maxima
+        PRG_HIP(hipMemsetAsync(h->colmin, 0, ((size_t)cap + (size_t)cap / prg::kGroup) * sizeof(float), h->stream));
     }
     h->N = n_local;
     h->Nglobal = n_global;
@@ -1012,17 +1019,37 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // segment lengths are multiples of the loop trip (8 points, or one 256-point super-group); the pads absorb the
     // overshoot and the prefetch over-read of the last segment
     const int quantum = use_cull ? prg::kSuper : 8;
-    // (row pass: at most 64 segments - the touched flags are one byte per (128-row block, segment) in rows of 64)
-    int SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M, quantum, 512);
-    int SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N, quantum, 64);
+    int SA, SB;
+    if (use_cull) {
+        // Culled sweeps: a workgroup = 128 lane points x 4 consecutive segments (one per wave, merged in LDS), so
+        // S segments cost S/4 partial planes.  Segments of 512 streamed points keep a wave's chain of dependent
+        // scalar loads short - the bound of a sparse E-step (tools/wave_trace.py) - and 256 segments (64 planes,
+        // the width of the row pass' touched-flag rows) are the cap; small problems get 256-point segments.
+        auto cull_segments = [](int64_t lane_points, int64_t stream_len) {
+            int64_t s = std::min<int64_t>(prg::ceil_div(stream_len, 512), 256);
+            if (s * prg::ceil_div(lane_points, 128) < 16384) s = std::min<int64_t>(std::max<int64_t>(stream_len / 256, 1), 256);
+            return (int)std::max<int64_t>(s, 1);
+        };
+        SA = h->seg_col ? h->seg_col : cull_segments(h->N, h->M);
+        SB = h->seg_row ? h->seg_row : cull_segments(h->M, h->N);
+    } else {
+        SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M, quantum, 256);
+        SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N, quantum, 64);
+    }
+    // equal segments of a whole number of quanta: seg = round_up(len / S), S = ceil(len / seg)
     auto seg_of = [quantum](int64_t len, int s) { return (int)prg::round_up(prg::ceil_div(len, s), quantum); };
     int segA = seg_of(h->M, SA), segB = seg_of(h->N, SB);
+    SA = (int)prg::ceil_div(h->M, segA);
+    SB = (int)prg::ceil_div(h->N, segB);
     while (SA > 1 && (int64_t)SA * segA + prg::kOverRead > h->Mcap) --SA, segA = seg_of(h->M, SA);
     while (SB > 1 && (int64_t)SB * segB + prg::kOverRead > h->Ncap) --SB, segB = seg_of(h->N, SB);
     PRG_REQUIRE((int64_t)SA * segA + prg::kOverRead <= h->Mcap && (int64_t)SB * segB + prg::kOverRead <= h->Ncap,
                 PRG_ERR_STATE, "prg_cpd_estep: internal segmenting failure");
-    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)SA * h->Ncap));
-    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)SB * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
+    // partial planes in HBM: one per segment, or one per four segments for the culled sweeps
+    const int PA = use_cull ? (int)prg::ceil_div(SA, 4) : SA, PB = use_cull ? (int)prg::ceil_div(SB, 4) : SB;
+    PRG_REQUIRE(!use_cull || PB <= 64, PRG_ERR_INVALID, "prg_cpd_estep: at most 256 row-pass segments with culling");
+    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)PA * h->Ncap));
+    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)PB * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
 
     if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
@@ -1042,8 +1069,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     else
         prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
-    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, SA, h->Ncap, h->N, h->pt1, h->params, w,
+    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, PA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
+                                                      h->colmin + h->Ncap,
                                                       use_cull ? h->tmeta : nullptr, h->tsmeta);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (use_cull)
@@ -1054,9 +1082,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         prg::launch_rowpass_packed(h, RB, SB, segB);
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
     const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
-    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, SB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
+    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, PB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart,
-                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)SB * 5 * h->Mcap)
+                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)PB * 5 * h->Mcap)
                                                            : nullptr);
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));

@@ -197,16 +197,29 @@ namespace {
 
 constexpr float kCullLog2 = -127.0f;
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+#ifdef PRG_WAVE_TRACE
+// Instrumented build (tools/wave_trace.py): every wave of the culled sweeps records its start / end shader clock,
+// the hardware id it ran on and how many groups it evaluated: trace[(kernel * max_waves + wave) * 4 + {0..3}].
+__device__ unsigned long long* g_wave_trace = nullptr;
+__device__ unsigned long long g_wave_trace_cap = 0;
+#define PRG_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_readcyclecounter(); unsigned trace_groups = 0
+#define PRG_TRACE_GROUP() ++trace_groups
+#define PRG_TRACE_END(kernel_id)                                                                                  \
+    if (g_wave_trace && (threadIdx.x & 63) == 0) {                                                                \
+        const unsigned long long w = ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6); \
+        if (w < g_wave_trace_cap) {                                                                               \
+            unsigned long long* o = g_wave_trace + ((unsigned long long)(kernel_id) * g_wave_trace_cap + w) * 4;  \
+            o[0] = trace_t0;                                                                                      \
+            o[1] = __builtin_readcyclecounter();                                                                  \
+            o[2] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4 /* HW_REG_HW_ID, 32 bits */);              \
+            o[3] = trace_groups;                                                                                  \
+        }                                                                                                         \
+    }
+#else
+#define PRG_TRACE_BEGIN()
+#define PRG_TRACE_GROUP()
+#define PRG_TRACE_END(kernel_id)
+#endif
 
 struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; };
 
@@ -221,181 +234,295 @@ __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&
     return d2;
 }
 
-// Which groups does a wave need?  Every lane tests ONE group of the segment against the wave's box (a 32-byte
-// vector load of the group's metadata, a few VALU ops) and a ballot turns the 64 verdicts into a bit mask - one
-// memory round trip for up to 2048 streamed points, where a scalar walk over super-group and group boxes paid a
-// dependent scalar load per box (late EM iterations were bound by exactly that latency chain).  The mask also
-// tells the wave which group comes NEXT, so the first quad of the next needed group is fetched while the current
-// one is still being evaluated.
-
-// Column pass with culling.  Lane owns the 2 adjacent columns n0 + 2*tid, +1.  `colmin_prev` (may be null) holds
-// min_m d^2 of every column from the previous E-step and `motion` the largest displacement any source point made
-// since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle inequality), which is
-// what makes a far group's contribution provably < 2^-127 of the final column sum.
-__global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
-                                                         const GroupMeta* __restrict__ zmeta, int seg_len,
-                                                         const double* __restrict__ params,
-                                                         const float* __restrict__ colmin_prev,
-                                                         const unsigned* __restrict__ motion,
-                                                         float2* __restrict__ colpart, int64_t ncap) {
-    const float kk = (float)(-kLog2e / (2.0 * params[13]));
-    const int64_t n0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
-    const float4 a = tgt4[n0], b = tgt4[n0 + 1];
-    const f2 x = {a.x, b.x}, y = {a.y, b.y}, z = {a.z, b.z};
-    f2 run = splat(INFINITY), off = splat(INFINITY), s = splat(0.f);
-    float lo[3], hi[3];
-    lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
-    lo[1] = wave_min(fminf(a.y, b.y)); hi[1] = wave_max(fmaxf(a.y, b.y));
-    lo[2] = wave_min(fminf(a.z, b.z)); hi[2] = wave_max(fmaxf(a.z, b.z));
-    float thr = INFINITY;  // skip a group when its box is farther than thr (squared) from the wave's box
-    if (colmin_prev) {
-        const float delta = __uint_as_float(*motion);
-        const float r0 = sqrtf(colmin_prev[n0]) + delta, r1 = sqrtf(colmin_prev[n0 + 1]) + delta;
-        const float seed = wave_max(fmaxf(r0 * r0, r1 * r1)) * 1.00001f;
-        thr = seed + kCullLog2 / kk;  // kk < 0: kk * (d2 - seed) < -127  <=>  d2 > seed + 127 / |kk|
+// Bounding box of the 128 points a wave owns = union of the boxes of its four 32-point groups, which the metadata
+// arrays already hold: scalar loads instead of two vector loads and 36 dependent cross-lane reduction steps - a
+// wave that finds nothing to do (most waves, in late EM iterations) is gone after one round trip.
+__device__ __forceinline__ void wave_box(const GroupMeta* __restrict__ own, float (&lo)[3], float (&hi)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(own[0].lo[k], own[1].lo[k]), fminf(own[2].lo[k], own[3].lo[k]));
+        hi[k] = fmaxf(fmaxf(own[0].hi[k], own[1].hi[k]), fmaxf(own[2].hi[k], own[3].hi[k]));
     }
-    const int lane = threadIdx.x & 63;
-    const int64_t base = (int64_t)blockIdx.y * seg_len;
-    const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + base);
-    const GroupMeta* __restrict__ gp = zmeta + base / prg::kGroup;
-    const int ngroups = seg_len / prg::kGroup;
-    for (int g0 = 0; g0 < ngroups; g0 += 64) {
-        bool need = false;
-        if (g0 + lane < ngroups) need = !(box_dist2(lo, hi, gp[g0 + lane]) > thr);
-        unsigned long long mask = __ballot(need);
-        if (mask == 0) continue;
-        int g = g0 + __builtin_ctzll(mask);
-        mask &= mask - 1;
-        Quad qa = zp[(int64_t)g * 8];
-        for (;;) {
-            const int gnext = mask ? g0 + __builtin_ctzll(mask) : -1;
-            mask &= mask - 1;  // (0 stays 0)
-            const Quad* __restrict__ q = zp + (int64_t)g * 8;
-            const Quad* __restrict__ qn = zp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const Quad qb = q[2 * t + 1];
-                f2 d2[8];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
-                    d2[c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qa.q[c].w))));
-                }
-                qa = (t < 3) ? q[2 * t + 2] : qn[0];  // last trip: first quad of the next needed group
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
-                    d2[4 + c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qb.q[c].w))));
-                }
-                f2 cm = d2[0];
-#pragma unroll
-                for (int c = 1; c < 8; ++c) cm = minv(cm, d2[c]);
-                if ((cm.x < run.x) | (cm.y < run.y)) {
-                    const f2 nm = minv(run, cm);
-                    const f2 noff = col_offset2(kk, nm);
-                    s *= exp2v(noff - off);
-                    run = nm;
-                    off = noff;
-                }
-#pragma unroll
-                for (int c = 0; c < 8; ++c) s += exp2v(fmav(d2[c], splat(kk), off));
-            }
-            if (gnext < 0) break;
-            g = gnext;
-        }
-    }
-    float4* out = reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.y * ncap + n0);
-    *out = make_float4(run.x, s.x, run.y, s.y);
 }
 
-// Row pass with culling.  Lane owns the 2 adjacent rows m0 + 2*tid, +1; a group is skipped when
+// Work mapping of the culled sweeps.  A workgroup owns 128 lane points (2 per lane) and FOUR consecutive segments
+// of the stream, one per wave; the four partial results are merged through LDS, so the partial planes in HBM
+// number S/4 while a wave's chain of dependent scalar loads is one short segment (512 points at C1).  That chain
+// is what bounds a sparse E-step: per-wave timelines (tools/wave_trace.py) show busy waves at ~5400 cycles per
+// needed group (scalar loads return out of order, every wait is a wait for everything, and there is nobody else
+// on the SIMD to hide it) next to tens of thousands of waves that exit immediately - the sweep lasts as long as
+// its longest wave.
+//
+// Which groups does a wave need?  Every lane tests ONE group of the segment against the wave's box (a 32-byte
+// vector load of the group's metadata, a few VALU ops) and a ballot turns the 64 verdicts into a bit mask - one
+// memory round trip for up to 2048 streamed points.  The mask also tells the wave which group comes NEXT, so the
+// first quad of the next needed group is fetched while the current one is still being evaluated.
+
+// Column pass with culling.  Lane owns the 2 adjacent columns n0 + 2*lane, +1.  `colmin_g` (may be null) holds,
+// per group of 32 columns, the largest min_m d^2 of the previous E-step and `motion` the largest displacement any
+// source point made since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle
+// inequality), which is what makes a far group's contribution provably < 2^-127 of the final column sum.
+__global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
+                                                         const GroupMeta* __restrict__ zmeta,
+                                                         const GroupMeta* __restrict__ tmeta, int seg_len, int nseg,
+                                                         const double* __restrict__ params,
+                                                         const float* __restrict__ colmin_g,
+                                                         const unsigned* __restrict__ motion,
+                                                         float2* __restrict__ colpart, int64_t ncap) {
+    PRG_TRACE_BEGIN();
+    __shared__ float4 part[4][64];
+    __shared__ int arrived;
+    if (threadIdx.x == 0) arrived = 0;
+    __syncthreads();  // (at launch, before any wave waits for memory: costs nothing; there is no barrier at the end)
+    const float kk = (float)(-kLog2e / (2.0 * params[13]));
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n0 = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const int seg = blockIdx.y * 4 + wv;
+    f2 run = splat(INFINITY), off = splat(INFINITY), s = splat(0.f);
+    if (seg < nseg) {
+        const int64_t gw = (int64_t)blockIdx.x * 4;  // the workgroup's four 32-column groups
+        float lo[3], hi[3];
+        wave_box(tmeta + gw, lo, hi);
+        float thr = INFINITY;  // skip a group when its box is farther than thr (squared) from the wave's box
+        if (colmin_g) {
+            const float cmax = fmaxf(fmaxf(colmin_g[gw], colmin_g[gw + 1]), fmaxf(colmin_g[gw + 2], colmin_g[gw + 3]));
+            const float r = sqrtf(cmax) + __uint_as_float(*motion);
+            thr = r * r * 1.00001f + kCullLog2 / kk;  // kk < 0: kk * (d2 - seed) < -127  <=>  d2 > seed + 127 / |kk|
+        }
+        const int64_t base = (int64_t)seg * seg_len;
+        const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4 + base);
+        const GroupMeta* __restrict__ gp = zmeta + base / prg::kGroup;
+        const int ngroups = seg_len / prg::kGroup;
+        // every load of the prologue is issued here, before anything is consumed: a wave that finds nothing to do -
+        // most waves of a sparse E-step - then lives for one memory round trip, not one per dependent load
+        GroupMeta gm = gp[min(lane, ngroups - 1)];
+        // the lane's own points are fetched only once a group is needed: 150k waves x 2 KB of them is what a sparse
+        // sweep otherwise spends its time on (tools/dispatch_floor.hip: the floor of a grid this size is its loads)
+        f2 x = splat(0.f), y = splat(0.f), z = splat(0.f);
+        bool have_points = false;
+        for (int g0 = 0; g0 < ngroups; g0 += 64) {
+            if (g0 > 0) gm = gp[min(g0 + lane, ngroups - 1)];
+            const bool need = (g0 + lane < ngroups) && !(box_dist2(lo, hi, gm) > thr);
+            unsigned long long mask = __ballot(need);
+            if (mask == 0) continue;
+            if (!have_points) {
+                const float4 a = tgt4[n0], b = tgt4[n0 + 1];
+                x = (f2){a.x, b.x};
+                y = (f2){a.y, b.y};
+                z = (f2){a.z, b.z};
+                have_points = true;
+            }
+            int g = g0 + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            Quad qa = zp[(int64_t)g * 8];
+            for (;;) {
+                const int gnext = mask ? g0 + __builtin_ctzll(mask) : -1;
+                mask &= mask - 1;  // (0 stays 0)
+                PRG_TRACE_GROUP();
+                const Quad* __restrict__ q = zp + (int64_t)g * 8;
+                const Quad* __restrict__ qn = zp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const Quad qb = q[2 * t + 1];
+                    f2 d2[8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f2 dx = x - splat(qa.q[c].x), dy = y - splat(qa.q[c].y), dz = z - splat(qa.q[c].z);
+                        d2[c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qa.q[c].w))));
+                    }
+                    qa = (t < 3) ? q[2 * t + 2] : qn[0];  // last trip: first quad of the next needed group
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f2 dx = x - splat(qb.q[c].x), dy = y - splat(qb.q[c].y), dz = z - splat(qb.q[c].z);
+                        d2[4 + c] = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, splat(qb.q[c].w))));
+                    }
+                    f2 cm = d2[0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) cm = minv(cm, d2[c]);
+                    if ((cm.x < run.x) | (cm.y < run.y)) {
+                        const f2 nm = minv(run, cm);
+                        const f2 noff = col_offset2(kk, nm);
+                        s *= exp2v(noff - off);
+                        run = nm;
+                        off = noff;
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) s += exp2v(fmav(d2[c], splat(kk), off));
+                }
+                if (gnext < 0) break;
+                g = gnext;
+            }
+        }
+    }
+    // Merge the four segments' (min, sum) pairs (sums are relative to the offset of their own minimum) without a
+    // barrier: every wave leaves its pair in LDS and counts itself in; whoever arrives last does the merge.  An idle
+    // wave is gone after its one round trip instead of holding a wave slot until its busiest sibling has finished.
+    part[wv][lane] = make_float4(run.x, s.x, run.y, s.y);
+    int last = 0;
+    if (lane == 0) last = atomicAdd(&arrived, 1) == 3;  // LDS ops of a wave execute in order: the pair is visible
+    if (__builtin_amdgcn_readfirstlane(last)) {
+        run = splat(INFINITY);
+        off = splat(INFINITY);
+        s = splat(0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 o = part[k][lane];
+            const f2 orun = {o.x, o.z}, os = {o.y, o.w};
+            const f2 nm = minv(run, orun);
+            const f2 noff = col_offset2(kk, nm);
+            // (an empty side has sum 0 and offset FLT_MAX or +inf: its factor is exp2(-huge) = 0, never inf * 0)
+            s = s * exp2v(noff - off) + os * exp2v(noff - col_offset2(kk, orun));
+            run = nm;
+            off = noff;
+        }
+        float4* out = reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.y * ncap + n0);
+        *out = make_float4(run.x, s.x, run.y, s.y);
+    }
+    PRG_TRACE_END(0);
+}
+
+// Row pass with culling.  Lane owns the 2 adjacent rows m0 + 2*lane, +1; a group is skipped when
 // kk * dist2(boxes) + max_n b_n < -127, i.e. every P of the block comes out of v_exp_f32 as exactly 0.
 __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
-                                                         const GroupMeta* __restrict__ tmeta, int seg_len,
+                                                         const GroupMeta* __restrict__ tmeta,
+                                                         const GroupMeta* __restrict__ zmeta, int seg_len, int nseg,
                                                          const double* __restrict__ params,
                                                          float* __restrict__ rowpart, int64_t mcap,
                                                          unsigned char* __restrict__ rowflag) {
+    PRG_TRACE_BEGIN();
+    __shared__ float2 part[4][5][64];
+    __shared__ int arrived, wave_touched[4];
+    if (threadIdx.x == 0) arrived = 0;
+    __syncthreads();  // (at launch; the merge at the end is barrier-free, see k_colpass_cull)
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
-    const int64_t m0 = (int64_t)blockIdx.x * (kBlock * 2) + 2 * threadIdx.x;
-    const float4 a = z4[m0], b = z4[m0 + 1];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t m0 = (int64_t)blockIdx.x * 128 + 2 * lane;
+    const int seg = blockIdx.y * 4 + wv;
     bool touched = false;  // wave-uniform: did this wave evaluate any pair of its (128 rows x segment) block?
-    const f2 zx = {a.x, b.x}, zy = {a.y, b.y}, zz = {a.z, b.z}, zq = {a.w, b.w};  // zq: weight term, 0 for plain CPD
     f2 p1 = splat(0.f), ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), e = splat(0.f);
-    float lo[3], hi[3];
-    lo[0] = wave_min(fminf(a.x, b.x)); hi[0] = wave_max(fmaxf(a.x, b.x));
-    lo[1] = wave_min(fminf(a.y, b.y)); hi[1] = wave_max(fmaxf(a.y, b.y));
-    lo[2] = wave_min(fminf(a.z, b.z)); hi[2] = wave_max(fmaxf(a.z, b.z));
-    const int lane = threadIdx.x & 63;
-    const int64_t base = (int64_t)blockIdx.y * seg_len;
-    const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + base);
-    const GroupMeta* __restrict__ gp = tmeta + base / prg::kGroup;
-    const int ngroups = seg_len / prg::kGroup;
-    for (int g0 = 0; g0 < ngroups; g0 += 64) {
-        bool need = false;
-        if (g0 + lane < ngroups) {
-            const GroupMeta gm = gp[g0 + lane];  // gm.aux = max b_n over the 32 points
-            need = !(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2);
-        }
-        unsigned long long mask = __ballot(need);
-        if (mask == 0) continue;
-        touched = true;
-        int g = g0 + __builtin_ctzll(mask);
-        mask &= mask - 1;
-        Quad cq = tp[(int64_t)g * 8];
-        for (;;) {
-            const int gnext = mask ? g0 + __builtin_ctzll(mask) : -1;
-            mask &= mask - 1;
-            const Quad* __restrict__ q = tp + (int64_t)g * 8;
-            const Quad* __restrict__ qn = tp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const Quad nq = (t < 7) ? q[t + 1] : qn[0];  // prefetch: next quad, or the next needed group's first
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f2 dx = zx - splat(cq.q[c].x), dy = zy - splat(cq.q[c].y), dz = zz - splat(cq.q[c].z);
-                    const f2 d = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, zq)));
-                    const f2 pr = exp2v(fmav(d, splat(kk), splat(cq.q[c].w)));
-                    p1 += pr;
-                    ux = fmav(pr, dx, ux);
-                    uy = fmav(pr, dy, uy);
-                    uz = fmav(pr, dz, uz);
-                    e = fmav(pr, d, e);
-                }
-                cq = nq;
+    if (seg < nseg) {
+        float lo[3], hi[3];
+        wave_box(zmeta + (int64_t)blockIdx.x * 4, lo, hi);
+        const int64_t base = (int64_t)seg * seg_len;
+        const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4 + base);
+        const GroupMeta* __restrict__ gp = tmeta + base / prg::kGroup;
+        const int ngroups = seg_len / prg::kGroup;
+        GroupMeta gm = gp[min(lane, ngroups - 1)];  // gm.aux = max b_n over the group's 32 points
+        f2 zx = splat(0.f), zy = splat(0.f), zz = splat(0.f), zq = splat(0.f);  // fetched when first needed
+        for (int g0 = 0; g0 < ngroups; g0 += 64) {
+            if (g0 > 0) gm = gp[min(g0 + lane, ngroups - 1)];
+            const bool need = (g0 + lane < ngroups) && !(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2);
+            unsigned long long mask = __ballot(need);
+            if (mask == 0) continue;
+            if (!touched) {
+                const float4 a = z4[m0], b = z4[m0 + 1];
+                zx = (f2){a.x, b.x};
+                zy = (f2){a.y, b.y};
+                zz = (f2){a.z, b.z};
+                zq = (f2){a.w, b.w};  // weight term, 0 for plain CPD
             }
-            if (gnext < 0) break;
-            g = gnext;
+            touched = true;
+            int g = g0 + __builtin_ctzll(mask);
+            mask &= mask - 1;
+            Quad cq = tp[(int64_t)g * 8];
+            for (;;) {
+                const int gnext = mask ? g0 + __builtin_ctzll(mask) : -1;
+                mask &= mask - 1;
+                PRG_TRACE_GROUP();
+                const Quad* __restrict__ q = tp + (int64_t)g * 8;
+                const Quad* __restrict__ qn = tp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const Quad nq = (t < 7) ? q[t + 1] : qn[0];  // prefetch: next quad, or the next needed group's first
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f2 dx = zx - splat(cq.q[c].x), dy = zy - splat(cq.q[c].y), dz = zz - splat(cq.q[c].z);
+                        const f2 d = fmav(dz, dz, fmav(dy, dy, fmav(dx, dx, zq)));
+                        const f2 pr = exp2v(fmav(d, splat(kk), splat(cq.q[c].w)));
+                        p1 += pr;
+                        ux = fmav(pr, dx, ux);
+                        uy = fmav(pr, dy, uy);
+                        uz = fmav(pr, dz, uz);
+                        e = fmav(pr, d, e);
+                    }
+                    cq = nq;
+                }
+                if (gnext < 0) break;
+                g = gnext;
+            }
         }
     }
-    // k_row_moments skips the partials of untouched (wave, segment) blocks: they are neither written nor read
-    if (lane == 0)
-        rowflag[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + blockIdx.y] = touched ? 1 : 0;  // [wave block][segment]
-    if (!touched) return;
-    float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
-    *reinterpret_cast<float2*>(o) = make_float2(p1.x, p1.y);
-    *reinterpret_cast<float2*>(o + mcap) = make_float2(-ux.x, -ux.y);
-    *reinterpret_cast<float2*>(o + 2 * mcap) = make_float2(-uy.x, -uy.y);
-    *reinterpret_cast<float2*>(o + 3 * mcap) = make_float2(-uz.x, -uz.y);
-    *reinterpret_cast<float2*>(o + 4 * mcap) = make_float2(fmaf(-zq.x, p1.x, e.x), fmaf(-zq.y, p1.y, e.y));
+    if (touched) {  // an untouched wave contributes nothing and leaves nothing to read
+        part[wv][0][lane] = make_float2(p1.x, p1.y);
+        part[wv][1][lane] = make_float2(ux.x, ux.y);
+        part[wv][2][lane] = make_float2(uy.x, uy.y);
+        part[wv][3][lane] = make_float2(uz.x, uz.y);
+        part[wv][4][lane] = make_float2(e.x, e.y);
+    }
+    int last = 0;
+    if (lane == 0) {
+        wave_touched[wv] = touched ? 1 : 0;
+        last = atomicAdd(&arrived, 1) == 3;
+    }
+    if (__builtin_amdgcn_readfirstlane(last)) {
+        // k_row_moments skips the partials of untouched (128-row block, plane) pairs: neither written nor read
+        const int t0 = wave_touched[0], t1 = wave_touched[1], t2 = wave_touched[2], t3 = wave_touched[3];
+        const bool any = (t0 | t1 | t2 | t3) != 0;
+        if (lane == 0) rowflag[(int64_t)blockIdx.x * 64 + blockIdx.y] = any ? 1 : 0;
+        if (any) {
+            const int tk[4] = {t0, t1, t2, t3};
+            p1 = ux = uy = uz = e = splat(0.f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!tk[k]) continue;
+                const float2 q0 = part[k][0][lane], q1 = part[k][1][lane], q2 = part[k][2][lane], q3 = part[k][3][lane],
+                             q4 = part[k][4][lane];
+                p1 += (f2){q0.x, q0.y};
+                ux += (f2){q1.x, q1.y};
+                uy += (f2){q2.x, q2.y};
+                uz += (f2){q3.x, q3.y};
+                e += (f2){q4.x, q4.y};
+            }
+            const float4 za = z4[m0], zb = z4[m0 + 1];  // the merging wave may be one that never loaded its rows
+            float* __restrict__ o = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
+            *reinterpret_cast<float2*>(o) = make_float2(p1.x, p1.y);
+            *reinterpret_cast<float2*>(o + mcap) = make_float2(-ux.x, -ux.y);
+            *reinterpret_cast<float2*>(o + 2 * mcap) = make_float2(-uy.x, -uy.y);
+            *reinterpret_cast<float2*>(o + 3 * mcap) = make_float2(-uz.x, -uz.y);
+            *reinterpret_cast<float2*>(o + 4 * mcap) = make_float2(fmaf(-za.w, p1.x, e.x), fmaf(-zb.w, p1.y, e.y));
+        }
+    }
+    PRG_TRACE_END(1);
 }
 
 }  // namespace
 
 namespace prg {
 
+#ifdef PRG_WAVE_TRACE
+extern "C" int prg_debug_set_wave_trace(unsigned long long* dev_buffer, unsigned long long max_waves) {
+    PRG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace), &dev_buffer, sizeof(dev_buffer)));
+    PRG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_wave_trace_cap), &max_waves, sizeof(max_waves)));
+    return PRG_OK;
+}
+#endif
+
+// S segments of seg_len streamed points, four per workgroup: S/4 (rounded up) partial planes
 void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
-    dim3 grid((unsigned)ceil_div(h->N, kBlock * 2), (unsigned)S);
-    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta), seg_len,
-                                                   h->params,
-                                                   use_seed ? h->colmin : nullptr, h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap);
+    dim3 grid((unsigned)ceil_div(h->N, 128), (unsigned)ceil_div(S, 4));
+    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
+                                                   reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len, S, h->params,
+                                                   use_seed ? h->colmin + h->Ncap : nullptr,
+                                                   h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap);
 }
 
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
-    dim3 grid((unsigned)ceil_div(h->M, kBlock * 2), (unsigned)S);
-    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len,
-                                                   h->params,
+    const int planes = (int)ceil_div(S, 4);
+    dim3 grid((unsigned)ceil_div(h->M, 128), (unsigned)planes);
+    k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta),
+                                                   reinterpret_cast<const GroupMeta*>(h->zmeta), seg_len, S, h->params,
                                                    h->rowpart, h->Mcap,
-                                                   reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)S * 5 * h->Mcap));
+                                                   reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)planes * 5 * h->Mcap));
 }
 
 }  // namespace prg

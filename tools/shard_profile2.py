@@ -20,7 +20,7 @@ for it in range(30):
 st = plan.get_params()
 cy, cx = reg._cy, reg._cx
 rows = dist.spatial_shard(tgt, 0, world) if world > 1 else np.arange(n)
-for segs in ((0, 0), (8, 1), (16, 2), (32, 4), (64, 8), (64, 16), (16, 8), (32, 16)):
+for segs in ((0, 0), (16, 16), (32, 32), (64, 64), (128, 64), (256, 64)):
     p2 = engine.CpdPlan()
     p2.set_source(src - cy)
     p2.set_target(tgt[rows] - cx, n_global=n)
