@@ -1,0 +1,133 @@
+"""Edge cases of the GPU paths: plan reuse, extreme aspect ratios, alignment boundaries of the kernels' tiling,
+degenerate inputs, heavy outliers, deep late-regime (culled) iterations.  Everything is checked against the numpy
+oracle on the same inputs; tolerances as in test_cpd_gpu.py (transform 1e-4, sigma2 1e-5)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_TF = 1e-4
+TOL_SIGMA2 = 1e-5
+
+
+def _check(kind, res, p, s2):
+    tr = res.transformation
+    lin = tr.rot if kind == "rigid" else tr.b
+    assert rel_err(lin, p["rot"] if kind == "rigid" else p["b"]) < TOL_TF, kind
+    assert np.max(np.abs(tr.t - p["t"])) < TOL_TF * max(1.0, np.max(np.abs(p["t"]))), kind
+    if kind == "rigid":
+        assert abs(tr.scale - p["scale"]) < TOL_TF * p["scale"]
+    assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2, (kind, res.sigma2, s2)
+
+
+@pytest.mark.parametrize("m,n", [(127, 129), (128, 128), (513, 255), (1025, 2047), (2049, 511)])
+def test_registration_across_tile_boundaries(m, n):
+    """Cloud sizes just below / at / above the 128-point wave tiles, 256-point super-groups and 512-point segments."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(n, m=m, seed=m + n)
+    for kind in ("rigid", "affine"):
+        res = cpd.registration_cpd(src, tgt, kind, w=0.1, maxiter=12, tol=-1.0)
+        p, s2, q, _ = co.registration(kind, src, tgt, w=0.1, maxiter=12, tol=-1.0, closed_form_init=True)
+        _check(kind, res, p, s2)
+
+
+@pytest.mark.parametrize("m,n", [(3, 6000), (6000, 4), (40, 9000), (9000, 60)])
+def test_extreme_aspect_ratios(m, n):
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(n, m=m, seed=7)
+    got = cpd.RigidCPD().expectation_step(src, tgt, 0.05, 0.15)
+    want = co.expectation_step(src, tgt, 0.05, 0.15)
+    assert np.max(np.abs(got.pt1 - want.pt1)) < 2e-6
+    assert rel_err(got.p1, want.p1) < 1e-5 and rel_err(got.px, want.px) < 1e-5
+    if min(m, n) >= 40:
+        res = cpd.registration_cpd(src, tgt, "rigid", w=0.05, maxiter=10, tol=-1.0)
+        p, s2, q, _ = co.registration("rigid", src, tgt, w=0.05, maxiter=10, tol=-1.0, closed_form_init=True)
+        _check("rigid", res, p, s2)
+
+
+def test_deep_late_regime_matches_oracle():
+    """40 iterations: sigma2 falls by four orders of magnitude, the sweeps end up skipping almost every block.
+    Segment / plane layout of this size differs from C1's (11 column segments of 256 points, 3 planes)."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(3500, m=3000, seed=91)
+    for kind, w in (("rigid", 0.0), ("affine", 0.1)):
+        res = cpd.registration_cpd(src, tgt, kind, w=w, maxiter=40, tol=-1.0)
+        p, s2, q, _ = co.registration(kind, src, tgt, w=w, maxiter=40, tol=-1.0, closed_form_init=True)
+        _check(kind, res, p, s2)
+    assert res.sigma2 < 1e-3
+
+
+def test_heavy_outliers_and_large_w():
+    """A third of the target is uniform clutter far from the object and w = 0.9: most columns end up dominated by
+    the uniform term, some die completely (den underflows) in late iterations."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(2000, m=1500, seed=12)
+    rng = np.random.default_rng(3)
+    clutter = rng.uniform(-6.0, 6.0, (1000, 3))
+    tgt = np.concatenate([tgt, clutter], axis=0)
+    rng.shuffle(tgt, axis=0)
+    res = cpd.registration_cpd(src, tgt, "rigid", w=0.9, maxiter=25, tol=-1.0)
+    p, s2, q, _ = co.registration("rigid", src, tgt, w=0.9, maxiter=25, tol=-1.0, closed_form_init=True)
+    _check("rigid", res, p, s2)
+
+
+def test_identical_clouds():
+    """source == target: the transform stays the identity while sigma2 collapses to the float32-eps clamp."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, _, _ = synthetic.rigid_pair(10, m=900, seed=5)
+    res = cpd.registration_cpd(src, src.copy(), "rigid", maxiter=30, tol=-1.0)
+    p, s2, q, _ = co.registration("rigid", src, src.copy(), maxiter=30, tol=-1.0, closed_form_init=True)
+    assert rel_err(res.transformation.rot, np.identity(3)) < 1e-5
+    assert np.max(np.abs(res.transformation.t)) < 1e-5
+    assert abs(res.transformation.scale - 1.0) < 1e-5
+    assert res.sigma2 <= max(2.0 * s2, 2.0 * np.finfo(np.float32).eps)
+
+
+def test_registrar_reuse_with_new_targets_and_sources():
+    """One registrar object, several registrations: bigger target (buffers grow), smaller target, new source."""
+    from probreg_amd import cpd, synthetic
+
+    src, tgt_a, _ = synthetic.rigid_pair(1200, m=1000, seed=21)
+    _, tgt_b, _ = synthetic.rigid_pair(5000, m=1000, seed=22)
+    src2, tgt_c, _ = synthetic.rigid_pair(800, m=2300, seed=23)
+    reg = cpd.RigidCPD(src)
+    runs = [(src, tgt_a), (src, tgt_b), (src, tgt_a), (src2, tgt_c), (src, tgt_b)]
+    for s, t in runs:
+        if s is not reg._source and not np.array_equal(s, reg._source):
+            reg.set_source(s)
+        got = reg.registration(t, w=0.05, maxiter=10, tol=-1.0)
+        fresh = cpd.RigidCPD(s).registration(t, w=0.05, maxiter=10, tol=-1.0)
+        assert np.array_equal(got.transformation.rot, fresh.transformation.rot)
+        assert got.sigma2 == fresh.sigma2
+
+
+def test_bcpd_two_dimensional_and_w0():
+    from oracle import bcpd_numpy as bo
+    from probreg_amd import bcpd
+
+    rng = np.random.default_rng(8)
+    g = np.stack(np.meshgrid(np.arange(9), np.arange(8), indexing="ij"), axis=-1).reshape(-1, 2)
+    src = g * 3.0 + rng.uniform(-0.6, 0.6, g.shape)
+    src -= src.mean(axis=0)
+    th = 0.15
+    r = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    tgt = 1.03 * (src + 0.3 * np.sin(0.4 * src[:, ::-1])) @ r.T + np.array([0.4, -0.3]) + rng.normal(0.0, 0.04, src.shape)
+    for w in (0.0, 0.1):
+        trans = bcpd.registration_bcpd(src, tgt, w=w, maxiter=6, tol=-1.0)
+        res, _ = bo.registration(src, tgt, w=w, maxiter=6, tol=-1.0, inv_dtype=np.float64)
+        ts = res.scale * np.dot(src + res.v, res.rot.T) + res.t
+        assert trans.rigid_trans.rot.shape == (2, 2)
+        assert rel_err(trans.transform(src), ts) < TOL_TF
+        assert abs(trans.rigid_trans.scale - res.scale) < TOL_TF
