@@ -152,44 +152,30 @@ __device__ __forceinline__ float half_max(float v) {
     return v;
 }
 
-// Writes the 8 group boxes and the super-group box of the 256 points this workgroup holds (one point per thread).
-// aux_lo / aux_hi < 0: only the aux range is refreshed (the boxes of a static cloud were written at upload).
+// Writes the boxes of the 8 groups of 32 points this workgroup holds (one point per thread): lo.xyz, hi.xyz, max aux,
+// min aux.  write_boxes == false: only the aux range is refreshed (the boxes of a static cloud were written at upload).
 __device__ __forceinline__ void block_group_meta(float x, float y, float z, float wmax_in, float wmin_in,
-                                                 bool write_boxes, float* __restrict__ gmeta,
-                                                 float* __restrict__ smeta) {
-    __shared__ float sh[8][8];
+                                                 bool write_boxes, float* __restrict__ gmeta) {
     float v[8];
     v[0] = half_min(x); v[1] = half_min(y); v[2] = half_min(z);
     v[3] = half_max(x); v[4] = half_max(y); v[5] = half_max(z);
     v[6] = half_max(wmax_in);
     v[7] = half_min(wmin_in);
-    const int gl = threadIdx.x >> 5;  // group within the block
     if ((threadIdx.x & 31) == 0) {
-        float* o = gmeta + ((int64_t)blockIdx.x * 8 + gl) * 8;
+        float* o = gmeta + ((int64_t)blockIdx.x * 8 + (threadIdx.x >> 5)) * 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < 8; ++c)
             if (write_boxes || c >= 6) o[c] = v[c];
-            sh[gl][c] = v[c];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int c = threadIdx.x;
-        if (write_boxes || c >= 6) {
-            float r = sh[0][c];
-            for (int k = 1; k < 8; ++k) r = (c < 3 || c == 7) ? fminf(r, sh[k][c]) : fmaxf(r, sh[k][c]);
-            smeta[(int64_t)blockIdx.x * 8 + c] = r;
-        }
     }
 }
 
 // z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).  The same kernel measures
-// how far the source moved since the previous E-step (cull bound of k_colpass_cull) and writes the group /
-// super-group boxes of the transformed cloud.  grid = cap / 256, one point per thread.
+// how far the source moved since the previous E-step (cull bound of k_colpass_cull) and writes the group
+// boxes of the transformed cloud.  grid = ceil(M / 256), one point per thread (pad-only blocks keep their static boxes).
 __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __restrict__ src4, float4* __restrict__ z4,
                                                              int64_t m, const double* __restrict__ params,
                                                              unsigned* __restrict__ motion, int slot,
-                                                             float* __restrict__ gmeta, float* __restrict__ smeta,
+                                                             float* __restrict__ gmeta,
                                                              const float* __restrict__ srcw,
                                                              const double* __restrict__ disp) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -232,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
         if (mv > 0.f) atomicMax(motion + slot, __float_as_uint(mv));
     }
     if (i == 0) motion[slot ^ 1] = 0u;
-    block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta, smeta);
+    block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta);
 }
 
 // bounding box (+ range of .w) of every group of 32 consecutive points -> meta[g][8] = lo.xyz, hi.xyz, max w, min w
@@ -258,21 +244,6 @@ __global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict_
     o[7] = wmin;
 }
 
-// super-group boxes: union of 8 consecutive group boxes (max / min of the aux range)
-__global__ __launch_bounds__(kBlock) void k_super_meta(const float* __restrict__ meta, int64_t nsuper,
-                                                       float* __restrict__ smeta) {
-    const int64_t sg = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (sg >= nsuper) return;
-    float o[8] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY, -INFINITY, INFINITY};
-    for (int k = 0; k < 8; ++k) {
-        const float* m = meta + (sg * 8 + k) * 8;
-        for (int c = 0; c < 3; ++c) { o[c] = fminf(o[c], m[c]); o[3 + c] = fmaxf(o[3 + c], m[3 + c]); }
-        o[6] = fmaxf(o[6], m[6]);
-        o[7] = fminf(o[7], m[7]);
-    }
-    for (int c = 0; c < 8; ++c) smeta[sg * 8 + c] = o[c];
-}
-
 // (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip)
 
 // Merge the S partial (min, sum) pairs of each column in fp64; apply cpd.py:78-82:
@@ -282,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
                                                      int nseg, int64_t ncap, int64_t n, float* __restrict__ pt1,
                                                      const double* __restrict__ params, double w, double m_over_n,
                                                      int dim, float* __restrict__ colmin, float* __restrict__ colmin_g,
-                                                     float* __restrict__ gmeta, float* __restrict__ smeta) {
+                                                     float* __restrict__ gmeta) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     float b = 0.f;  // pads keep b = 0
     float cmin = 0.f;  // pads do not widen the seed
@@ -335,8 +306,8 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
         const float gm = half_max(cmin);
         if ((threadIdx.x & 31) == 0) colmin_g[(int64_t)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5)] = gm;
     }
-    // refresh the b_n range of this workgroup's 8 groups / 1 super-group (their boxes are static)
-    if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta, smeta);
+    // refresh the b_n range of this workgroup's 8 groups (their boxes are static)
+    if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -676,10 +647,10 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion, (void*)h->zsmeta, (void*)h->tsmeta, (void*)h->srcw})
+                    (void*)h->motion, (void*)h->srcw})
         if (q) (void)hipFree(q);
     h->perm_src = h->perm_tgt = nullptr;
-    h->zmeta = h->tmeta = h->colmin = h->zsmeta = h->tsmeta = nullptr;
+    h->zmeta = h->tmeta = h->colmin = nullptr;
     h->motion = nullptr;
     h->src4 = h->z4 = h->tgt4 = nullptr;
     h->pt1 = nullptr;
@@ -703,7 +674,7 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
     return PRG_OK;
 }
 
-// capacity: the cloud + room for 64 segments each rounded up to a 256-point super-group + prefetch slack
+// capacity: the cloud + room for the segments' rounding to 256-point multiples + prefetch slack
 int cap_for(int64_t n) { return (int)prg::round_up(n + 64 * prg::kSuper + 1024, 1024); }
 
 // Morton (Z-curve) order of a cloud: sorted position -> original index (morton.h), uploaded as the plan's permutation.
@@ -818,8 +789,6 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     }
     if (cap != h->Mcap || !h->zmeta) {
         PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
-        PRG_TRY(ensure_exact(&h->zsmeta, (size_t)(cap / prg::kSuper + 4) * 8));
-        PRG_HIP(hipMemsetAsync(h->zsmeta, 0, (size_t)(cap / prg::kSuper + 4) * 8 * sizeof(float), h->stream));
         if (!h->motion) {
             PRG_TRY(ensure_exact(&h->motion, 2));
             PRG_HIP(hipMemsetAsync(h->motion, 0, 2 * sizeof(unsigned), h->stream));
@@ -842,7 +811,6 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
                                                        h->perm_src);
     // boxes of the whole padded array once; the per-iteration transform kernel refreshes the blocks with real points
     k_group_meta<<<grid1(cap / prg::kGroup), kBlock, 0, h->stream>>>(h->z4, cap / prg::kGroup, h->zmeta);
-    k_super_meta<<<grid1(cap / prg::kSuper), kBlock, 0, h->stream>>>(h->zmeta, cap / prg::kSuper, h->zsmeta);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));  // the caller's buffer may be pageable host memory
     h->have_colmin = false;
@@ -903,8 +871,6 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     }
     if (cap != h->Ncap || !h->tmeta) {
         PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
-        PRG_TRY(ensure_exact(&h->tsmeta, (size_t)(cap / prg::kSuper + 4) * 8));
-        PRG_HIP(hipMemsetAsync(h->tsmeta, 0, (size_t)(cap / prg::kSuper + 4) * 8 * sizeof(float), h->stream));
         PRG_TRY(ensure_exact(&h->colmin, (size_t)cap + (size_t)cap / prg::kGroup));  // + per-group maxima
         PRG_HIP(hipMemsetAsync(h->colmin, 0, ((size_t)cap + (size_t)cap / prg::kGroup) * sizeof(float), h->stream));
     }
@@ -922,9 +888,8 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     PRG_HIP(hipMemcpyAsync(h->stage, target_hd, (size_t)n_local * dim * sizeof(float), hipMemcpyDefault, h->stream));
     k_pack_cloud<<<grid1(cap), kBlock, 0, h->stream>>>((const float*)h->stage, n_local, dim, h->tgt4, cap,
                                                        prg::kTgtPad, 0.f, h->perm_tgt);
-    // the target never moves: its group / super-group boxes are written once (k_colfinal refreshes the b_n range)
+    // the target never moves: its group boxes are written once (k_colfinal refreshes the b_n range)
     k_group_meta<<<grid1(cap / prg::kGroup), kBlock, 0, h->stream>>>(h->tgt4, cap / prg::kGroup, h->tmeta);
-    k_super_meta<<<grid1(cap / prg::kSuper), kBlock, 0, h->stream>>>(h->tmeta, cap / prg::kSuper, h->tsmeta);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
     h->have_colmin = false;
@@ -1016,7 +981,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int64_t nblkA = prg::ceil_div(h->N, kBlock * RA), nblkB = prg::ceil_div(h->M, kBlock * RB);
     // Culled sweeps need both clouds Morton-sorted (compact waves / groups); they walk the stream in groups of 32.
     const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;  // (segment counts stay tunable)
-    // segment lengths are multiples of the loop trip (8 points, or one 256-point super-group); the pads absorb the
+    // segment lengths are multiples of the loop trip (8 points, or 256 points = 8 groups); the pads absorb the
     // overshoot and the prefetch over-read of the last segment
     const int quantum = use_cull ? prg::kSuper : 8;
     int SA, SB;
@@ -1057,9 +1022,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     ++h->estep_count;
     if (h->nonrigid)
         PRG_TRY(prg::nonrigid_transform(h));
-    else  // one fused kernel: transform, source motion, group / super-group boxes of the transformed cloud
+    else  // one fused kernel: transform, source motion, group boxes of the transformed cloud
         k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
-            h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->zsmeta, h->srcw,
+            h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw,
             h->bcpd ? h->W : nullptr);  // pad-only blocks are static
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_cull)
@@ -1072,7 +1037,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, PA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
                                                       h->colmin + h->Ncap,
-                                                      use_cull ? h->tmeta : nullptr, h->tsmeta);
+                                                      use_cull ? h->tmeta : nullptr);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);

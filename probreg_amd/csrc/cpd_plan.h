@@ -43,10 +43,9 @@ struct prg_cpd {
     int* perm_src = nullptr;    // [M] sorted position -> original index (nullptr = identity order)
     int* perm_tgt = nullptr;    // [N]
     float* zmeta = nullptr;     // [Mcap/32][8] per group of 32 transformed source points: lo.xyz, hi.xyz, -, -
-    float* tmeta = nullptr;     // [Ncap/32][8] per group of 32 target points: lo.xyz, hi.xyz, max b_n, -
-    float* zsmeta = nullptr;    // [Mcap/256 + 1][8] super-group boxes of the transformed source
-    float* tsmeta = nullptr;    // [Ncap/256 + 1][8] super-group boxes of the target: lo, hi, max b_n, min b_n
-    float* colmin = nullptr;    // [Ncap] min_m d^2 per column from the previous E-step (seed of the cull bound)
+    float* tmeta = nullptr;     // [Ncap/32][8] per group of 32 target points: lo.xyz, hi.xyz, max b_n, min b_n
+    float* colmin = nullptr;    // [Ncap] min_m d^2 per column from the previous E-step (seed of the cull bound),
+                                // followed by [Ncap/32] per-group maxima of it
     unsigned* motion = nullptr; // float bits of max_m |z_new - z_old| of the last transform
     bool have_colmin = false;
     uint64_t estep_count = 0;   // parity selects the motion slot of the current E-step

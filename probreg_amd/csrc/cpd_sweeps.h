@@ -22,7 +22,7 @@ __device__ __forceinline__ float col_offset(float kk, float dmin) {
 }
 
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
-constexpr int kSuper = 256;    // streamed points per super-group (8 groups); culled segments are multiples of this
+constexpr int kSuper = 256;    // quantum of a culled segment's length (8 groups)
 // culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup
 void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed);
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len);
