@@ -31,6 +31,7 @@ WORKLOADS = {
     "affine_200k": ("affine", 200000, "C2 AffineCPD fp32 synthetic N=M=200000 D=3 w=0"),
     "nonrigid_50k": ("nonrigid", 50000, "C3 NonRigidCPD fp32 E-step / fp64 M-step synthetic N=M=50000 beta=2 lmd=2"),
     "filterreg_500k": ("filterreg", 500000, "C4 FilterReg rigid pt2pt synthetic N=M=500000, 5% outliers, w=0.05"),
+    "bcpd_20k": ("bcpd", 20000, "BCPD (SURVEY 8f rank 4) fp32 E-step / fp64 M-step synthetic N=M=20000 lmd=2 w=0.05"),
     "rigid_20k": ("rigid", 20000, "reduced RigidCPD fp32 synthetic N=M=20000 (debug only)"),
 }
 F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X f64 matrix peak (v_mfma_f64_16x16x4_f64, 32 FLOP/clk/SIMD at 2.4 GHz)
@@ -111,6 +112,38 @@ def bench_nonrigid(args, n, desc):
     return out
 
 
+def bench_bcpd(args, n, desc):
+    """BCPD: one step = weighted E-step + Woodbury M-step (bcpd.py:82-98 loop body without the convergence test)."""
+    import torch
+    from probreg_amd import bcpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(n, seed=0)
+    src, tgt = src * 10.0, tgt * 10.0  # object ~20 units across: the c = 1 inverse-multiquadric kernel has a sensible width
+    reg = bcpd.CombinedBCPD(src)
+    stamps = []
+    reg.set_callbacks([lambda tr: (torch.cuda.synchronize(), stamps.append(time.perf_counter()))])
+    reg.registration(tgt, w=0.05, maxiter=args.warmup + args.steps, tol=-1.0)
+    elapsed = stamps[-1] - stamps[args.warmup - 1] if args.warmup > 0 else stamps[-1] - stamps[0]
+    steps = args.steps if args.warmup > 0 else args.steps - 1
+    plan = reg._plan
+    nu, resid = np.ones(n), np.zeros((n, 3))
+    plan.bcpd_solve(2.0, 10.0, resid, nu)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.bcpd_solve(2.0, 10.0, resid, nu)
+    torch.cuda.synchronize()
+    t_m = time.perf_counter() - t0
+    flops = 4.0 / 3.0 * n ** 3  # Cholesky (1/3) + triangular solve with M right-hand sides (1)
+    out = _base(args, "EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, desc, "f32 E-step / f64 M-step")
+    out["steps"] = steps
+    out["ms_per_step"] = 1e3 * elapsed / steps
+    out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_nt_f64 (Cholesky of S + triangular solve for diag(Sigma))",
+                       "achieved": flops / t_m / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops / t_m / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
+                       "algorithmic_flops_per_mstep": flops, "solve_ms": 1e3 * t_m}
+    return out
+
+
 def bench_filterreg(args, n, desc):
     """C4: one step = lattice E-step + Kabsch M-step (filterreg.py:129-146), sigma2 updated every step."""
     import torch
@@ -187,10 +220,10 @@ def main():
     from probreg_amd import _lib, cpd, synthetic
 
     kind, n, desc = WORKLOADS[args.workload]
-    if kind in ("nonrigid", "filterreg"):
+    if kind in ("nonrigid", "filterreg", "bcpd"):
         if world > 1:
             raise SystemExit("%s runs as single-GPU replicas (DESIGN.md section 6)" % args.workload)
-        out = bench_nonrigid(args, n, desc) if kind == "nonrigid" else bench_filterreg(args, n, desc)
+        out = {"nonrigid": bench_nonrigid, "filterreg": bench_filterreg, "bcpd": bench_bcpd}[kind](args, n, desc)
         print(json.dumps(out))
         return
     if kind == "rigid":
