@@ -764,9 +764,23 @@ extern "C" int prg_cpd_bcpd_solve(prg_cpd* h, double lmd, double cfac, const dou
     k_build_bt<<<dim3((unsigned)prg::ceil_div(mp, kBlock), (unsigned)std::min<int64_t>(mp, 32768)), kBlock, 0, st>>>(h->G, m, mp, sp, wt);
     PRG_TRY(cholesky_lookahead(h, S, mp, linv, info));
 
-    // Wt <- Wt L^-T, left-looking over 512-column panels: one K-deep rectangular update with everything to the
-    // left of the panel, then four (update inside the panel, multiply by the inverted diagonal block) steps
-    constexpr int64_t NBO = 512;
+    // Wt <- Wt L^-T, left-looking over panels of k 128-column blocks: one K-deep rectangular update with everything
+    // to the left of the panel, then k (update inside the panel, multiply by the inverted diagonal block) steps.
+    // The update runs nblk x k workgroups, 512 at a time (two per CU): k is chosen so that this is close to a whole
+    // number of rounds - at M = 20k (157 block rows) four blocks per panel would leave the second round 23 % full.
+    int kpanel = 4;
+    {
+        double best = 1e30;
+        for (int k = 4; k <= 16; ++k) {
+            const double wgs = (double)nblk * k;
+            const double waste = ceil(wgs / 512.0) * 512.0 / wgs;
+            if (waste <= best + 1e-9) {  // ties: the wider panel (fewer, larger launches)
+                best = waste;
+                kpanel = k;
+            }
+        }
+    }
+    const int64_t NBO = (int64_t)kpanel * NB;
     for (int64_t K0 = 0; K0 < mp; K0 += NBO) {
         const int64_t kend = std::min<int64_t>(K0 + NBO, mp);
         if (K0 > 0)
