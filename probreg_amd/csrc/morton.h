@@ -1,5 +1,5 @@
 // Morton (Z-curve) order of a point cloud on the host: result[i] = original index of the i-th point along the curve.
-// One-off work at upload (std::stable_sort over n 64-bit keys: ~10 ms per 100k points); the kernels only ever see the
+// One-off work at upload (a radix sort of n 64-bit keys: ~1 ms per 100k points); the kernels only ever see the
 // sorted arrays, so spatially close points share wavefronts / workgroups / hash-table neighbourhoods.
 #pragma once
 #include <math.h>
@@ -21,6 +21,24 @@ inline uint64_t spread21(uint64_t v) {  // 21 bits -> every third bit
     return v;
 }
 
+// LSD radix sort of 64-bit keys, 11 bits per pass, only over the bits that are in use
+inline void radix_sort_u64(std::vector<uint64_t>& key, int used_bits) {
+    std::vector<uint64_t> tmp(key.size());
+    uint64_t* a = key.data();
+    uint64_t* b = tmp.data();
+    const size_t n = key.size();
+    for (int shift = 0; shift < used_bits; shift += 11) {
+        size_t count[2049] = {0};
+        for (size_t i = 0; i < n; ++i) ++count[((a[i] >> shift) & 2047) + 1];
+        for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
+        for (size_t i = 0; i < n; ++i) b[count[(a[i] >> shift) & 2047]++] = a[i];
+        std::swap(a, b);
+    }
+    if (a != key.data()) key.swap(tmp);
+}
+
+// The Morton code and the point's index share one 64-bit key (code in the high bits, as many bits per axis as the
+// index leaves room for, at most 21), so the sort moves plain integers and ties keep the input order.
 template <typename T>
 std::vector<int> morton_order(const T* pts, int64_t n, int dim) {
     double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -31,16 +49,20 @@ std::vector<int> morton_order(const T* pts, int64_t n, int dim) {
         }
     double ext = 0.0;
     for (int k = 0; k < dim; ++k) ext = std::max(ext, hi[k] - lo[k]);
-    const double scale = ext > 0.0 ? 2097151.0 / ext : 0.0;  // one isotropic 21-bit grid
+    int idx_bits = 1;
+    while (((int64_t)1 << idx_bits) < n) ++idx_bits;
+    const int axis_bits = std::min(21, (64 - idx_bits) / 3);  // spread21 interleaves for three axes whatever dim is
+    const double scale = ext > 0.0 ? (double)(((uint64_t)1 << axis_bits) - 1) / ext : 0.0;  // one isotropic grid
     std::vector<uint64_t> key((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         uint64_t code = 0;
         for (int k = 0; k < dim; ++k) code |= spread21((uint64_t)(((double)pts[i * dim + k] - lo[k]) * scale)) << k;
-        key[i] = code;
+        key[i] = code << idx_bits | (uint64_t)i;
     }
+    radix_sort_u64(key, idx_bits + 3 * axis_bits);
     std::vector<int> perm((size_t)n);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return key[a] < key[b]; });
+    const uint64_t idx_mask = ((uint64_t)1 << idx_bits) - 1;
+    for (int64_t i = 0; i < n; ++i) perm[i] = (int)(key[i] & idx_mask);
     return perm;
 }
 
