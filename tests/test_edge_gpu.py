@@ -131,3 +131,44 @@ def test_bcpd_two_dimensional_and_w0():
         assert trans.rigid_trans.rot.shape == (2, 2)
         assert rel_err(trans.transform(src), ts) < TOL_TF
         assert abs(trans.rigid_trans.scale - res.scale) < TOL_TF
+
+
+@pytest.mark.parametrize("workload", ["C1_rigid_100k", "C2_affine_200k"])
+def test_full_size_identities_through_every_regime(workload):
+    """BASELINE configs at full size, 30 EM iterations (dense -> mid -> late: the culled sweeps end up skipping 97 %
+    of the blocks).  With w = 0 every column of P sums to one, so after EVERY E-step n_p = N, sum_m px_m = sum_n x_n
+    and sum_n pt1_n |x_n|^2 = sum_n |x_n|^2 - size-independent checks of the whole E-step; the M-step must keep the
+    rotation orthonormal (rigid) and sigma2 must fall monotonically on this data."""
+    from probreg_amd import _lib, synthetic
+    from probreg_amd.engine import CpdPlan
+
+    if workload.startswith("C1"):
+        n, kind = 100000, _lib.PRG_TF_RIGID
+        src, tgt, _ = synthetic.rigid_pair(n, seed=0)
+    else:
+        n, kind = 200000, _lib.PRG_TF_AFFINE
+        src, tgt, _ = synthetic.affine_pair(n, seed=0)
+    s32, t32 = (src - src.mean(0)).astype(np.float32), (tgt - tgt.mean(0)).astype(np.float32)
+    t64 = t32.astype(np.float64)
+    sx, sxx = t64.sum(0), np.sum(t64 * t64)
+    plan = CpdPlan()
+    plan.set_source(s32)
+    plan.set_target(t32)
+    plan.init_sums()
+    plan.init_params(None)
+    prev = np.inf
+    for it in range(30):
+        plan.estep(0.0)
+        mom = plan.get_moments()
+        assert abs(mom[0] - n) < 3e-6 * n, (it, mom[0])
+        assert np.max(np.abs(mom[1:4] - sx)) < 3e-6 * n, it
+        assert abs(mom[22] - sxx) < 3e-6 * sxx, it
+        plan.mstep(kind, True)
+        p = plan.get_params()
+        assert p[13] < prev
+        prev = p[13]
+        if kind == _lib.PRG_TF_RIGID:
+            rot = p[:9].reshape(3, 3)
+            assert np.allclose(rot @ rot.T, np.eye(3), atol=1e-12)
+    assert prev < 2e-4
+    plan.close()
