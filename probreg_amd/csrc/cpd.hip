@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double p1 = 0, u[3] = {0, 0, 0}, e = 0;
         // (128-row wave block, segment) partials the culled row pass never touched are absent (neither written nor
-        // read): the wave fetches its block's 64 flag bytes once and walks the set bits (<= 64 segments)
+        // read): the wave fetches its block's 64 flag bytes once and walks the set bits (<= 64 planes)
         uint64_t live = nseg >= 64 ? ~0ull : ((1ull << nseg) - 1ull);
         if (rowflag) {
             const int wb = __builtin_amdgcn_readfirstlane((int)(i >> 7));

@@ -24,7 +24,7 @@ def _check(kind, res, p, s2):
 
 @pytest.mark.parametrize("m,n", [(127, 129), (128, 128), (513, 255), (1025, 2047), (2049, 511)])
 def test_registration_across_tile_boundaries(m, n):
-    """Cloud sizes just below / at / above the 128-point wave tiles, 256-point super-groups and 512-point segments."""
+    """Cloud sizes just below / at / above the 128-point wave tiles, 256-point segment quantum and 512-point segments."""
     from oracle import cpd_numpy as co
     from probreg_amd import cpd, synthetic
 
