@@ -258,6 +258,10 @@ class AffineCPD(CoherentPointDrift):
     def _result_from_params(self, params):
         dim = self._source.shape[1]
         b = params[:9].reshape(3, 3)[:dim, :dim].copy()
+        if not np.all(np.isfinite(b)):
+            # Y^T diag(P1) Y is singular (fewer than D + 1 supported source points, or coplanar ones): the
+            # reference's np.linalg.solve (cpd.py:237) raises here, the device solve leaves non-finite numbers
+            raise np.linalg.LinAlgError("Singular matrix")
         t = params[9:9 + dim] + self._cx - b @ self._cy
         return MstepResult(tf.AffineTransformation(b, t), float(params[13]), float(params[14]))
 

@@ -199,3 +199,15 @@ def test_million_point_clouds():
         assert ms["total"] < 1000.0  # ~400 ms on an MI355X
         plan.mstep(_lib.PRG_TF_RIGID, True)
     plan.close()
+
+
+def test_singular_affine_raises_like_the_reference():
+    """Two source points cannot determine a 2-D affine map: np.linalg.solve raises in the reference (cpd.py:237),
+    the device solve leaves non-finite numbers, and the wrapper turns those into the same exception."""
+    from probreg_amd import cpd
+
+    rng = np.random.default_rng(0)
+    src = rng.normal(size=(2, 2))
+    tgt = rng.normal(size=(300, 2))
+    with pytest.raises(np.linalg.LinAlgError):
+        cpd.registration_cpd(src, tgt, "affine", maxiter=5, tol=-1.0)
