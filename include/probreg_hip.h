@@ -140,8 +140,10 @@ int prg_cpd_get_tsource(prg_cpd* h, float* tsource_hd);
  * (float64, host or device), rebuilds MOMENTS[0..22] on the device, no M-step yet. */
 int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p1_hd, const double* px_hd);
 
-/* Tuning knobs (0 keeps the current / automatic value): points per lane (2 or 4) and the
- * number of segments the reduction axis is split into, for the column and row pass. */
+/* Tuning knobs (0 keeps the automatic value): points per lane (2 or 4 select the non-culled packed sweeps, -2 / -4
+ * their scalar form; 0 = automatic, which is also the only setting that uses the culled sweeps) and the number of
+ * segments (<= 256) the streamed axis is split into, for the column and the row pass.  The culled sweeps evaluate
+ * four consecutive segments per workgroup, so S segments occupy ceil(S / 4) partial planes. */
 int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_row);
 
 /* ---- non-rigid CPD ------------------------------------------------------------------- */
