@@ -285,8 +285,8 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
             if (p[k].y != 0.f) ssum += (double)(p[k].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, p[k].x)));
     }
     const double den = ssum * exp2(-(double)goff);  // underflows to 0 exactly where fp64 exp() does
-    double c = pow(2.0 * M_PI * sigma2, dim * 0.5);
-    c *= w / (1.0 - w) * m_over_n;
+    double c = 0.0;  // uniform (outlier) term of cpd.py:78-79; w == 0 is the common case and fp64 pow() is not free
+    if (w > 0.0) c = pow(2.0 * M_PI * sigma2, dim * 0.5) * (w / (1.0 - w) * m_over_n);
     float p;
     if (den == 0.0) {
         b = -INFINITY;
