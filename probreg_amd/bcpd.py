@@ -214,24 +214,26 @@ class CombinedBCPD(BayesianCoherentPointDrift):
         # v_hat = s2s2 Sigma diag(nu) residual and diag(Sigma), Sigma = (lmd G^-1 + s2s2 diag(nu))^-1   (bcpd.py:123-129)
         v_hat, sigma_diag = self._plan.bcpd_solve(self.lmd, s2s2, residual, nu)
         u_hat = source + v_hat
+        # mixing weights (bcpd.py:130): alpha_m = exp(psi(k + nu_m) - psi(k M + N_p))
         alpha = np.exp(spsp.psi(self.k + nu_v) - spsp.psi(self.k * m + n_p))
-        x_m = np.sum(nu_v * x_hat.T, axis=1) / n_p
-        sigma2_m = np.sum(nu_v * sigma_diag) / n_p
-        u_m = np.sum(nu_v * u_hat.T, axis=1) / n_p
-        u_hm = u_hat - u_m
-        s_xu = np.matmul(np.multiply(nu_v, (x_hat - x_m).T), u_hm) / n_p
-        s_uu = np.matmul(np.multiply(nu_v, u_hm.T), u_hm) / n_p + sigma2_m * np.identity(dim)
-        phi, _, psih = np.linalg.svd(s_xu, full_matrices=True)
-        c = np.ones(dim)
-        c[-1] = np.linalg.det(np.dot(phi, psih))
-        rot = np.matmul(phi * c, psih)
-        tr_rsxu = np.trace(np.matmul(rot, s_xu))
-        scale = tr_rsxu / np.trace(s_uu)
-        t = x_m - scale * np.dot(rot, u_m)
-        y_hat = rigid_trans.transform(source + v_hat)  # (sic) the previous similarity, bcpd.py:145
-        s1 = np.dot(nu_d, np.sum(np.square(target), axis=1))
-        s2 = np.sum(px * y_hat)
-        s3 = np.dot(nu_v, np.sum(np.square(y_hat), axis=1))
+        # similarity from the nu-weighted first and second moments of (x_hat, u_hat)   (bcpd.py:131-143)
+        wts = nu_v / n_p
+        x_m, u_m = wts @ x_hat, wts @ u_hat
+        sigma2_m = float(wts @ sigma_diag)
+        xc, uc = x_hat - x_m, u_hat - u_m
+        s_xu = (xc * wts[:, None]).T @ uc
+        s_uu = (uc * wts[:, None]).T @ uc + sigma2_m * np.identity(dim)
+        left, _, right_t = np.linalg.svd(s_xu, full_matrices=True)
+        flip = np.ones(dim)
+        flip[-1] = np.linalg.det(left @ right_t)          # keep det(rot) = +1
+        rot = (left * flip) @ right_t
+        scale = np.trace(rot @ s_xu) / np.trace(s_uu)      # (sic) rot, not rot.T - as the reference, bcpd.py:141
+        t = x_m - scale * (rot @ u_m)
+        # residual variance against the PREVIOUS similarity applied to y + v_hat (sic, bcpd.py:145-150)
+        y_hat = rigid_trans.transform(u_hat)
+        s1 = nu_d @ np.einsum("nd,nd->n", target, target)
+        s2 = np.einsum("md,md->", px, y_hat)
+        s3 = nu_v @ np.einsum("md,md->m", y_hat, y_hat)
         sigma2 = (s1 - 2.0 * s2 + s3) / (n_p * dim) + scale ** 2 * sigma2_m
         return MstepResult(tf.CombinedTransformation(rot, t, scale, v_hat), u_hat, sigma_diag, alpha, sigma2)
 
