@@ -1,15 +1,26 @@
 #!/usr/bin/env python
-"""Benchmark of the CPD EM hot path on MI355X.
+"""Benchmark of the CPD / FilterReg EM hot path on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one EM iteration (transform + E-step column pass + E-step row pass + fp64 moment
-reduction + [all-reduce] + device M-step) of RigidCPD on BASELINE.json's config C1: synthetic
-N = M = 100 000 3-D points, fp32 pair arithmetic, w = 0.  With N GPUs the SAME problem is solved
-with the target cloud sharded over the ranks ("scaling": "strong"); one all-reduce of 32 doubles
-per iteration.  Inputs are resident in HBM before the timed region.  Rank 0 prints one JSON line.
+A "step" is one EM iteration (transform + E-step column pass + E-step row pass + fp64 moment reduction +
+[all-reduce] + device M-step) of RigidCPD on BASELINE.json's config C1: synthetic N = M = 100 000 3-D points, fp32 pair
+arithmetic, w = 0.  With N GPUs the SAME problem is solved with the target cloud sharded over the ranks ("scaling":
+"strong"); one all-reduce of 32 doubles per iteration.  Inputs are resident in HBM before the timed region.
+
+THE TIMED WINDOW IS PINNED: the E-step's cost depends on sigma2 (the sweeps skip blocks whose every pair is an exact
+fp32 zero), so after the W warm-up steps the EM state is put back to the start of the registration and the K timed
+steps are EM iterations 0 .. K-1 of that registration - `--warmup` cannot move the headline.  The line also carries
+`dense_it_s` (iteration 0 alone: every pair evaluated), `late_it_s` (iterations 45..49) and `trajectory_it_s` (= value).
+
+Rank 0 prints ONE JSON line.  With the defaults (1 GPU, C1) it also carries
+  roofline        binding roofline of the dominant kernel (row pass): fp32 VALU, from the pairs the kernel actually
+                  evaluated (device counters) x its flop per pair, HIP-event timed on the plan's stream
+  parity          GPU vs the CPU oracle on the cpu_baseline sample (same inputs, same iterations)
+  cpu_baseline    oracle/cpd_estep_c.c timed on the host cores at three sizes, fitted t = a M N
+  other_workloads C2 (affine 200k), C3 (non-rigid 50k), C4 (FilterReg 500k) measured the same way, each with its roofline
 """
 import argparse
 import json
@@ -23,7 +34,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # HBM3E 8 TB/s
+VALU_F32_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
+F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64
+
+# Flop per EVALUATED source-target pair, counted from the kernels' instruction mix (fma = 2, everything else = 1):
+#   row pass   3 sub + 3 fma (d2) + 1 fma (exponent) + 1 exp + 1 add (p1) + 4 fma (u, e)            = 21
+#   col pass   3 sub + 3 fma (d2) + 1 min + 1 fma (exponent) + 1 exp + 1 add (sum)                  = 14
+FLOP_ROW, FLOP_COL = 21.0, 14.0
 
 WORKLOADS = {
     # name: (kind, N = M, description)
@@ -34,50 +53,241 @@ WORKLOADS = {
     "bcpd_20k": ("bcpd", 20000, "BCPD (SURVEY 8f rank 4) fp32 E-step / fp64 M-step synthetic N=M=20000 lmd=2 w=0.05"),
     "rigid_20k": ("rigid", 20000, "reduced RigidCPD fp32 synthetic N=M=20000 (debug only)"),
 }
-F64_MFMA_PEAK_TFLOPS = 78.6  # MI355X f64 matrix peak (v_mfma_f64_16x16x4_f64, 32 FLOP/clk/SIMD at 2.4 GHz)
+
+# the UNMODIFIED reference NumPy path (stub import) probed at survey time on the 8-vCPU build
+# container - it cannot run on the GPU box (/root/reference does not exist there), so it rides along as a constant.
+REFERENCE_NUMPY_PROBE = {
+    "what": "reference probreg RigidCPD NumPy path, EM iterations/s (maxiter=20, tol=0), 8 vCPU Xeon 2.1 GHz (BASELINE.md 2)",
+    "it_s_at_n_eq_m": {"1000": 19.95, "3000": 5.10, "6000": 0.99},
+    "extrapolated_s_per_iteration_at_100k": 225.0,
+}
 
 
-def cpu_baseline(n_full):
-    """Oracle timed on the host cores on a bounded sample of the same workload (rank 0, N=1 only)."""
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline (oracle, rank 0 / N = 1 only) and the parity block that rides on the same sample
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline_and_parity(n_full, kind="rigid"):
+    """C oracle timed at three sizes (fit t_iter = a M N) + GPU-vs-oracle parity on the largest sample."""
     from oracle import cpd_c, cpd_numpy as co
-    from probreg_amd import synthetic
+    from probreg_amd import cpd, synthetic
 
-    ns = 40000
-    src, tgt, _ = synthetic.rigid_pair(ns, seed=0)
-    sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
-    params = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
-    iters = 2
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        ts = co.transform("rigid", params, src)
-        es = co.EstepResult(*cpd_c.expectation_step(ts, tgt, sigma2, 0.0))
-        params, sigma2, _q = co.mstep_rigid(src, tgt, es)
-    dt = (time.perf_counter() - t0) / iters
-    scale = (float(n_full) * n_full) / (float(ns) * ns)
-    return {
-        "value": 1.0 / (dt * scale),
+    sizes, iters = (10000, 20000, 40000), 2
+    per_iter, last = [], None
+    for ns in sizes:
+        src, tgt, _ = synthetic.rigid_pair(ns, seed=0)
+        sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
+        params = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            ts = co.transform("rigid", params, src)
+            es = co.EstepResult(*cpd_c.expectation_step(ts, tgt, sigma2, 0.0))
+            params, sigma2, _q = co.mstep_rigid(src, tgt, es)
+        per_iter.append((time.perf_counter() - t0) / iters)
+        last = (src, tgt, params, sigma2)
+    mn = np.array([float(s) * s for s in sizes])
+    t = np.array(per_iter)
+    a = float(np.sum(t * mn) / np.sum(mn * mn))  # least squares through the origin
+    resid = [float(ti / (a * x) - 1.0) for ti, x in zip(t, mn)]
+    baseline = {
+        "value": 1.0 / (a * float(n_full) * n_full),
         "unit": "EM iterations/s",
         "cores": cpd_c.threads(),
         "kind": "port",
-        "sample": "oracle/cpd_estep_c.c (C/OpenMP fp64 restatement of probreg cpd.py:71-88) + numpy M-step, "
-                  "RigidCPD N=M=%d, %d iterations, %.2f s/iteration measured, scaled by M*N (x%.2f) to N=M=%d"
-                  % (ns, iters, dt, scale, n_full),
-        "measured_iter_s_at_sample": 1.0 / dt,
+        "sample": "oracle/cpd_estep_c.c (C/OpenMP fp64 restatement of probreg cpd.py:71-88) + numpy M-step, RigidCPD "
+                  "N=M in {10k, 20k, 40k}, %d iterations each; fit t_iter = a*M*N, value = 1/(a*%d^2) (extrapolated)"
+                  % (iters, n_full),
+        "fit": {"a_seconds_per_pair": a, "sizes": list(sizes), "s_per_iteration": per_iter,
+                "relative_residuals": resid},
+        "reference_numpy_probe": REFERENCE_NUMPY_PROBE,
     }
+    # parity: the product on the SAME 40k input for the SAME number of iterations
+    src, tgt, p, s2 = last
+    res = cpd.registration_cpd(src, tgt, "rigid", maxiter=iters, tol=-1.0)
+    tr = res.transformation
+    parity = {
+        "against": "oracle (C E-step + numpy M-step, fp64) on synthetic.rigid_pair(%d, seed=0), %d EM iterations"
+                   % (sizes[-1], iters),
+        "rot_max_abs_err": float(np.max(np.abs(tr.rot - p["rot"]))),
+        "t_max_abs_err": float(np.max(np.abs(tr.t - p["t"]))),
+        "scale_rel_err": float(abs(tr.scale - p["scale"]) / abs(p["scale"])),
+        "sigma2_rel_err": float(abs(res.sigma2 - s2) / s2),
+        "tolerance": {"transform": 1e-4, "sigma2": 1e-5},
+        "full_size": "tests/test_fullsize_gpu.py holds C1 (100k, dense + late regime), C2 (200k), C3 (12k) and C4 (500k) "
+                     "to the oracle at the same tolerances",
+    }
+    parity["ok"] = bool(parity["rot_max_abs_err"] < 1e-4 and parity["t_max_abs_err"] < 1e-4
+                        and parity["scale_rel_err"] < 1e-4 and parity["sigma2_rel_err"] < 1e-5)
+    return baseline, parity
 
 
-def _base(args, metric, value, elapsed, desc, dtype):
-    return {"metric": metric, "value": value, "unit": "EM iterations/s", "n_gpus": 1, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+def _pmc_traffic(workload, key):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(path):
+        try:
+            return json.load(open(path)).get(workload, {}).get(key)
+        except Exception:
+            return None
+    return None
+
+
+def _base(metric, value, elapsed, steps, warmup, desc, dtype, world=1):
+    return {"metric": metric, "value": value, "unit": "EM iterations/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": desc}}
 
 
-def bench_nonrigid(args, n, desc):
-    """C3: one step = E-step (fp32 sweeps) + fp64 Cholesky M-step (cpd.py:284-303)."""
+# ----------------------------------------------------------------------------------------------------------------
+# C1 / C2: rigid / affine CPD
+# ----------------------------------------------------------------------------------------------------------------
+def bench_cpd(workload, steps, warmup, tuning=""):
+    import torch
+    from probreg_amd import _lib, cpd, synthetic
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    kind, n, desc = WORKLOADS[workload]
+    if kind == "rigid":
+        src, tgt, truth = synthetic.rigid_pair(n, seed=0)
+        reg = cpd.RigidCPD(src)
+        kind_id = _lib.PRG_TF_RIGID
+    else:
+        src, tgt, truth = synthetic.affine_pair(n, seed=0)
+        reg = cpd.AffineCPD(src)
+        kind_id = _lib.PRG_TF_AFFINE
+    reg._initialize(tgt)  # upload (target rows sharded over ranks), sigma2 initialiser
+    plan = reg._plan
+    if tuning:
+        plan.set_tuning(*[int(v) for v in tuning.split(",")])
+
+    def step():
+        plan.estep(0.0)
+        reg._all_reduce_moments(plan)
+        plan.mstep(kind_id, True)
+
+    def fence():
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def timed(k):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(warmup):
+        step()
+    reg._restart()                 # EM state back to iteration 0: the timed window is iterations 0 .. steps-1
+    elapsed = timed(steps)
+    res = reg._result_from_params(plan.get_params())
+
+    # regimes: iteration 0 alone (every pair evaluated) and iterations 45..49 (sigma2 ~ noise level: ~97 % culled)
+    reg._restart()
+    t_dense = timed(1)
+    for _ in range(44):
+        step()
+    t_late = timed(5) / 5.0
+
+    # Per-kernel timing with HIP events on the plan's stream + the device counters of evaluated pairs: the SAME
+    # iterations 0 .. steps-1 replayed (their duration depends on sigma2, so they are averaged over the trajectory
+    # the timed region walked).
+    reg._restart()
+    acc, first, last = {}, None, None
+    pairs_row = pairs_col = 0.0
+    first_pairs = last_pairs = None
+    for _ in range(steps):
+        ms = plan.estep_timed(0.0)
+        pc, pr = plan.pair_counts()
+        reg._all_reduce_moments(plan)
+        plan.mstep(kind_id, True)
+        if first is None:
+            first, first_pairs = dict(ms), (pc, pr)
+        last, last_pairs = dict(ms), (pc, pr)
+        pairs_col += pc
+        pairs_row += pr
+        for k, v in ms.items():
+            acc[k] = acc.get(k, 0.0) + v / steps
+    if rank != 0:
+        return None
+
+    m_pts, n_loc = plan.m, plan.n
+    row_s_total, col_s_total = acc["rowpass"] * 1e-3 * steps, acc["colpass"] * 1e-3 * steps
+    row_tf = pairs_row * FLOP_ROW / row_s_total / 1e12
+    col_tf = pairs_col * FLOP_COL / col_s_total / 1e12
+    dense_row_tf = first_pairs[1] * FLOP_ROW / (first["rowpass"] * 1e-3) / 1e12
+    dense_col_tf = first_pairs[0] * FLOP_COL / (first["colpass"] * 1e-3) / 1e12
+    # SURVEY.md 8(d) figure kept beside it: algorithmic bytes of the reference's formulation at fp32 (P written once
+    # by the column pass, read once by the row pass) over the measured time - an EFFECTIVE rate, not a roofline
+    alg_row = 4.0 * m_pts * n_loc + 4.0 * (m_pts + n_loc) * 5
+    out = _base("EM iterations/sec (RigidCPD, N=M=100k fp32)" if workload == "rigid_100k"
+                else "EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, steps, warmup, desc, "f32", world)
+    out["config"].update({
+        "window": "EM iterations 0..%d of the registration (state reset after the warm-up steps)" % (steps - 1),
+        "target_sharding": "contiguous runs of the target's Morton order over %d rank(s)" % world,
+        "collective": "1 all-reduce of 32 fp64 per iteration" if world > 1 else "none",
+        "m": m_pts, "n_local": n_loc, "n_global": n})
+    out["trajectory_it_s"] = steps / elapsed
+    out["dense_it_s"] = 1.0 / t_dense
+    out["late_it_s"] = 1.0 / t_late
+    out["roofline"] = {
+        "bound": "valu",
+        "kernel": "k_rowpass_cull (E-step sweep 2: P1, PX, sigma2 residual)",
+        "achieved": row_tf,
+        "peak": VALU_F32_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": row_tf / VALU_F32_PEAK_TFLOPS,
+        "traffic": _pmc_traffic(workload, "rowpass_hbm_bytes_per_launch"),
+        "how": "flop = pairs the kernel evaluated (per-workgroup device counters, prg_cpd_pair_counts) x %g flop/pair; "
+               "time = HIP events on the plan's stream; both summed over the %d timed-window iterations" % (FLOP_ROW, steps),
+        "avg_launch_ms": acc["rowpass"],
+        "pairs_evaluated_per_launch": pairs_row / steps,
+        "pairs_total_per_launch": float(m_pts) * n_loc,
+        "evaluated_fraction": pairs_row / steps / (float(m_pts) * n_loc),
+        "dense_regime": {"what": "iteration 0: sigma2 large, every (wave, group) block evaluated",
+                         "rowpass": {"ms": first["rowpass"], "pairs": first_pairs[1], "achieved": dense_row_tf,
+                                     "frac": dense_row_tf / VALU_F32_PEAK_TFLOPS},
+                         "colpass": {"ms": first["colpass"], "pairs": first_pairs[0], "achieved": dense_col_tf,
+                                     "frac": dense_col_tf / VALU_F32_PEAK_TFLOPS}},
+        "late_regime": {"what": "iteration %d of the window" % (steps - 1),
+                        "rowpass": {"ms": last["rowpass"], "pairs": last_pairs[1],
+                                    "frac": last_pairs[1] * FLOP_ROW / (last["rowpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS},
+                        "colpass": {"ms": last["colpass"], "pairs": last_pairs[0],
+                                    "frac": last_pairs[0] * FLOP_COL / (last["colpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS}},
+        "colpass": {"achieved": col_tf, "frac": col_tf / VALU_F32_PEAK_TFLOPS, "avg_launch_ms": acc["colpass"],
+                    "pairs_evaluated_per_launch": pairs_col / steps, "flop_per_pair": FLOP_COL},
+        "effective_hbm": {"what": "SURVEY 8(d) algorithmic bytes (P written once + read once at fp32 = 4 M N per sweep "
+                                  "launch) / measured time; the fused sweeps never store P, so this is an effective "
+                                  "rate to set beside the 8 TB/s HBM peak, not a fraction of a binding roofline",
+                          "algorithmic_bytes_per_launch": alg_row,
+                          "rowpass_GBs": alg_row / (acc["rowpass"] * 1e-3) / 1e9,
+                          "e_step_GBs": 2.0 * alg_row / (acc["total"] * 1e-3) / 1e9,
+                          "hbm_peak_GBs": HBM_PEAK_GBS},
+    }
+    out["kernel_ms"] = {"mean_over_timed_iterations": acc, "first_timed_iteration": first, "last_timed_iteration": last}
+    out["result"] = {"sigma2": res.sigma2, "q": res.q}
+    if kind == "rigid":
+        r_true, _t_true, _ = truth
+        out["result"]["rot_err_vs_truth"] = float(np.max(np.abs(res.transformation.rot - r_true)))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# C3: non-rigid CPD
+# ----------------------------------------------------------------------------------------------------------------
+def bench_nonrigid(workload, steps, warmup):
+    """One step = E-step (fp32 sweeps) + fp64 Cholesky M-step (cpd.py:284-303)."""
     import torch
     from probreg_amd import cpd, synthetic
 
+    _kind, n, desc = WORKLOADS[workload]
     src, tgt = synthetic.nonrigid_pair(n, seed=0)
     reg = cpd.NonRigidCPD(src)
     reg._initialize(tgt)
@@ -87,11 +297,11 @@ def bench_nonrigid(args, n, desc):
         plan.estep(0.0)
         plan.mstep_nonrigid(2.0)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -103,7 +313,7 @@ def bench_nonrigid(args, n, desc):
     torch.cuda.synchronize()
     t_m = time.perf_counter() - t0
     flops = n ** 3 / 3.0 + 3 * 2.0 * n * n * 3   # Cholesky + three G-times-(M x 3) products
-    out = _base(args, "EM iterations/sec (%s)" % desc, args.steps / elapsed, elapsed, desc, "f32 E-step / f64 M-step")
+    out = _base("EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, steps, warmup, desc, "f32 E-step / f64 M-step")
     out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_nt_f64 (blocked Cholesky of S = cI + D^1/2 G D^1/2)",
                        "achieved": flops / t_m / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / t_m / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -112,19 +322,20 @@ def bench_nonrigid(args, n, desc):
     return out
 
 
-def bench_bcpd(args, n, desc):
+def bench_bcpd(workload, steps, warmup):
     """BCPD: one step = weighted E-step + Woodbury M-step (bcpd.py:82-98 loop body without the convergence test)."""
     import torch
     from probreg_amd import bcpd, synthetic
 
+    _kind, n, desc = WORKLOADS[workload]
     src, tgt = synthetic.nonrigid_pair(n, seed=0)
     src, tgt = src * 10.0, tgt * 10.0  # object ~20 units across: the c = 1 inverse-multiquadric kernel has a sensible width
     reg = bcpd.CombinedBCPD(src)
     stamps = []
     reg.set_callbacks([lambda tr: (torch.cuda.synchronize(), stamps.append(time.perf_counter()))])
-    reg.registration(tgt, w=0.05, maxiter=args.warmup + args.steps, tol=-1.0)
-    elapsed = stamps[-1] - stamps[args.warmup - 1] if args.warmup > 0 else stamps[-1] - stamps[0]
-    steps = args.steps if args.warmup > 0 else args.steps - 1
+    reg.registration(tgt, w=0.05, maxiter=warmup + steps, tol=-1.0)
+    elapsed = stamps[-1] - stamps[warmup - 1] if warmup > 0 else stamps[-1] - stamps[0]
+    nsteps = steps if warmup > 0 else steps - 1
     plan = reg._plan
     nu, resid = np.ones(n), np.zeros((n, 3))
     plan.bcpd_solve(2.0, 10.0, resid, nu)
@@ -134,9 +345,7 @@ def bench_bcpd(args, n, desc):
     torch.cuda.synchronize()
     t_m = time.perf_counter() - t0
     flops = 4.0 / 3.0 * n ** 3  # Cholesky (1/3) + triangular solve with M right-hand sides (1)
-    out = _base(args, "EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, desc, "f32 E-step / f64 M-step")
-    out["steps"] = steps
-    out["ms_per_step"] = 1e3 * elapsed / steps
+    out = _base("EM iterations/sec (%s)" % desc, nsteps / elapsed, elapsed, nsteps, warmup, desc, "f32 E-step / f64 M-step")
     out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_nt_f64 (Cholesky of S + triangular solve for diag(Sigma))",
                        "achieved": flops / t_m / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                        "frac": flops / t_m / 1e12 / F64_MFMA_PEAK_TFLOPS, "traffic": None,
@@ -144,43 +353,64 @@ def bench_bcpd(args, n, desc):
     return out
 
 
-def bench_filterreg(args, n, desc):
-    """C4: one step = lattice E-step + Kabsch M-step (filterreg.py:129-146), sigma2 updated every step."""
+# ----------------------------------------------------------------------------------------------------------------
+# C4: FilterReg
+# ----------------------------------------------------------------------------------------------------------------
+def bench_filterreg(workload, steps, warmup):
+    """One step = lattice E-step + Kabsch M-step (filterreg.py:129-146), sigma2 updated every step.  As for C1 the
+    window is pinned: the state goes back to the start of the registration after the warm-up steps."""
     import torch
     from probreg_amd import filterreg, math_utils as mu, synthetic
 
+    _kind, n, desc = WORKLOADS[workload]
     src, tgt, (r_true, _) = synthetic.filterreg_pair(n, seed=0)
     reg = filterreg.RigidFilterReg(src, update_sigma2=True)
     plan = reg._ensure_plan(tgt)
-    state = {"rot": np.identity(3), "t": np.zeros(3), "sigma2": max(mu.squared_kernel_sum(src, tgt), 1e-4)}
+    s2_0 = max(mu.squared_kernel_sum(src, tgt), 1e-4)
+    state = {}
     sizes = []
-
-    plan.set_state(state["rot"], state["t"], state["sigma2"])  # once: the M-step kernel advances the device state
 
     def step():
         size, _blur = plan.estep()
-        out = plan.mstep(0.05, True, "pt2pt", 1e-4)
-        state["rot"], state["t"], state["sigma2"] = out[:9].reshape(3, 3).copy(), out[9:12].copy(), out[12]
+        out = plan.mstep(0.05, True, "pt2pt", 1e-4)  # the M-step kernel advances the device state
+        state["rot"], state["sigma2"] = out[:9].reshape(3, 3).copy(), out[15]
         sizes.append(size)
 
-    for _ in range(args.warmup):
+    plan.set_state(np.identity(3), np.zeros(3), s2_0)
+    for _ in range(warmup):
         step()
+    plan.set_state(np.identity(3), np.zeros(3), s2_0)  # back to iteration 0
+    del sizes[:]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     d, c = 3, 5
-    lat = float(np.mean(sizes[args.warmup:]))
+    lat = float(np.mean(sizes))
     alg = (2 * n) * (4 * d + 8 * (d + 1)) + n * (4 * c + 8 * (d + 1) + 8 * c * (d + 1)) \
         + n * (8 * (d + 1) + 4 * c * (d + 1) + 4 * c) + (d + 1) * lat * c * 16
-    out = _base(args, "EM iterations/sec (%s)" % desc, args.steps / elapsed, elapsed, desc, "f32 lattice / f64 M-step")
+    out = _base("EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, steps, warmup, desc, "f32 lattice / f64 M-step")
+    out["config"]["window"] = "EM iterations 0..%d of the registration (state reset after the warm-up steps)" % (steps - 1)
     out["roofline"] = {"bound": "hbm", "kernel": "whole lattice E-step (embed, hash, splat, blur, slice)",
-                       "achieved": alg / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": alg / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                       "algorithmic_bytes_per_iteration": alg, "mean_lattice_vertices": lat}
+                       "achieved": alg / (elapsed / steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": alg / (elapsed / steps) / 1e9 / HBM_PEAK_GBS,
+                       "traffic": _pmc_traffic(workload, "iteration_hbm_bytes"),
+                       "algorithmic_bytes_per_iteration": alg, "mean_lattice_vertices": lat,
+                       "lattice_vertices_first_last": [sizes[0], sizes[-1]]}
     out["result"] = {"sigma2": state["sigma2"], "rot_err_vs_truth": float(np.max(np.abs(state["rot"] - r_true)))}
+    return out
+
+
+def _slim(line):
+    """What an `other_workloads` entry keeps of a workload's own line."""
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "result",
+            "dense_it_s", "late_it_s")
+    out = {k: line[k] for k in keep if k in line}
+    rf = out.get("roofline", {})
+    for k in ("how", "effective_hbm", "late_regime"):
+        rf.pop(k, None)
     return out
 
 
@@ -190,7 +420,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="rigid_100k", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the parity block")
+    ap.add_argument("--no-other-workloads", action="store_true", help="C1 only (skip the C2 / C3 / C4 entries)")
     ap.add_argument("--tuning", default="", help="r_col,seg_col,r_row,seg_row (0 = auto)")
     args = ap.parse_args()
 
@@ -217,131 +448,28 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from probreg_amd import _lib, cpd, synthetic
-
     kind, n, desc = WORKLOADS[args.workload]
     if kind in ("nonrigid", "filterreg", "bcpd"):
         if world > 1:
             raise SystemExit("%s runs as single-GPU replicas (DESIGN.md section 6)" % args.workload)
-        out = {"nonrigid": bench_nonrigid, "filterreg": bench_filterreg, "bcpd": bench_bcpd}[kind](args, n, desc)
+        out = {"nonrigid": bench_nonrigid, "filterreg": bench_filterreg, "bcpd": bench_bcpd}[kind](
+            args.workload, args.steps, args.warmup)
         print(json.dumps(out))
         return
-    if kind == "rigid":
-        src, tgt, truth = synthetic.rigid_pair(n, seed=0)
-        reg = cpd.RigidCPD(src)
-        kind_id = _lib.PRG_TF_RIGID
-    else:
-        src, tgt, truth = synthetic.affine_pair(n, seed=0)
-        reg = cpd.AffineCPD(src)
-        kind_id = _lib.PRG_TF_AFFINE
-    reg._initialize(tgt)  # upload (target rows sharded over ranks), sigma2 initialiser
-    plan = reg._plan
-    if args.tuning:
-        plan.set_tuning(*[int(v) for v in args.tuning.split(",")])
-
-    def step():
-        plan.estep(0.0)
-        reg._all_reduce_moments(plan)
-        plan.mstep(kind_id, True)
-
-    def fence():
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    start_params = plan.get_params()  # EM state at the start of the timed region (replayed below)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-    res = reg._result_from_params(plan.get_params())
-
-    # Per-kernel timing with HIP events on the plan's stream: the SAME K iterations replayed from the saved
-    # state (the sweeps skip provably-zero blocks, so their duration depends on sigma2 and must be averaged
-    # over the same trajectory the timed region walked).
-    plan.set_params(start_params)
-    acc, first = {}, None
-    for _ in range(args.steps):
-        ms = plan.estep_timed(0.0)
-        reg._all_reduce_moments(plan)
-        plan.mstep(kind_id, True)
-        first = first or dict(ms)
-        for k, v in ms.items():
-            acc[k] = acc.get(k, 0.0) + v / args.steps
-    last = dict(ms)
-
+    out = bench_cpd(args.workload, args.steps, args.warmup, args.tuning)
     if rank == 0:
-        m_pts, n_loc = plan.m, plan.n
-        # algorithmic bytes of the reference's formulation at fp32: P (M x N fp32) is written
-        # once by the column pass and read once by the row pass; + the clouds and the per-point outputs.
-        row_bytes = 4.0 * m_pts * n_loc + 4.0 * (m_pts + n_loc) * 5
-        col_bytes = 4.0 * m_pts * n_loc + 4.0 * (m_pts + n_loc) * 5
-        row_s, col_s = acc["rowpass"] * 1e-3, acc["colpass"] * 1e-3
-        achieved = row_bytes / row_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("rowpass_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "EM iterations/sec (RigidCPD, N=M=100k fp32)" if args.workload == "rigid_100k"
-                      else "EM iterations/sec (%s)" % desc,
-            "value": args.steps / elapsed,
-            "unit": "EM iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": desc, "target_sharding": "contiguous runs of the target's Morton order over %d rank(s)" % world,
-                       "collective": "1 all-reduce of 32 fp64 per iteration" if world > 1 else "none",
-                       "m": m_pts, "n_local": n_loc, "n_global": n},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k_rowpass (E-step sweep 2: P1, PX, sigma2 residual)",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": row_bytes,
-                "avg_launch_ms": acc["rowpass"],
-                "colpass": {"achieved": col_bytes / col_s / 1e9, "frac": col_bytes / col_s / 1e9 / HBM_PEAK_GBS,
-                            "avg_launch_ms": acc["colpass"]},
-                "e_step": {"algorithmic_bytes": row_bytes + col_bytes, "ms": acc["total"],
-                           "frac": (row_bytes + col_bytes) / (acc["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                "dense_regime": {"avg_launch_ms": first["rowpass"],
-                                 "frac": row_bytes / (first["rowpass"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                 "what": "first timed iteration: sigma2 still large, no (wave, group) block is "
-                                         "skipped - the sweep's VALU-bound throughput on all M x N pairs"},
-                "note": "algorithmic bytes = the reference formulation's irreducible fp32 traffic (8 B per "
-                        "source-target pair per E-step); the fused kernels keep P in registers and skip blocks "
-                        "whose every pair is an exact fp32 zero, so physical HBM traffic is MBs and the kernels "
-                        "are VALU/transcendental bound (DESIGN.md section 3.1)",
-            },
-            "kernel_ms": {"mean_over_timed_iterations": acc, "first_timed_iteration": first,
-                          "last_timed_iteration": last},
-            "result": {"sigma2": res.sigma2, "q": res.q},
-        }
-        if kind == "rigid":
-            r_true, t_true, _ = truth
-            out["result"]["rot_err_vs_truth"] = float(np.max(np.abs(res.transformation.rot - r_true)))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n)
+            out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(n)
+        if world == 1 and args.workload == "rigid_100k" and not args.no_other_workloads:
+            others = {}
+            for name, fn, k, w in (("affine_200k", bench_cpd, 5, 1), ("nonrigid_50k", bench_nonrigid, 2, 1),
+                                   ("filterreg_500k", bench_filterreg, 20, 3)):
+                try:
+                    others[name] = _slim(fn(name, k, w))
+                except Exception as e:  # a failing side workload must not take the headline line with it
+                    others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                torch.cuda.empty_cache()
+            out["other_workloads"] = others
         print(json.dumps(out))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()

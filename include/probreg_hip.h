@@ -118,6 +118,12 @@ int prg_cpd_estep(prg_cpd* h, double w);
  * (measurement hook for bench.py's `roofline` object; synchronises the stream) */
 int prg_cpd_estep_timed(prg_cpd* h, double w, float* ms_out);
 
+/* Measurement hook: source-target pairs the column / row pass of the LAST E-step actually evaluated.  The culled
+ * sweeps skip (wave, 32-point group) blocks whose every pair is an exact zero; each workgroup
+ * leaves its count of evaluated blocks (128 x 32 pairs each) in a device array that is summed here.  Dense
+ * launches report the pairs their grid covers (pads included).  Synchronises the stream. */
+int prg_cpd_pair_counts(prg_cpd* h, double* col_pairs, double* row_pairs);
+
 /* M-step from (all-reduced) MOMENTS into PARAMS; identical on every rank.
  * Replaces: RigidCPD._maximization_step cpd.py:160-192 (update_scale as there) and
  * AffineCPD._maximization_step cpd.py:219-244. */
@@ -137,7 +143,9 @@ int prg_cpd_get_tsource(prg_cpd* h, float* tsource_hd);
 
 /* M-step from explicitly supplied EstepResult arrays (the reference's public
  * maximization_step(target, estep_res) signature, cpd.py:90-93): uploads pt1/p1/px
- * (float64, host or device), rebuilds MOMENTS[0..22] on the device, no M-step yet. */
+ * (float64, host or device, caller's point order), rebuilds MOMENTS[0..22] on the device and the
+ * per-point (p1, px) block the non-rigid solve reads (NonRigidCPD.maximization_step, cpd.py:272-303:
+ * follow with prg_cpd_set_params(sigma2_p) and prg_cpd_mstep_nonrigid); no M-step yet. */
 int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p1_hd, const double* px_hd);
 
 /* Tuning knobs (0 keeps the automatic value): points per lane (2 or 4 select the non-culled packed sweeps, -2 / -4
@@ -251,8 +259,9 @@ int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd)
 /* M-step (weighted Kabsch + composition + optional sigma2 update).  out_host[18]: [0..8] rot, [9..11] t,
  * [12] sigma2 of the NEXT iteration, [13] q, [14] number of points with m0 != 0, [15] new (un-clamped) sigma2,
  * [16] 1 if a transform was estimated (0 = every m0 was zero: the reference returns q = None,
- * filterreg.py:167-168), [17] sigma2 this step used.  min_sigma2 > 0 advances the device state like the driver
- * (`self._sigma2 = max(res.sigma2, min_sigma2)`, filterreg.py:140) so the loop needs no upload per iteration.
+ * filterreg.py:167-168), [17] sigma2 this step used.  min_sigma2 >= 0 advances the device state like the driver
+ * (`self._sigma2 = max(res.sigma2, min_sigma2)`, filterreg.py:140) so the loop needs no upload per iteration;
+ * a negative min_sigma2 leaves the device sigma2 untouched (M-step only).
  * Replaces: RigidFilterReg._maximization_step filterreg.py:158-196 + cc/kabsch.cc:6-109. */
 int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host);
 
@@ -263,6 +272,17 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma
 int prg_fr_set_target_normals(prg_filterreg* h, const double* normals_hd);
 int prg_fr_get_nx(prg_filterreg* h, float* nx_hd);
 int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host);
+
+/* M-step from caller-supplied E-step arrays - the reference's public FilterReg.maximization_step(t_source, target,
+ * estep_res, w, objective_type) -> RigidFilterReg._maximization_step (filterreg.py:110-113, 158-196).  No handle:
+ * t_source [m x dim] float64; m0 [m], m1 [m x dim], m2 [m] (NULL = sigma2 is not re-estimated, filterreg.py:190),
+ * nx [m x 3] (non-NULL selects the point-to-plane objective, filterreg.py:183-186) float32; n_target enters the
+ * outlier constant (filterreg.py:164); rot9 / t3 / sigma2 = trans_p and the current variance.  out_host[18] as
+ * prg_fr_mstep ([12] repeats the input sigma2, [15] the new one). */
+int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_source_hd, int64_t m, int dim,
+                             int64_t n_target, const float* m0_hd, const float* m1_hd, const float* m2_hd,
+                             const float* nx_hd, const double* rot9, const double* t3, double sigma2, double w,
+                             double* out_host);
 
 /* Weighted Kabsch on float32 clouds: centroids weighted by w, covariance by w^2; rot_host dim x dim
  * row-major, t_host dim.  Replaces: _kabsch.kabsch / kabsch2d (cc/kabsch_py.cc, cc/kabsch.cc:6-109). */

@@ -30,6 +30,14 @@ int cpd_oracle_threads(void) {
 #endif
 }
 
+/* exp(a) for a < -745.2 is exactly 0.0 in IEEE double (the smallest subnormal is exp(-744.44); everything
+ * below -745.14 rounds to 0), so the call is skipped there - bit-identical to calling it, and what keeps a
+ * late-EM-iteration E-step (sigma2 ~ 1e-5: almost every pair underflows) affordable at N = M = 1e5. */
+static inline double exp_or_zero(double a) { return a < -745.2 ? 0.0 : exp(a); }
+
+#define TILE 512 /* streamed points kept in L1 while a block of owned points sweeps over them */
+#define OWN 64   /* owned points per work item */
+
 /* t_source: M x D, target: N x D (row-major float64); outputs pt1[N], p1[M], px[M x D]; returns n_p */
 double cpd_oracle_estep(const double* ts, int64_t m, const double* x, int64_t n, int d, double sigma2, double w,
                         double* pt1, double* p1, double* px) {
@@ -37,42 +45,72 @@ double cpd_oracle_estep(const double* ts, int64_t m, const double* x, int64_t n,
     double c = pow(2.0 * M_PI * sigma2, d * 0.5);
     c *= w / (1.0 - w) * (double)m / (double)n;
     double* den = (double*)malloc(sizeof(double) * (size_t)n);
-    double* kmass = (double*)malloc(sizeof(double) * (size_t)n);
-#pragma omp parallel for schedule(static)
-    for (int64_t j = 0; j < n; ++j) {
-        double s = 0.0;
-        for (int64_t i = 0; i < m; ++i) {
-            double d2 = 0.0;
-            for (int k = 0; k < d; ++k) {
-                const double df = ts[i * d + k] - x[j * d + k];
-                d2 += df * df;
+    /* sweep 1 (cpd.py:74-82): den_j = sum_i exp(-|ts_i - x_j|^2 / 2 sigma2), columns owned, sources streamed in tiles */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t j0 = 0; j0 < n; j0 += OWN) {
+        const int64_t j1 = j0 + OWN < n ? j0 + OWN : n;
+        double s[OWN];
+        for (int q = 0; q < OWN; ++q) s[q] = 0.0;
+        for (int64_t i0 = 0; i0 < m; i0 += TILE) {
+            const int64_t i1 = i0 + TILE < m ? i0 + TILE : m;
+            for (int64_t j = j0; j < j1; ++j) {
+                double acc = s[j - j0];
+                for (int64_t i = i0; i < i1; ++i) {
+                    double d2 = 0.0;
+                    for (int k = 0; k < d; ++k) {
+                        const double df = ts[i * d + k] - x[j * d + k];
+                        d2 += df * df;
+                    }
+                    acc += exp_or_zero(d2 * inv);
+                }
+                s[j - j0] = acc;
             }
-            s += exp(d2 * inv);
         }
-        kmass[j] = s;
-        if (s == 0.0) s = EPS32;
-        den[j] = s + c;
-        pt1[j] = kmass[j] / den[j];
+        for (int64_t j = j0; j < j1; ++j) {
+            const double kmass = s[j - j0];
+            double sj = kmass;
+            if (sj == 0.0) sj = EPS32; /* cpd.py:81 */
+            den[j] = sj + c;           /* cpd.py:82 */
+            pt1[j] = kmass / den[j];   /* column sum of P (cpd.py:85) */
+        }
     }
+    /* sweep 2 (cpd.py:84-87): P = K / den, p1 = row sums, px = P @ target; rows owned, targets streamed in tiles */
     double n_p = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : n_p)
-    for (int64_t i = 0; i < m; ++i) {
-        double s = 0.0, acc[3] = {0.0, 0.0, 0.0};
-        for (int64_t j = 0; j < n; ++j) {
-            double d2 = 0.0;
-            for (int k = 0; k < d; ++k) {
-                const double df = ts[i * d + k] - x[j * d + k];
-                d2 += df * df;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_p)
+    for (int64_t i0 = 0; i0 < m; i0 += OWN) {
+        const int64_t i1 = i0 + OWN < m ? i0 + OWN : m;
+        double s[OWN], acc[OWN][3];
+        for (int q = 0; q < OWN; ++q) s[q] = acc[q][0] = acc[q][1] = acc[q][2] = 0.0;
+        for (int64_t jt = 0; jt < n; jt += TILE) {
+            const int64_t je = jt + TILE < n ? jt + TILE : n;
+            for (int64_t i = i0; i < i1; ++i) {
+                double si = s[i - i0], a0 = acc[i - i0][0], a1 = acc[i - i0][1], a2 = acc[i - i0][2];
+                for (int64_t j = jt; j < je; ++j) {
+                    double d2 = 0.0;
+                    for (int k = 0; k < d; ++k) {
+                        const double df = ts[i * d + k] - x[j * d + k];
+                        d2 += df * df;
+                    }
+                    const double e = exp_or_zero(d2 * inv);
+                    if (e == 0.0) continue; /* contributes exact zeros */
+                    const double p = e / den[j];
+                    si += p;
+                    a0 += p * x[j * d];
+                    a1 += p * x[j * d + 1];
+                    if (d > 2) a2 += p * x[j * d + 2];
+                }
+                s[i - i0] = si;
+                acc[i - i0][0] = a0;
+                acc[i - i0][1] = a1;
+                acc[i - i0][2] = a2;
             }
-            const double p = exp(d2 * inv) / den[j];
-            s += p;
-            for (int k = 0; k < d; ++k) acc[k] += p * x[j * d + k];
         }
-        p1[i] = s;
-        for (int k = 0; k < d; ++k) px[i * d + k] = acc[k];
-        n_p += s;
+        for (int64_t i = i0; i < i1; ++i) {
+            p1[i] = s[i - i0];
+            for (int k = 0; k < d; ++k) px[i * d + k] = acc[i - i0][k];
+            n_p += s[i - i0];
+        }
     }
     free(den);
-    free(kmass);
     return n_p;
 }

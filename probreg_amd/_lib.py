@@ -64,6 +64,7 @@ SIGNATURES = {
     "prg_cpd_init_params": [_vp, _vp],
     "prg_cpd_estep": [_vp, _d],
     "prg_cpd_estep_timed": [_vp, _d, _vp],
+    "prg_cpd_pair_counts": [_vp, _c.POINTER(_d), _c.POINTER(_d)],
     "prg_cpd_mstep": [_vp, _i, _i],
     "prg_cpd_get_params": [_vp, _vp],
     "prg_cpd_set_params": [_vp, _vp],
@@ -104,6 +105,7 @@ SIGNATURES = {
     "prg_fr_set_target_normals": [_vp, _vp],
     "prg_fr_get_nx": [_vp, _vp],
     "prg_fr_mstep_pt2pl": [_vp, _d, _i, _d, _vp],
+    "prg_fr_mstep_from_arrays": [_i, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _d, _d, _vp],
     "prg_kabsch_weighted": [_i, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
 }
 

@@ -142,6 +142,17 @@ class CoherentPointDrift(abc.ABC):
         if plan._moments_tensor is not None:
             pdist.all_reduce_sum_(plan._moments_tensor)
 
+    def _restart(self):
+        """Put an initialised plan back to the start of its registration (sigma2 initialiser, q0, initial transform)
+        without re-uploading the clouds - bench.py times the SAME EM iterations whatever its warm-up did."""
+        plan = self._plan
+        mom = plan.moments_tensor() if pdist.initialized() else None
+        plan.init_sums()
+        if mom is not None:
+            pdist.all_reduce_sum_(mom)
+        plan.init_params(self._init_block)
+        return plan
+
     @abc.abstractmethod
     def _initialize(self, target):
         return MstepResult(None, None, None)
@@ -209,7 +220,8 @@ class RigidCPD(CoherentPointDrift):
         scale = float(ip.get("scale", 1.0))
         # centred frame: z - cx = s R (y - cy) + t'  with  t' = t + s R cy - cx
         t_c = t + scale * rot @ self._cy - self._cx
-        plan.init_params(_params_block(rot, t_c, scale, dim, self._cx - self._cy))
+        self._init_block = _params_block(rot, t_c, scale, dim, self._cx - self._cy)
+        plan.init_params(self._init_block)
         return self._result_from_params(plan.get_params())
 
     def _device_mstep(self, plan):
@@ -249,7 +261,8 @@ class AffineCPD(CoherentPointDrift):
         b = np.asarray(ip.get("b", np.identity(dim)), dtype=np.float64)
         t = np.asarray(ip.get("t", np.zeros(dim)), dtype=np.float64)
         t_c = t + b @ self._cy - self._cx
-        plan.init_params(_params_block(b, t_c, 1.0, dim, self._cx - self._cy))
+        self._init_block = _params_block(b, t_c, 1.0, dim, self._cx - self._cy)
+        plan.init_params(self._init_block)
         return self._result_from_params(plan.get_params())
 
     def _device_mstep(self, plan):
@@ -338,6 +351,7 @@ class NonRigidCPD(CoherentPointDrift):
 
     def _initialize(self, target):
         plan = self._setup_plan(target)
+        self._init_block = None
         plan.init_params(None)
         self._tf_obj.w = np.zeros_like(self._source)
         plan.set_w(self._tf_obj.w)
@@ -368,24 +382,52 @@ class NonRigidCPD(CoherentPointDrift):
         return MstepResult(self._tf_obj, float(params[13]), float(params[14]))
 
     def maximization_step(self, target, estep_res, sigma2_p=None):
-        return self._maximization_step(self._source, target, estep_res, sigma2_p)
+        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._tf_obj, self._lmd)
 
-    def _maximization_step(self, source, target, estep_res, sigma2_p=None):
-        raise NotImplementedError(
-            "NonRigidCPD.maximization_step on explicit arrays is not exposed; use registration()."
-        )
+    def _maximization_step(self, source, target, estep_res, sigma2_p, tf_obj=None, lmd=None, xp=np):
+        """Non-rigid M-step from explicit EstepResult arrays (reference cpd.py:272-303), on the GPU.
+
+        ``(diag(p1) G + lmd sigma2_p I) W = px - diag(p1) Y`` is solved by the plan that holds ``G`` for this
+        object's source; like the reference the transformation object is updated in place (``tf_obj.w``) and returned,
+        and ``q`` is the new sigma2.  ``sigma2_p`` is the variance of the E-step that produced ``estep_res``.
+        """
+        if sigma2_p is None:
+            raise ValueError("NonRigidCPD.maximization_step needs sigma2_p (the regulariser is lmd * sigma2_p).")
+        tf_obj = self._tf_obj if tf_obj is None else tf_obj
+        lmd = self._lmd if lmd is None else lmd
+        source = _as_points(source)
+        if tf_obj is not self._tf_obj or source.shape != self._source.shape or not np.array_equal(source, self._source):
+            raise ValueError("NonRigidCPD._maximization_step: source / tf_obj must be this object's own (G lives "
+                             "on the GPU plan built for them).")
+        target = _as_points(target)
+        pt1, p1, px, _n_p = estep_res
+        plan = self._plan
+        plan.set_target(target, n_global=target.shape[0])
+        self._upload_priors(target)
+        plan.moments_from_estep(pt1, p1, px)
+        p = plan.get_params()
+        p[13] = float(sigma2_p)
+        plan.set_params(p)
+        plan.mstep_nonrigid(lmd)
+        out = plan.get_params()
+        tf_obj.w = plan.get_w()
+        return MstepResult(tf_obj, float(out[13]), float(out[14]))
+
+    def _upload_priors(self, target):
+        """Hook of ConstrainedNonRigidCPD; plain non-rigid CPD has no correspondence priors."""
 
 
 class ConstrainedNonRigidCPD(NonRigidCPD):
-    """Extended CPD with point-correspondence priors (reference cpd.py:306-404, Golyanik et al. 2016).
+    """Non-rigid CPD with known correspondences (reference cpd.py:306-404; Golyanik et al., "Extended coherent
+    point drift algorithm with correspondence priors and optimal subsampling", 2016).
 
-    Args:
-        source (numpy.ndarray, optional): Source point cloud data.
-        beta (float, optional): Parameter of RBF kernel.
-        lmd (float, optional): Parameter for regularization term.
-        alpha (float): Degree of reliability of priors, ~1e-8 (highly reliable) .. 1 (highly unreliable).
-        use_cuda (bool, optional): accepted for compatibility, ignored.
-        idx_source / idx_target (numpy.ndarray of ints, optional): indices of known correspondences.
+    On top of ``NonRigidCPD``'s ``source`` / ``beta`` / ``lmd``:
+
+    alpha                  : how much the listed correspondences are trusted - the prior terms enter the linear
+                             system scaled by ``sigma2 / alpha``, so 1e-8 pins the pairs and 1 barely uses them
+    idx_source, idx_target : equally long integer arrays; source point ``idx_source[k]`` is known to match target
+                             point ``idx_target[k]``
+    use_cuda               : kept for call-site compatibility, ignored (the engine is always the HIP one)
 
     The reference materialises a dense M x N 0-1 matrix ``p_tilde`` (cpd.py:370-374); only its row sums
     ``p1_tilde`` and ``px_tilde = p_tilde @ target`` enter the M-step, so they are formed directly from the
@@ -398,8 +440,7 @@ class ConstrainedNonRigidCPD(NonRigidCPD):
         self.idx_source, self.idx_target = idx_source, idx_target
         super(ConstrainedNonRigidCPD, self).__init__(source, beta, lmd, use_cuda, device)
 
-    def _initialize(self, target):
-        res = super(ConstrainedNonRigidCPD, self)._initialize(target)
+    def _upload_priors(self, target):
         target = _as_points(target)
         m, dim = self._source.shape
         self.p1_tilde = np.zeros(m)
@@ -410,6 +451,10 @@ class ConstrainedNonRigidCPD(NonRigidCPD):
             np.add.at(self.p1_tilde, pairs[:, 0], 1.0)
             np.add.at(self.px_tilde, pairs[:, 0], target[pairs[:, 1]])
         self._plan.set_priors(self.p1_tilde, self.px_tilde, self.alpha)
+
+    def _initialize(self, target):
+        res = super(ConstrainedNonRigidCPD, self)._initialize(target)
+        self._upload_priors(target)
         return res
 
 

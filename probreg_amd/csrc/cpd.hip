@@ -443,6 +443,24 @@ __global__ __launch_bounds__(kBlock) void k_moments_from_arrays(const double* __
     block_reduce_store(a, mompart);
 }
 
+// The same arrays as the per-point fp64 block [4][Mcap] (p1, px) the non-rigid solve reads (kernel order).
+__global__ __launch_bounds__(kBlock) void k_rowacc_from_arrays(const double* __restrict__ pt1,
+                                                               const double* __restrict__ p1,
+                                                               const double* __restrict__ px, int dim, int64_t m,
+                                                               int64_t n, int64_t mcap,
+                                                               const int* __restrict__ perm_src,
+                                                               const int* __restrict__ perm_tgt,
+                                                               double* __restrict__ rowacc, float* __restrict__ pt1f) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) pt1f[i] = (float)pt1[perm_tgt ? perm_tgt[i] : i];
+    if (i >= m) return;
+    const int64_t j = perm_src ? perm_src[i] : i;
+    rowacc[i] = p1[j];
+    rowacc[mcap + i] = px[j * dim];
+    rowacc[2 * mcap + i] = px[j * dim + 1];
+    rowacc[3 * mcap + i] = dim > 2 ? px[j * dim + 2] : 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // device M-step (fp64, one thread)
 // ---------------------------------------------------------------------------------------------
@@ -647,8 +665,10 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion, (void*)h->srcw})
+                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount})
         if (q) (void)hipFree(q);
+    h->wgcount = nullptr;
+    h->wg_cap = 0;
     h->perm_src = h->perm_tgt = nullptr;
     h->zmeta = h->tmeta = h->colmin = nullptr;
     h->motion = nullptr;
@@ -969,6 +989,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
                                            init_dev);
     PRG_HIP(hipGetLastError());
     if (init_params_host) PRG_HIP(hipStreamSynchronize(h->stream));  // host buffer may be reused by the caller
+    h->have_colmin = false;  // a new registration starts: its first column pass takes no seed from the previous one
     return PRG_OK;
 }
 
@@ -1016,6 +1037,19 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)PA * h->Ncap));
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)PB * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
+    if (use_cull) {  // per-workgroup counters of evaluated (wave, group) blocks (prg_cpd_pair_counts)
+        const int64_t need = std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->M, 128) * PB);
+        if (need > h->wg_cap) {
+            if (h->wgcount) {
+                PRG_HIP(hipStreamSynchronize(h->stream));
+                (void)hipFree(h->wgcount);
+            }
+            h->wgcount = nullptr;
+            h->wg_cap = 0;
+            PRG_HIP(hipMalloc((void**)&h->wgcount, (size_t)need * 2 * sizeof(unsigned)));
+            h->wg_cap = need;
+        }
+    }
 
     if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
     const int slot = (int)(h->estep_count & 1);
@@ -1082,6 +1116,30 @@ int prg_cpd_estep_timed(prg_cpd* h, double w, float* ms_out) {
     }
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(ev[i]);
     return st;
+}
+
+int prg_cpd_pair_counts(prg_cpd* h, double* col_pairs, double* row_pairs) {
+    PRG_REQUIRE(h && h->have_estep && col_pairs && row_pairs, PRG_ERR_STATE, "prg_cpd_pair_counts: no E-step has been run");
+    prg::DeviceGuard g(h->device);
+    *col_pairs = h->dense_pairs_col;
+    *row_pairs = h->dense_pairs_row;
+    if (h->wg_col > 0 || h->wg_row > 0) {
+        std::vector<unsigned> host((size_t)h->wg_cap * 2);
+        PRG_HIP(hipMemcpyAsync(host.data(), h->wgcount, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        PRG_HIP(hipStreamSynchronize(h->stream));
+        const double block_pairs = 128.0 * prg::kGroup;  // a (wave, group) block: 128 lane points x 32 streamed points
+        if (h->wg_col > 0) {
+            double s = 0.0;
+            for (int64_t i = 0; i < h->wg_col; ++i) s += host[(size_t)i];
+            *col_pairs = s * block_pairs;
+        }
+        if (h->wg_row > 0) {
+            double s = 0.0;
+            for (int64_t i = 0; i < h->wg_row; ++i) s += host[(size_t)(h->wg_cap + i)];
+            *row_pairs = s * block_pairs;
+        }
+    }
+    return PRG_OK;
 }
 
 int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {
@@ -1175,8 +1233,11 @@ int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p
     k_moments_from_arrays<<<nblk, kBlock, 0, h->stream>>>(d_pt1, d_p1, d_px, h->D, h->M, h->N, h->src4, h->tgt4,
                                                           h->perm_src, h->perm_tgt, h->mompart);
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
+    k_rowacc_from_arrays<<<nblk, kBlock, 0, h->stream>>>(d_pt1, d_p1, d_px, h->D, h->M, h->N, h->Mcap, h->perm_src,
+                                                         h->perm_tgt, h->rowacc, h->pt1);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
+    h->have_estep = true;  // rowacc / MOMENTS now hold an E-step result (the caller's)
     return PRG_OK;
 }
 

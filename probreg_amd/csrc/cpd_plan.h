@@ -48,6 +48,12 @@ struct prg_cpd {
                                 // followed by [Ncap/32] per-group maxima of it
     unsigned* motion = nullptr; // float bits of max_m |z_new - z_old| of the last transform
     bool have_colmin = false;
+    // measurement hook: evaluated (wave, group) blocks per workgroup of the last culled column / row pass
+    // ([0, wg_cap) column pass, [wg_cap, 2 wg_cap) row pass); wg_col / wg_row = workgroups of the last launches,
+    // dense_pairs_* = pairs covered by the last NON-culled launches (0 when the culled kernels ran)
+    unsigned* wgcount = nullptr;
+    int64_t wg_cap = 0, wg_col = 0, wg_row = 0;
+    double dense_pairs_col = 0.0, dense_pairs_row = 0.0;
     uint64_t estep_count = 0;   // parity selects the motion slot of the current E-step
 
     // staging for uploads / moments_from_estep

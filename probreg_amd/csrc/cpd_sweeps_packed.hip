@@ -167,6 +167,8 @@ namespace prg {
 
 void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->N, kBlock * R), (unsigned)S);
+    h->wg_col = 0;
+    h->dense_pairs_col = (double)grid.x * (kBlock * R) * (double)S * seg_len;
     if (R == 2)
         k_colpass<1><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, seg_len, h->params, h->colpart, h->Ncap);
     else
@@ -175,6 +177,8 @@ void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len) {
 
 void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->M, kBlock * R), (unsigned)S);
+    h->wg_row = 0;
+    h->dense_pairs_row = (double)grid.x * (kBlock * R) * (double)S * seg_len;
     if (R == 2)
         k_rowpass<1><<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, seg_len, h->params, h->rowpart, h->Mcap);
     else
@@ -268,10 +272,12 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
                                                          const double* __restrict__ params,
                                                          const float* __restrict__ colmin_g,
                                                          const unsigned* __restrict__ motion,
-                                                         float2* __restrict__ colpart, int64_t ncap) {
+                                                         float2* __restrict__ colpart, int64_t ncap,
+                                                         unsigned* __restrict__ wgcount) {
     PRG_TRACE_BEGIN();
     __shared__ float4 part[4][64];
-    __shared__ int arrived;
+    __shared__ int arrived, wave_groups[4];
+    int ngrp = 0;  // (wave, group) blocks this wave evaluates: 128 x 32 pairs each (measurement hook, wave-uniform)
     if (threadIdx.x == 0) arrived = 0;
     __syncthreads();  // (at launch, before any wave waits for memory: costs nothing; there is no barrier at the end)
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
@@ -305,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
             const bool need = (g0 + lane < ngroups) && !(box_dist2(lo, hi, gm) > thr);
             unsigned long long mask = __ballot(need);
             if (mask == 0) continue;
+            ngrp += __builtin_popcountll(mask);
             if (!have_points) {
                 const float4 a = tgt4[n0], b = tgt4[n0 + 1];
                 x = (f2){a.x, b.x};
@@ -359,8 +366,14 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
     // wave is gone after its one round trip instead of holding a wave slot until its busiest sibling has finished.
     part[wv][lane] = make_float4(run.x, s.x, run.y, s.y);
     int last = 0;
-    if (lane == 0) last = atomicAdd(&arrived, 1) == 3;  // LDS ops of a wave execute in order: the pair is visible
+    if (lane == 0) {
+        wave_groups[wv] = ngrp;
+        last = atomicAdd(&arrived, 1) == 3;  // LDS ops of a wave execute in order: the pair is visible
+    }
     if (__builtin_amdgcn_readfirstlane(last)) {
+        if (lane == 0)  // one plain store per workgroup; summed on the host when the bench asks (prg_cpd_pair_counts)
+            wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] =
+                (unsigned)(wave_groups[0] + wave_groups[1] + wave_groups[2] + wave_groups[3]);
         run = splat(INFINITY);
         off = splat(INFINITY);
         s = splat(0.f);
@@ -388,10 +401,12 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
                                                          const GroupMeta* __restrict__ zmeta, int seg_len, int nseg,
                                                          const double* __restrict__ params,
                                                          float* __restrict__ rowpart, int64_t mcap,
-                                                         unsigned char* __restrict__ rowflag) {
+                                                         unsigned char* __restrict__ rowflag,
+                                                         unsigned* __restrict__ wgcount) {
     PRG_TRACE_BEGIN();
     __shared__ float2 part[4][5][64];
     __shared__ int arrived, wave_touched[4];
+    int ngrp = 0;  // evaluated (wave, group) blocks, as in k_colpass_cull
     if (threadIdx.x == 0) arrived = 0;
     __syncthreads();  // (at launch; the merge at the end is barrier-free, see k_colpass_cull)
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
@@ -414,6 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
             const bool need = (g0 + lane < ngroups) && !(fmaf(box_dist2(lo, hi, gm), kk, gm.aux) < kCullLog2);
             unsigned long long mask = __ballot(need);
             if (mask == 0) continue;
+            ngrp += __builtin_popcountll(mask);
             if (!touched) {
                 const float4 a = z4[m0], b = z4[m0 + 1];
                 zx = (f2){a.x, b.x};
@@ -461,14 +477,17 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_cull(const float4* __restric
     }
     int last = 0;
     if (lane == 0) {
-        wave_touched[wv] = touched ? 1 : 0;
+        wave_touched[wv] = touched ? ngrp : 0;  // (count of evaluated groups: non-zero iff touched)
         last = atomicAdd(&arrived, 1) == 3;
     }
     if (__builtin_amdgcn_readfirstlane(last)) {
         // k_row_moments skips the partials of untouched (128-row block, plane) pairs: neither written nor read
         const int t0 = wave_touched[0], t1 = wave_touched[1], t2 = wave_touched[2], t3 = wave_touched[3];
         const bool any = (t0 | t1 | t2 | t3) != 0;
-        if (lane == 0) rowflag[(int64_t)blockIdx.x * 64 + blockIdx.y] = any ? 1 : 0;
+        if (lane == 0) {
+            rowflag[(int64_t)blockIdx.x * 64 + blockIdx.y] = any ? 1 : 0;
+            wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned)(t0 + t1 + t2 + t3);
+        }
         if (any) {
             const int tk[4] = {t0, t1, t2, t3};
             p1 = ux = uy = uz = e = splat(0.f);
@@ -513,7 +532,10 @@ void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
     k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
                                                    reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len, S, h->params,
                                                    use_seed ? h->colmin + h->Ncap : nullptr,
-                                                   h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap);
+                                                   h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap,
+                                                   h->wgcount);
+    h->wg_col = (int64_t)grid.x * grid.y;
+    h->dense_pairs_col = 0.0;
 }
 
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
@@ -522,7 +544,10 @@ void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
     k_rowpass_cull<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const GroupMeta*>(h->tmeta),
                                                    reinterpret_cast<const GroupMeta*>(h->zmeta), seg_len, S, h->params,
                                                    h->rowpart, h->Mcap,
-                                                   reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)planes * 5 * h->Mcap));
+                                                   reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)planes * 5 * h->Mcap),
+                                                   h->wgcount + h->wg_cap);
+    h->wg_row = (int64_t)grid.x * grid.y;
+    h->dense_pairs_row = 0.0;
 }
 
 }  // namespace prg

@@ -133,6 +133,8 @@ namespace prg {
 
 void launch_colpass_scalar(prg_cpd* h, int R, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->N, kBlock * R), (unsigned)S);
+    h->wg_col = 0;
+    h->dense_pairs_col = (double)grid.x * (kBlock * R) * (double)S * seg_len;
     if (R == 2)
         k_colpass<2, 8><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, seg_len, h->params, h->colpart, h->Ncap);
     else
@@ -141,6 +143,8 @@ void launch_colpass_scalar(prg_cpd* h, int R, int S, int seg_len) {
 
 void launch_rowpass_scalar(prg_cpd* h, int R, int S, int seg_len) {
     dim3 grid((unsigned)ceil_div(h->M, kBlock * R), (unsigned)S);
+    h->wg_row = 0;
+    h->dense_pairs_row = (double)grid.x * (kBlock * R) * (double)S * seg_len;
     if (R == 2)
         k_rowpass<2><<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, seg_len, h->params, h->rowpart, h->Mcap);
     else

@@ -876,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __rest
     state[13] = mom[27];  // q = r_sum
     state[17] = state[12];
     state[15] = update_sigma2 ? mom[28] / (3.0 * mom[29]) : state[12];
-    if (min_sigma2 > 0.0) state[12] = fmax(state[15], min_sigma2);
+    if (min_sigma2 >= 0.0) state[12] = fmax(state[15], min_sigma2);  // negative: do not advance (see k_fr_finish)
 }
 
 // weighted Kabsch from moments (cc/kabsch.cc:6-109): mom[0] sw, [1..3] sw*model, [4..6] sw*target, [7] sw2,
@@ -978,7 +978,26 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__
     state[13] = mom[23];
     state[17] = state[12];                                               // sigma2 this step was computed with
     state[15] = update_sigma2 ? mom[24] / (3.0 * mom[25]) : state[12];  // :192-195 (3.0 hard-coded there)
-    if (min_sigma2 > 0.0) state[12] = fmax(state[15], min_sigma2);      // self._sigma2 = max(res.sigma2, min_sigma2), :140
+    // self._sigma2 = max(res.sigma2, min_sigma2), :140 - for every legal min_sigma2 (0 included); a NEGATIVE value
+    // is the explicit "leave the device sigma2 alone" request of the stand-alone M-step entry points
+    if (min_sigma2 >= 0.0) state[12] = fmax(state[15], min_sigma2);
+}
+
+// caller-supplied E-step arrays -> the [m][ch] value layout and the [m][3] fp64 transformed source the M-step
+// kernels read (prg_fr_mstep_from_arrays)
+__global__ __launch_bounds__(kBlock) void k_fr_pack_estep(const double* __restrict__ tsrc, const float* __restrict__ m0,
+                                                          const float* __restrict__ m1, const float* __restrict__ m2,
+                                                          const float* __restrict__ nx, int64_t m, int dim, int ch,
+                                                          double* __restrict__ ts, float* __restrict__ vout) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    for (int k = 0; k < 3; ++k) ts[i * 3 + k] = k < dim ? tsrc[i * dim + k] : 0.0;
+    float* o = vout + i * ch;
+    o[0] = m0[i];
+    for (int k = 0; k < 3; ++k) o[1 + k] = k < dim ? m1[i * dim + k] : 0.f;
+    o[4] = m2 ? m2[i] : 0.f;
+    if (ch == 8)
+        for (int k = 0; k < 3; ++k) o[5 + k] = nx[i * 3 + k];
 }
 
 // stand-alone Kabsch: moments of (model, target, weight) float32 clouds -> partials [nblk][kFrComp]
@@ -1327,6 +1346,70 @@ int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min
     PRG_HIP(hipMemcpyAsync(h->L.pinned, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
     for (int i = 0; i < 18; ++i) out_host[i] = h->L.pinned[i];
+    return PRG_OK;
+}
+
+// RigidFilterReg._maximization_step on explicit arrays (filterreg.py:158-196) - same kernels as prg_fr_mstep /
+// prg_fr_mstep_pt2pl, fed from the caller's buffers instead of a plan's last E-step
+int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_source_hd, int64_t m, int dim,
+                             int64_t n_target, const float* m0_hd, const float* m1_hd, const float* m2_hd,
+                             const float* nx_hd, const double* rot9, const double* t3, double sigma2, double w,
+                             double* out_host) {
+    PRG_REQUIRE(t_source_hd && m0_hd && m1_hd && rot9 && t3 && out_host, PRG_ERR_INVALID,
+                "prg_fr_mstep_from_arrays: NULL argument");
+    PRG_REQUIRE(m > 0 && n_target > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID,
+                "prg_fr_mstep_from_arrays: need m > 0, n_target > 0 and dim in {2,3}");  // "dim must be 2 or 3", :161
+    PRG_REQUIRE(!nx_hd || dim == 3, PRG_ERR_INVALID, "prg_fr_mstep_from_arrays: point-to-plane needs 3-D clouds");
+    PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep_from_arrays: w must be in [0, 1) (got %g)", w);
+    PRG_REQUIRE(sigma2 > 0.0, PRG_ERR_INVALID, "prg_fr_mstep_from_arrays: sigma2 must be > 0 (got %g)", sigma2);
+    prg::DeviceGuard g(device);
+    PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_fr_mstep_from_arrays: hipSetDevice(%d) failed", device);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int ch = nx_hd ? 8 : 5;
+    const int nblk = (int)prg::ceil_div(m, kBlock);
+    struct Tmp {
+        void* p = nullptr;
+        ~Tmp() { if (p) (void)hipFree(p); }
+    } b_in, b_ts, b_v, b_part, b_state;
+    // staging: t_source | m0 | m1 | m2 | nx
+    const size_t o_ts = 0, o_m0 = o_ts + (size_t)m * dim * sizeof(double), o_m1 = o_m0 + (size_t)m * sizeof(float),
+                 o_m2 = o_m1 + (size_t)m * dim * sizeof(float), o_nx = o_m2 + (size_t)m * sizeof(float),
+                 total = o_nx + (size_t)m * 3 * sizeof(float);
+    PRG_HIP(hipMalloc(&b_in.p, total));
+    PRG_HIP(hipMalloc(&b_ts.p, (size_t)m * 3 * sizeof(double)));
+    PRG_HIP(hipMalloc(&b_v.p, (size_t)m * ch * sizeof(float)));
+    PRG_HIP(hipMalloc(&b_part.p, (size_t)nblk * kFrComp * sizeof(double)));
+    PRG_HIP(hipMalloc(&b_state.p, 64 * sizeof(double)));
+    char* in = (char*)b_in.p;
+    PRG_HIP(hipMemcpyAsync(in + o_ts, t_source_hd, (size_t)m * dim * sizeof(double), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(in + o_m0, m0_hd, (size_t)m * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(in + o_m1, m1_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, st));
+    if (m2_hd) PRG_HIP(hipMemcpyAsync(in + o_m2, m2_hd, (size_t)m * sizeof(float), hipMemcpyDefault, st));
+    if (nx_hd) PRG_HIP(hipMemcpyAsync(in + o_nx, nx_hd, (size_t)m * 3 * sizeof(float), hipMemcpyDefault, st));
+    double host_state[64] = {0.0};
+    for (int i = 0; i < 9; ++i) host_state[i] = rot9[i];
+    for (int i = 0; i < 3; ++i) host_state[9 + i] = t3[i];
+    host_state[12] = sigma2;
+    PRG_HIP(hipMemcpyAsync(b_state.p, host_state, sizeof(host_state), hipMemcpyHostToDevice, st));
+    k_fr_pack_estep<<<nblk, kBlock, 0, st>>>((const double*)(in + o_ts), (const float*)(in + o_m0),
+                                             (const float*)(in + o_m1), m2_hd ? (const float*)(in + o_m2) : nullptr,
+                                             nx_hd ? (const float*)(in + o_nx) : nullptr, m, dim, ch, (double*)b_ts.p,
+                                             (float*)b_v.p);
+    const double wfac = w / (1.0 - w) * (double)n_target / (double)m;
+    const int update_sigma2 = m2_hd ? 1 : 0;
+    if (nx_hd) {
+        k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>((const float*)b_v.p, (const double*)b_ts.p, m, wfac,
+                                                  (const double*)b_state.p, (double*)b_part.p);
+        k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>((const double*)b_part.p, nblk, update_sigma2, -1.0, (double*)b_state.p);
+    } else {
+        k_fr_terms<<<nblk, kBlock, 0, st>>>((const float*)b_v.p, ch, (const double*)b_ts.p, m, dim, wfac,
+                                            (const double*)b_state.p, (double*)b_part.p);
+        k_fr_finish<<<1, kBlock, 0, st>>>((const double*)b_part.p, nblk, dim, update_sigma2, -1.0, (double*)b_state.p);
+    }
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(host_state, b_state.p, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < 18; ++i) out_host[i] = host_state[i];
     return PRG_OK;
 }
 

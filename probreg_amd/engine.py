@@ -119,6 +119,12 @@ class CpdPlan(object):
         names = ("transform", "colpass", "colfinal", "rowpass", "moments", "total")
         return dict(zip(names, [float(v) for v in ms]))
 
+    def pair_counts(self):
+        """(column-pass pairs, row-pass pairs) the last E-step actually evaluated (prg_cpd_pair_counts)."""
+        a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        check(lib.prg_cpd_pair_counts(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return float(a.value), float(b.value)
+
     def mstep(self, kind, update_scale=True):
         check(lib.prg_cpd_mstep(self._h, int(kind), 1 if update_scale else 0))
 

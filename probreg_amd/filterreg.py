@@ -93,7 +93,8 @@ class _Plan(object):
         check(lib.prg_fr_get_nx(self._h, ptr(nx)))
         return nx
 
-    def mstep(self, w, update_sigma2, objective_type="pt2pt", min_sigma2=0.0):
+    def mstep(self, w, update_sigma2, objective_type="pt2pt", min_sigma2=-1.0):
+        """``min_sigma2`` >= 0 advances the device sigma2 like the driver (filterreg.py:140); negative leaves it alone."""
         out = np.zeros(18)
         fn = lib.prg_fr_mstep_pt2pl if objective_type == "pt2pl" else lib.prg_fr_mstep
         check(fn(self._h, float(w), 1 if update_sigma2 else 0, float(min_sigma2), ptr(out)))
@@ -167,6 +168,16 @@ class FilterReg(abc.ABC):
             plan.close()
         return EstepResult(m0, m1, m2, nx)
 
+    def maximization_step(self, t_source, target, estep_res, w=0.0, objective_type="pt2pt"):
+        """M-step on explicit E-step arrays (reference filterreg.py:110-113)."""
+        return self._maximization_step(t_source, target, estep_res, self._tf_result, self._sigma2, w,
+                                       objective_type=objective_type)
+
+    @staticmethod
+    @abc.abstractmethod
+    def _maximization_step(t_source, target, estep_res, trans_p, sigma2, w=0.0, objective_type="pt2pt"):
+        return None
+
     def registration(self, target, w=0.0, objective_type="pt2pt", maxiter=50, tol=0.001, min_sigma2=1.0e-4,
                      feature_fn=_identity):
         """EM driver (reference filterreg.py:120-147)."""
@@ -191,7 +202,14 @@ class FilterReg(abc.ABC):
         res = MstepResult(self._tf_result, self._sigma2, None)
         # the transform and sigma2 live on the device: uploaded once, advanced by the M-step kernel
         plan.set_state(self._tf_result.rot, self._tf_result.t, self._sigma2)
+        # tf_init_params['scale']: the reference's first transform applies it (filterreg.py:129) and every M-step
+        # returns a scale-free RigidTransformation (:196), so it acts on the first iteration only
+        scale0 = float(getattr(self._tf_result, "scale", 1.0))
+        if scale0 != 1.0:
+            plan.set_source(self._source * scale0)
         for i in range(maxiter):
+            if i == 1 and scale0 != 1.0:
+                plan.set_source(self._source)
             plan.estep()
             out = plan.mstep(w, self._update_sigma2, objective_type, min_sigma2)
             if out[16] == 0.0:  # every m0 == 0 (filterreg.py:167-168, :136-138)
@@ -224,6 +242,38 @@ class RigidFilterReg(FilterReg):
             # the reference needs explicit 2-D tf_init_params for 2-D data (examples/filterreg_rigid2d.py);
             # default to the 2-D identity instead of failing with a shape error
             self._tf_result = self._tf_type(np.identity(2), np.zeros(2))
+
+
+    @staticmethod
+    def _maximization_step(t_source, target, estep_res, trans_p, sigma2, w=0.0, objective_type="pt2pt"):
+        """Rigid M-step from explicit arrays (reference filterreg.py:158-196): weighted Kabsch (pt2pt) or twist
+        solve (pt2pl) on the GPU, composition with ``trans_p``, sigma2 re-estimated when ``estep_res.m2`` is given."""
+        t_source = np.ascontiguousarray(_as_points(t_source))
+        target = _as_points(target)
+        m, dim = t_source.shape
+        assert dim == 2 or dim == 3, "dim must be 2 or 3."
+        if objective_type not in ("pt2pt", "pt2pl"):
+            raise ValueError("Unknown objective_type: %s." % objective_type)
+        m0, m1, m2, nx = estep_res
+        if objective_type == "pt2pl" and nx is None:
+            raise ValueError("objective_type 'pt2pl' needs estep_res.nx.")
+        _lib.require_gpu()
+        f32 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        m0, m1, m2 = f32(m0), f32(m1), f32(m2)
+        nx = f32(nx) if objective_type == "pt2pl" else None
+        rot = np.identity(3)
+        rot[:dim, :dim] = trans_p.rot
+        t = np.zeros(3)
+        t[:dim] = trans_p.t
+        dev, st = _current_device_and_stream()
+        out = np.zeros(18)
+        check(lib.prg_fr_mstep_from_arrays(dev, ctypes.c_void_p(st), ptr(t_source), m, dim, target.shape[0], ptr(m0),
+                                           ptr(m1), ptr(m2), ptr(nx), ptr(np.ascontiguousarray(rot)), ptr(t),
+                                           float(sigma2), float(w), ptr(out)))
+        if out[16] == 0.0:  # every m0 == 0 (filterreg.py:167-168)
+            return MstepResult(trans_p, sigma2, None)
+        return MstepResult(tf.RigidTransformation(out[:9].reshape(3, 3)[:dim, :dim].copy(), out[9:9 + dim].copy()),
+                           float(out[15]), float(out[13]))
 
 
 def registration_filterreg(source, target, target_normals=None, sigma2=None, update_sigma2=False, w=0,

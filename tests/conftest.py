@@ -44,3 +44,9 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(float(np.max(np.abs(b))), 1e-300)
     return float(np.max(np.abs(a - b))) / den
+
+
+@pytest.fixture(scope="session")
+def mstep_golden():
+    """Single M-step calls of the reference on explicit E-step arrays (tests/golden/make_golden.py mstep)."""
+    return Golden(os.path.join(GOLDEN_DIR, "mstep_golden.npz"))

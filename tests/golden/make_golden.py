@@ -344,7 +344,84 @@ def main_bcpd():
     print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
 
 
+def main_mstep():
+    """Single M-step calls of the reference on explicit E-step arrays: NonRigidCPD.maximization_step (cpd.py:272-303),
+    ConstrainedNonRigidCPD.maximization_step (:377-404) and FilterReg.maximization_step (filterreg.py:110-113 ->
+    RigidFilterReg._maximization_step :158-196, both objectives).  The E-step arrays are the reference's own."""
+    from oracle import permutohedral as ph
+
+    assert ph.ref_available(), "build oracle/_ref first: make -C oracle ref"
+    ref = ref_import.load(with_filterreg=True)
+    fish_s = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_source.txt"))
+    fish_t = np.loadtxt(os.path.join(ref_import.REFERENCE_ROOT, "examples", "fish_target.txt"))
+    flat = {}
+
+    def nonrigid_case(name, src, tgt, sigma2, w, k_warm, **ctor):
+        cls = ref.cpd.ConstrainedNonRigidCPD if "idx_source" in ctor else ref.cpd.NonRigidCPD
+        reg = cls(src.copy(), **ctor)
+        if k_warm:  # a few EM iterations first: the M-step then starts from a non-trivial W
+            reg.registration(tgt.copy(), w=w, maxiter=k_warm, tol=-1.0)
+        else:
+            reg._initialize(tgt.copy())
+        t_source = reg._tf_obj.transform(src)
+        es = reg.expectation_step(t_source, tgt, sigma2, w)
+        res = reg.maximization_step(tgt, es, sigma2)
+        pre = "nonrigid/%s/" % name
+        flat[pre + "source"], flat[pre + "target"] = src, tgt
+        flat[pre + "t_source"] = t_source
+        flat[pre + "sigma2_p"], flat[pre + "w"], flat[pre + "k_warm"] = np.asarray(sigma2), np.asarray(w), np.asarray(k_warm)
+        flat[pre + "pt1"], flat[pre + "p1"], flat[pre + "px"], flat[pre + "n_p"] = es.pt1, es.p1, es.px, np.asarray(es.n_p)
+        flat[pre + "out_w"] = res.transformation.w.copy()
+        flat[pre + "out_tsource"] = res.transformation.transform(src)
+        flat[pre + "out_sigma2"], flat[pre + "out_q"] = np.asarray(res.sigma2), np.asarray(res.q)
+        for k, v in ctor.items():
+            flat[pre + "ctor_" + k] = np.asarray(v)
+        print("mstep nonrigid %-22s sigma2=%.10e" % (name, res.sigma2))
+
+    nonrigid_case("fish_cold", fish_s, fish_t, 5.0e-2, 0.0, 0)
+    nonrigid_case("fish_warm3_w01", fish_s, fish_t, 4.0e-3, 0.1, 3)
+    s, t = synthetic.nonrigid_pair(1100, m=900, seed=21)
+    nonrigid_case("synth_900_warm2", s, t, 2.0e-3, 0.0, 2, beta=1.5, lmd=3.0)
+    idx = np.array([0, 10, 20, 30, 40, 50, 60, 70, 80, 90])
+    nonrigid_case("fish_constrained", fish_s, fish_t, 1.0e-2, 0.0, 2, alpha=1e-4, idx_source=idx, idx_target=idx)
+
+    def filterreg_case(name, src, tgt, rot, t, sigma2, w, update_sigma2, normals=None):
+        objective = "pt2pl" if normals is not None else "pt2pt"
+        reg = ref.filterreg.RigidFilterReg(src.copy(), normals, sigma2, update_sigma2,
+                                           tf_init_params={"rot": rot, "t": t})
+        t_source = reg._tf_result.transform(src)
+        es = reg.expectation_step(t_source, tgt, tgt, sigma2, update_sigma2, objective)
+        res = reg.maximization_step(t_source, tgt, es, w=w, objective_type=objective)
+        pre = "filterreg/%s/" % name
+        flat[pre + "t_source"], flat[pre + "target"] = t_source, tgt
+        flat[pre + "rot_p"], flat[pre + "t_p"] = np.asarray(rot), np.asarray(t)
+        flat[pre + "sigma2"], flat[pre + "w"] = np.asarray(float(sigma2)), np.asarray(w)
+        flat[pre + "m0"], flat[pre + "m1"] = es.m0, es.m1
+        if es.m2 is not None:
+            flat[pre + "m2"] = es.m2
+        if es.nx is not None:
+            flat[pre + "nx"] = es.nx
+        flat[pre + "out_rot"], flat[pre + "out_t"] = np.asarray(res.transformation.rot), np.asarray(res.transformation.t)
+        flat[pre + "out_sigma2"], flat[pre + "out_q"] = np.asarray(float(res.sigma2)), np.asarray(float(res.q))
+        print("mstep filterreg %-22s sigma2=%.9e q=%.9e" % (name, res.sigma2, res.q))
+
+    s, t, _ = synthetic.filterreg_pair(3000, m=2200, seed=31)
+    r0 = synthetic.rot_zx(4.0, -3.0)
+    filterreg_case("synth_pt2pt_update", s, t, r0, np.array([0.01, -0.02, 0.005]), 4.0e-3, 0.05, True)
+    filterreg_case("synth_pt2pt_fixed_w0", s, t, np.identity(3), np.zeros(3), 2.0e-2, 0.0, False)
+    filterreg_case("fish2d_update", fish_s, fish_t, np.identity(2), np.zeros(2), 5.0e-2, 0.1, True)
+    s, t, nrm, _ = synthetic.pt2pl_pair(3000, m=2000, seed=33)
+    filterreg_case("synth_pt2pl_update", s, t, r0, np.zeros(3), 6.0e-3, 0.05, True, normals=nrm)
+    flat["filterreg/synth_pt2pl_update/normals"] = nrm
+    out = os.path.join(HERE, "mstep_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mstep":
+        main_mstep()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "bcpd":
         main_bcpd()
         sys.exit(0)

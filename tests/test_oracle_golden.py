@@ -113,3 +113,40 @@ def test_constrained_nonrigid_matches_reference():
         g = co.rbf_kernel(c["source"], c["source"], 2.0)
         ts = co.transform("nonrigid", params, c["source"], g)
         assert rel_err(ts, c["out_tsource"]) < 1e-6, name
+
+
+@pytest.mark.parametrize("name", ["fish_cold", "fish_warm3_w01", "synth_900_warm2", "fish_constrained"])
+def test_nonrigid_mstep_restatement_matches_reference_single_call(mstep_golden, name):
+    """oracle.cpd_numpy.mstep_nonrigid(_constrained) against one NonRigidCPD.maximization_step call of the reference
+    on the reference's own E-step arrays (cpd.py:272-303, :377-404)."""
+    c = mstep_golden.case("nonrigid/" + name)
+    es = co.EstepResult(c["pt1"], c["p1"], c["px"], c["n_p"])
+    g = co.rbf_kernel(c["source"], c["source"], float(c.get("ctor_beta", 2.0)))
+    lmd = float(c.get("ctor_lmd", 2.0))
+    if "ctor_idx_source" in c:
+        m, dim = c["source"].shape
+        p1_t, px_t = np.zeros(m), np.zeros((m, dim))
+        p1_t[c["ctor_idx_source"]] = 1.0
+        px_t[c["ctor_idx_source"]] = c["target"][c["ctor_idx_target"]]
+        p, s2, q = co.mstep_nonrigid_constrained(c["source"], c["target"], es, c["sigma2_p"], g, lmd,
+                                                 float(c["ctor_alpha"]), p1_t, px_t)
+    else:
+        p, s2, q = co.mstep_nonrigid(c["source"], c["target"], es, c["sigma2_p"], g, lmd)
+    assert abs(s2 - c["out_sigma2"]) <= 1e-9 * c["out_sigma2"]
+    assert np.max(np.abs(p["w"] - c["out_w"])) <= 1e-6 * np.max(np.abs(c["out_w"]))
+
+
+@pytest.mark.parametrize("name", ["synth_pt2pt_update", "synth_pt2pt_fixed_w0", "fish2d_update", "synth_pt2pl_update"])
+def test_filterreg_mstep_restatement_matches_reference_single_call(mstep_golden, name):
+    """oracle.filterreg_numpy.maximization_step against one RigidFilterReg._maximization_step call of the reference
+    (filterreg.py:158-196; Kabsch / twist solve restated from cc/kabsch.cc, cc/point_to_plane.cc)."""
+    from oracle import filterreg_numpy as fo
+
+    c = mstep_golden.case("filterreg/" + name)
+    es = fo.EstepResult(c["m0"], c["m1"], c.get("m2"), c.get("nx"))
+    res = fo.maximization_step(c["t_source"], c["target"], es, c["rot_p"], c["t_p"], c["sigma2"], w=c["w"],
+                               objective_type="pt2pl" if "nx" in c else "pt2pt")
+    assert np.max(np.abs(res.rot - c["out_rot"])) < 2e-6
+    assert np.max(np.abs(res.t - c["out_t"])) < 2e-6
+    assert abs(res.sigma2 - c["out_sigma2"]) <= 1e-7 * c["out_sigma2"]
+    assert abs(res.q - c["out_q"]) <= 2e-6 * abs(c["out_q"])
