@@ -126,6 +126,9 @@ class CoherentPointDrift(abc.ABC):
         rank, world = pdist.world()
         cy, cx = self._centres(source, target)
         rows = pdist.spatial_shard(target, rank, world)
+        if len(rows) == 0:
+            raise ValueError("the target has %d points, fewer than the %d ranks it is sharded over."
+                             % (target.shape[0], world))
         plan = self._plan if self._plan is not None else CpdPlan(self._device)
         self._plan = plan
         self._cy, self._cx = cy, cx
@@ -135,12 +138,12 @@ class CoherentPointDrift(abc.ABC):
         mom = plan.moments_tensor() if pdist.initialized() else None
         plan.init_sums()
         if mom is not None:
-            pdist.all_reduce_sum_(mom)
+            pdist.all_reduce_sum_(mom, getattr(plan, "stream", None))
         return plan
 
     def _all_reduce_moments(self, plan):
         if plan._moments_tensor is not None:
-            pdist.all_reduce_sum_(plan._moments_tensor)
+            pdist.all_reduce_sum_(plan._moments_tensor, getattr(plan, "stream", None))
 
     def _restart(self):
         """Put an initialised plan back to the start of its registration (sigma2 initialiser, q0, initial transform)
@@ -149,7 +152,7 @@ class CoherentPointDrift(abc.ABC):
         mom = plan.moments_tensor() if pdist.initialized() else None
         plan.init_sums()
         if mom is not None:
-            pdist.all_reduce_sum_(mom)
+            pdist.all_reduce_sum_(mom, getattr(plan, "stream", None))
         plan.init_params(self._init_block)
         return plan
 
@@ -371,7 +374,7 @@ class NonRigidCPD(CoherentPointDrift):
             __cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr_, False), "version": 2}
 
         t = torch.as_tensor(_View(), device="cuda:%d" % plan.device)
-        pdist.all_reduce_sum_(t)
+        pdist.all_reduce_sum_(t, plan.stream)
 
     def _device_mstep(self, plan):
         plan.mstep_nonrigid(self._lmd)

@@ -81,11 +81,23 @@ def spatial_shard(target, rank, world_size):
     return morton_order(target)[lo:hi]
 
 
-def all_reduce_sum_(tensor):
-    """In-place SUM all-reduce of a torch tensor (device tensor -> RCCL over xGMI, CPU tensor -> gloo)."""
+def all_reduce_sum_(tensor, stream=None):
+    """In-place SUM all-reduce of a torch tensor (device tensor -> RCCL over xGMI, CPU tensor -> gloo).
+
+    ``stream``: the raw hipStream_t (int) the tensor's producer / consumer kernels run on.  torch.distributed orders
+    a collective against torch's CURRENT stream, so when the plan was created under a different stream than the one
+    current now, the collective is issued under that stream instead - otherwise it would race the plan's kernels.
+    """
     import torch.distributed as dist
 
     if dist.is_available() and dist.is_initialized():  # also with one rank: keeps the collective path exercised
+        if stream is not None and getattr(tensor, "is_cuda", False):
+            import torch
+
+            if int(torch.cuda.current_stream(tensor.device).cuda_stream) != int(stream):
+                with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=tensor.device)):
+                    dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
+                return tensor
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
     return tensor
 

@@ -88,3 +88,33 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_oracle():
             assert np.max(np.abs(a["t"] - p["t"])) <= TOL_T * max(1.0, np.max(np.abs(p["t"]))), kind
             if kind == "rigid":
                 assert abs(a["scale"] - p["scale"]) <= TOL_T * p["scale"]
+
+
+def test_bench_under_torchrun_with_rccl_when_two_gpus_are_present():
+    """RCCL with real peers: `torchrun --nproc-per-node 2 bench.py --gpus 2` (one rank per GPU, backend nccl = RCCL,
+    the per-iteration all-reduce of the 32-double moment block over xGMI) must reproduce the single-GPU EM state.
+    Self-skips on a one-GPU box (the driver's multi-GPU node is the first place this can run)."""
+    import json
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--steps", "6", "--warmup", "1", "--workload", "rigid_20k", "--no-cpu-baseline", "--no-other-workloads"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, cwd=root, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          os.path.join(root, "bench.py"), "--gpus", "2"] + common, cwd=root, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert b["n_gpus"] == 2 and b["value"] > 0
+    assert abs(a["result"]["sigma2"] - b["result"]["sigma2"]) <= 1e-5 * a["result"]["sigma2"]
+    assert abs(a["result"]["q"] - b["result"]["q"]) <= 1e-5 * abs(a["result"]["q"])
