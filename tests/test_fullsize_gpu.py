@@ -2,10 +2,10 @@
 oracle run on the exact inputs ``bench.py`` uses, for a handful of EM iterations, and must agree within the
 north-star tolerances (transform 1e-4 relative, sigma2 1e-5 relative).
 
-  C1  RigidCPD   N = M = 100 000   5 iterations from the identity (dense sweeps) and 3 iterations continued from the
+  C1  RigidCPD   N = M = 100 000   3 iterations from the identity (dense sweeps) and 2 iterations continued from the
                                    GPU's own state after 25 (late regime: 196 segments / 49 partial planes, ~97 % of
-                                   the (wave, group) blocks culled) - oracle/cpd_estep_c.c, ~5 s per iteration
-  C2  AffineCPD  N = M = 200 000   2 iterations from the identity and 2 continued from iteration 22
+                                   the (wave, group) blocks culled) - oracle/cpd_estep_c.c, ~6 s per iteration
+  C2  AffineCPD  N = M = 200 000   1 iteration from the identity and 1 continued from iteration 22 (~29 s each)
   C3  NonRigid   N = M = 12 000    3 iterations (largest M whose three M x M fp64 temporaries the numpy oracle holds
                                    comfortably; the blocked Cholesky walks 94 diagonal blocks / 24 outer panels)
   C4  FilterReg  N = M = 500 000   5 iterations, 5 % outliers, sigma2 updated - oracle/filterreg_numpy.py on the C lattice
@@ -63,12 +63,12 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
     from probreg_amd import cpd, synthetic
 
     if config.startswith("C1"):
-        kind, n, k_dense, k_warm, k_late = "rigid", 100000, 5, 25, 3
+        kind, n, k_dense, k_warm, k_late = "rigid", 100000, 3, 25, 2
         src, tgt, _ = synthetic.rigid_pair(n, seed=0)
         reg = cpd.RigidCPD(src)
         ident = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
     else:
-        kind, n, k_dense, k_warm, k_late = "affine", 200000, 2, 22, 2
+        kind, n, k_dense, k_warm, k_late = "affine", 200000, 1, 22, 1
         src, tgt, _ = synthetic.affine_pair(n, seed=0)
         reg = cpd.AffineCPD(src)
         ident = dict(b=np.identity(3), t=np.zeros(3))
