@@ -78,6 +78,16 @@ int prg_cpd_destroy(prg_cpd* h);
  * is an exact zero in fp32.  The non-rigid path keeps the source unsorted. */
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
 
+/* Engine of the E-step's DENSE regime (sigma2 large: every pair contributes).  mode 0 (default): the vector-pipe sweeps.
+ * mode 1: the column pass runs on the matrix cores (f32 MFMA distance blocks) while
+ * |log2(e) / (2 sigma2)| * (squared diagonal of the target's bounding box) < bound (default 400) and the registration
+ * then stays on the culled vector-pipe sweeps; mode 2: BOTH sweeps on the matrix cores whatever the bound says.  On
+ * gfx950 f32 MFMA executes on the vector ALUs (tools/mfma_overlap.hip), so modes 1 / 2 are parity-tested alternatives
+ * of equal speed, not the default.  bound = 0 keeps the current value.  prg_cpd_last_estep_engine reports which engine
+ * the last E-step's column pass used (1 = matrix cores). */
+int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound);
+int prg_cpd_last_estep_engine(prg_cpd* h, int* engine);
+
 /* Upload the (already centred) source cloud, replicated on every device.
  * Replaces: CoherentPointDrift.set_source, cpd.py:61-62. */
 int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim);

@@ -55,6 +55,8 @@ SIGNATURES = {
     "prg_cpd_create": [_pp, _i, _vp],
     "prg_cpd_destroy": [_vp],
     "prg_cpd_set_options": [_vp, _i, _i, _i],
+    "prg_cpd_set_dense_engine": [_vp, _i, _d],
+    "prg_cpd_last_estep_engine": [_vp, _c.POINTER(_i)],
     "prg_cpd_set_source": [_vp, _vp, _i64, _i],
     "prg_cpd_set_target": [_vp, _vp, _i64, _i, _i64],
     "prg_cpd_bind_moments": [_vp, _vp],

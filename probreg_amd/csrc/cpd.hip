@@ -16,6 +16,8 @@
 #include <math.h>
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 
 #include "cpd_plan.h"
 #include "cpd_sweeps.h"
@@ -217,7 +219,10 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
         for (int k = 1; k < kBlock / 64; ++k) mv = fmaxf(mv, wave_moved[k]);
         if (mv > 0.f) atomicMax(motion + slot, __float_as_uint(mv));
     }
-    if (i == 0) motion[slot ^ 1] = 0u;
+    if (i == 0) {
+        motion[slot ^ 1] = 0u;
+        motion[4 + slot] = 0u;  // k_colfinal of THIS E-step collects the largest column minimum here
+    }
     block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta);
 }
 
@@ -244,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict_
     o[7] = wmin;
 }
 
-// (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip)
+// (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip / cpd_sweeps_mfma.hip)
 
 // Merge the S partial (min, sum) pairs of each column in fp64; apply cpd.py:78-82:
 //   den == 0 -> eps32 (then the whole column of P is 0/eps = 0), den += c.
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
                                                      int nseg, int64_t ncap, int64_t n, float* __restrict__ pt1,
                                                      const double* __restrict__ params, double w, double m_over_n,
                                                      int dim, float* __restrict__ colmin, float* __restrict__ colmin_g,
-                                                     float* __restrict__ gmeta) {
+                                                     float* __restrict__ gmeta, int seed_mode,
+                                                     unsigned* __restrict__ stat, int slot) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     float b = 0.f;  // pads keep b = 0
     float cmin = 0.f;  // pads do not widen the seed
@@ -266,6 +272,16 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     // own (their 1-ulp error is far below the fp32 sums they multiply); the running sum is fp64.
     float gmin = INFINITY, goff = INFINITY;  // goff = smallest offset seen = offset of the column minimum
     double ssum = 0.0;
+    if (seed_mode) {
+        // matrix-core column pass: every segment's sum is relative to the SAME offset, known before the sweep
+        // (prg::col_seed_offset from the previous E-step's minimum, still in colmin[i], and this E-step's motion)
+        goff = prg::col_seed_offset(kkf, colmin[i], __uint_as_float(stat[slot]));
+        for (int s0 = 0; s0 < nseg; ++s0) {
+            const float2 p = colpart[(int64_t)s0 * ncap + i];
+            gmin = fminf(gmin, p.x);
+            ssum += (double)p.y;
+        }
+    } else
     for (int s0 = 0; s0 < nseg; s0 += 8) {
         float2 p[8];
 #pragma unroll
@@ -305,6 +321,16 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     {
         const float gm = half_max(cmin);
         if ((threadIdx.x & 31) == 0) colmin_g[(int64_t)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5)] = gm;
+        // largest column minimum of the whole shard: the host's bracket check for the next matrix-core column pass
+        __shared__ float wg_max[kBlock / 32];
+        if ((threadIdx.x & 31) == 0) wg_max[threadIdx.x >> 5] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = wg_max[0];
+#pragma unroll
+            for (int k = 1; k < kBlock / 32; ++k) mx = fmaxf(mx, wg_max[k]);
+            if (mx > 0.f) atomicMax(stat + 4 + slot, __float_as_uint(mx));  // (+inf orders above every finite value)
+        }
     }
     // refresh the b_n range of this workgroup's 8 groups (their boxes are static)
     if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta);
@@ -349,7 +375,8 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
                                                         int64_t m, const float4* __restrict__ src4,
                                                         const float4* __restrict__ z4, double* __restrict__ rowacc,
                                                         double* __restrict__ mompart,
-                                                        const unsigned char* __restrict__ rowflag) {
+                                                        const unsigned char* __restrict__ rowflag,
+                                                        const float4* __restrict__ rorig) {
     double a[kMomComp];
 #pragma unroll
     for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
@@ -392,7 +419,9 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
             u[2] += (double)v3 + k2 * (double)w3;
             e += (double)v4 + k2 * (double)w4;
         }
-        const float4 zf = z4[i], yf = src4[i];
+        // reference point of the residual sums: the row's own z_m (VALU sweeps) or the origin of its 512-row block
+        // (matrix-core sweeps) - the identities below hold for any reference
+        const float4 zf = rorig ? rorig[i / prg::kMfmaWgPoints] : z4[i], yf = src4[i];
         const double z[3] = {zf.x, zf.y, zf.z};
         const double y[3] = {yf.x, yf.y, yf.z};
         double px[3];
@@ -665,8 +694,9 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount})
+                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount, (void*)h->rorig})
         if (q) (void)hipFree(q);
+    h->rorig = nullptr;
     h->wgcount = nullptr;
     h->wg_cap = 0;
     h->perm_src = h->perm_tgt = nullptr;
@@ -698,9 +728,20 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
 int cap_for(int64_t n) { return (int)prg::round_up(n + 64 * prg::kSuper + 1024, 1024); }
 
 // Morton (Z-curve) order of a cloud: sorted position -> original index (morton.h), uploaded as the plan's permutation.
-int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev) {
+int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev, double* ext2 = nullptr) {
     std::vector<float> host((size_t)n * dim);
     PRG_HIP(hipMemcpy(host.data(), pts_hd, host.size() * sizeof(float), hipMemcpyDefault));
+    if (ext2) {  // squared diagonal of the cloud's bounding box (scale of the dense-regime criterion)
+        *ext2 = 0.0;
+        for (int k = 0; k < dim; ++k) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int64_t i = 0; i < n; ++i) {
+                lo = std::min(lo, host[(size_t)i * dim + k]);
+                hi = std::max(hi, host[(size_t)i * dim + k]);
+            }
+            *ext2 += (double)(hi - lo) * (double)(hi - lo);
+        }
+    }
     const std::vector<int> perm = prg::morton_order(host.data(), n, dim);
     if (*perm_dev) (void)hipFree(*perm_dev);
     *perm_dev = nullptr;
@@ -763,6 +804,7 @@ int prg_cpd_create(prg_cpd** out, int device, void* hip_stream) {
     PRG_REQUIRE(h != nullptr, PRG_ERR_NOMEM, "prg_cpd_create: out of host memory");
     h->device = device;
     h->stream = (hipStream_t)hip_stream;
+    if (const char* eng = getenv("PRG_DENSE_ENGINE")) h->dense_engine = std::max(0, std::min(2, atoi(eng)));  // experiments
     hipError_t e = hipMalloc((void**)&h->state, (PRG_NMOMENTS + PRG_NPARAMS) * sizeof(double));
     if (e != hipSuccess) {
         delete h;
@@ -810,9 +852,10 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     if (cap != h->Mcap || !h->zmeta) {
         PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
         if (!h->motion) {
-            PRG_TRY(ensure_exact(&h->motion, 2));
-            PRG_HIP(hipMemsetAsync(h->motion, 0, 2 * sizeof(unsigned), h->stream));
+            PRG_TRY(ensure_exact(&h->motion, 8));
+            PRG_HIP(hipMemsetAsync(h->motion, 0, 8 * sizeof(unsigned), h->stream));
         }
+        PRG_TRY(ensure_exact(&h->rorig, (size_t)(cap / prg::kMfmaWgPoints) + 4));
     }
     h->M = m;
     h->D = dim;
@@ -894,12 +937,16 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
         PRG_TRY(ensure_exact(&h->colmin, (size_t)cap + (size_t)cap / prg::kGroup));  // + per-group maxima
         PRG_HIP(hipMemsetAsync(h->colmin, 0, ((size_t)cap + (size_t)cap / prg::kGroup) * sizeof(float), h->stream));
     }
+    if (!h->motion) {
+        PRG_TRY(ensure_exact(&h->motion, 8));
+        PRG_HIP(hipMemsetAsync(h->motion, 0, 8 * sizeof(unsigned), h->stream));
+    }
     h->N = n_local;
     h->Nglobal = n_global;
     h->D = dim;
     h->Ncap = cap;
     if (h->opt_sort_tgt) {
-        PRG_TRY(morton_permutation(h, target_hd, n_local, dim, &h->perm_tgt));
+        PRG_TRY(morton_permutation(h, target_hd, n_local, dim, &h->perm_tgt, &h->text2));
     } else if (h->perm_tgt) {
         (void)hipFree(h->perm_tgt);
         h->perm_tgt = nullptr;
@@ -950,6 +997,22 @@ int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_ro
     return PRG_OK;
 }
 
+int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_dense_engine: NULL handle");
+    PRG_REQUIRE(mode >= 0 && mode <= 2, PRG_ERR_INVALID, "prg_cpd_set_dense_engine: mode must be 0, 1 or 2");
+    PRG_REQUIRE(bound >= 0.0, PRG_ERR_INVALID, "prg_cpd_set_dense_engine: bound must be >= 0 (0 keeps the default)");
+    h->dense_engine = mode;
+    if (bound > 0.0) h->dense_bound = bound;
+    h->mfma_off = false;
+    return PRG_OK;
+}
+
+int prg_cpd_last_estep_engine(prg_cpd* h, int* engine) {
+    PRG_REQUIRE(h && engine, PRG_ERR_INVALID, "prg_cpd_last_estep_engine: NULL argument");
+    *engine = h->last_estep_mfma ? 1 : 0;
+    return PRG_OK;
+}
+
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull) {
     PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_options: NULL handle");
     PRG_REQUIRE(!h->have_source && !h->have_target, PRG_ERR_STATE,
@@ -990,6 +1053,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     PRG_HIP(hipGetLastError());
     if (init_params_host) PRG_HIP(hipStreamSynchronize(h->stream));  // host buffer may be reused by the caller
     h->have_colmin = false;  // a new registration starts: its first column pass takes no seed from the previous one
+    h->mfma_off = false;     // ... and it starts in the dense regime
     return PRG_OK;
 }
 
@@ -1034,8 +1098,13 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // partial planes in HBM: one per segment, or one per four segments for the culled sweeps
     const int PA = use_cull ? (int)prg::ceil_div(SA, 4) : SA, PB = use_cull ? (int)prg::ceil_div(SB, 4) : SB;
     PRG_REQUIRE(!use_cull || PB <= 64, PRG_ERR_INVALID, "prg_cpd_estep: at most 256 row-pass segments with culling");
-    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)PA * h->Ncap));
-    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)PB * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
+    // matrix-core sweeps (dense regime, decided per E-step below): segments of whole 512-point chunks, one plane each
+    const bool mfma_possible = use_cull && h->dense_engine > 0 && !h->srcw;
+    static const int mfma_seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;  // 0: fill the chip once
+    const int PAm = mfma_possible ? prg::mfma_planes(h->N, h->M, mfma_seg) : 0,
+              PBm = mfma_possible ? prg::mfma_planes(h->M, h->N, mfma_seg) : 0;
+    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)std::max(PA, PAm) * h->Ncap));
+    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)std::max(PB, PBm) * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
     if (use_cull) {  // per-workgroup counters of evaluated (wave, group) blocks (prg_cpd_pair_counts)
         const int64_t need = std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->M, 128) * PB);
@@ -1060,20 +1129,48 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
             h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw,
             h->bcpd ? h->W : nullptr);  // pad-only blocks are static
+    // Dense regime on the matrix cores?  The host decides per E-step from three numbers the device already has:
+    // sigma2, the source motion of this transform and the largest column minimum of the previous E-step (DESIGN.md
+    // 3.1c).  One small read-back per E-step while the registration is in the dense regime; once sigma2 has fallen to
+    // where the culled VALU sweeps skip most of the pairs (|kk| * extent^2 above the bound) the registration stays on
+    // them and never synchronises again.
+    bool use_mfma = false;
+    if (mfma_possible && !h->mfma_off && h->have_colmin) {
+        if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
+        float* st = reinterpret_cast<float*>(h->pinned + 40);
+        PRG_HIP(hipMemcpyAsync(st, h->motion, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        PRG_HIP(hipMemcpyAsync(h->pinned + 39, h->params + 13, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        PRG_HIP(hipStreamSynchronize(h->stream));
+        const double sigma2 = h->pinned[39], nk = kLog2e / (2.0 * sigma2);
+        const double mo = st[slot], cmax = st[4 + (slot ^ 1)], r = sqrt(cmax);
+        const double width = r >= mo ? 4.0 * r * mo : (r + mo) * (r + mo);  // of the bracket of a column minimum
+        const bool dense = h->dense_engine >= 2 || nk * h->text2 < h->dense_bound;
+        if (!dense) h->mfma_off = true;
+        use_mfma = dense && sigma2 > 0.0 && std::isfinite(cmax) && nk * width < 150.0;
+    }
+    h->last_estep_mfma = use_mfma;
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
-    if (use_cull)
+    if (use_mfma)
+        prg::launch_colpass_mfma(h, mfma_seg);
+    else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, h->have_colmin && !h->srcw);  // the seed bound assumes unweighted distances
     else if (ra < 0)
         prg::launch_colpass_scalar(h, RA, SA, segA);
     else
         prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
-    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, PA, h->Ncap, h->N, h->pt1, h->params, w,
+    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, use_mfma ? PAm : PA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
                                                       h->colmin + h->Ncap,
-                                                      use_cull ? h->tmeta : nullptr);
+                                                      use_cull ? h->tmeta : nullptr, use_mfma ? 1 : 0, h->motion, slot);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
-    if (use_cull)
+    // (the row pass gains nothing from the matrix cores on gfx950 - f32 MFMA executes on the vector ALUs and its four
+    // contraction MFMAs cost what the FMAs they replace cost, profiles/r2_mfma_valu_overlap_microbench.log - so the
+    // automatic mode keeps the culled vector-pipe row pass; mode 2 runs both sweeps on the matrix cores for the tests)
+    const bool row_mfma = use_mfma && h->dense_engine >= 2;
+    if (row_mfma)
+        prg::launch_rowpass_mfma(h, mfma_seg);
+    else if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);
     else if (rb < 0)
         prg::launch_rowpass_scalar(h, RB, SB, segB);
@@ -1081,10 +1178,11 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         prg::launch_rowpass_packed(h, RB, SB, segB);
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
     const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
-    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, PB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
+    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, row_mfma ? PBm : PB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart,
-                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)PB * 5 * h->Mcap)
-                                                           : nullptr);
+                                                  use_cull && !row_mfma ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)PB * 5 * h->Mcap)
+                                                                        : nullptr,
+                                                  row_mfma ? h->rorig : nullptr);
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());

@@ -46,8 +46,18 @@ struct prg_cpd {
     float* tmeta = nullptr;     // [Ncap/32][8] per group of 32 target points: lo.xyz, hi.xyz, max b_n, min b_n
     float* colmin = nullptr;    // [Ncap] min_m d^2 per column from the previous E-step (seed of the cull bound),
                                 // followed by [Ncap/32] per-group maxima of it
-    unsigned* motion = nullptr; // float bits of max_m |z_new - z_old| of the last transform
+    unsigned* motion = nullptr; // [8] float bits, slot = parity of the E-step: [0,1] max_m |z_new - z_old| of the transform,
+                                // [4,5] largest column minimum of the E-step (what the host needs to decide whether the
+                                // matrix-core column pass may run)
     bool have_colmin = false;
+    // matrix-core (dense regime) sweeps
+    float4* rorig = nullptr;    // [Mcap/512] origin of each 512-row block of the last matrix-core row pass
+    int dense_engine = 0;       // 0: VALU sweeps only (default: measured as fast), 1: matrix-core column
+                                // pass in the dense regime, 2: both sweeps on the matrix cores, always (tests)
+    double dense_bound = 400.0;  // dense regime = |kk| * (target bounding-box diagonal)^2 below this (C1: sigma2 > ~1e-2)
+    bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
+    bool last_estep_mfma = false;
+    double text2 = 0.0;         // squared diagonal of the local target's bounding box
     // measurement hook: evaluated (wave, group) blocks per workgroup of the last culled column / row pass
     // ([0, wg_cap) column pass, [wg_cap, 2 wg_cap) row pass); wg_col / wg_row = workgroups of the last launches,
     // dense_pairs_* = pairs covered by the last NON-culled launches (0 when the culled kernels ran)

@@ -21,6 +21,26 @@ __device__ __forceinline__ float col_offset(float kk, float dmin) {
     return p > 0.f ? __uint_as_float(__float_as_uint(p) - 1u) : 0.f;
 }
 
+// ---- matrix-core sweeps (cpd_sweeps_mfma.hip) ----
+constexpr int kMfmaOwn = 8;                       // tiles of 16 points a wave owns (128 rows / columns)
+constexpr int kMfmaWgPoints = 4 * 16 * kMfmaOwn;  // points a workgroup owns and shifts to one origin (512)
+// Exponent offset of a column's sum in the matrix-core column pass, from what is known BEFORE the sweep: cm = min d^2 of
+// the previous E-step, mo = largest source displacement since.  This E-step's minimum lies in
+// [max(sqrt(cm) - mo, 0)^2, (sqrt(cm) + mo)^2] = [lo, hi]; with g = |kk| (hi - lo) the offset |kk| lo + max(g - 80, 0) keeps
+// the largest term's exponent inside [-80, max(g - 80, 0)]: no overflow and no loss to flushed terms while g < 180 (the
+// host checks the widest bracket).  Explicitly rounded operations: the column pass and k_colfinal must agree bit for bit.
+__device__ __forceinline__ float col_seed_offset(float kk, float cm, float mo) {
+    const float r = __fsqrt_rn(cm);
+    const float rl = fmaxf(__fsub_rn(r, mo), 0.f), rh = __fadd_rn(r, mo);
+    const float lo = __fmul_rn(rl, rl), hi = __fmul_rn(rh, rh);
+    const float nk = -kk;
+    const float g = __fmul_rn(nk, __fsub_rn(hi, lo));
+    return __fadd_rn(__fmul_rn(nk, lo), fmaxf(__fsub_rn(g, 80.f), 0.f));
+}
+void launch_colpass_mfma(prg_cpd* h, int S);  // S segments of the streamed cloud (0 = fill the chip once)
+void launch_rowpass_mfma(prg_cpd* h, int S);
+int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
+
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
 constexpr int kSuper = 256;    // quantum of a culled segment's length (8 groups)
 // culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup

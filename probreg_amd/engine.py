@@ -65,6 +65,17 @@ class CpdPlan(object):
     def set_options(self, sort_source=True, sort_target=True, cull=True):
         check(lib.prg_cpd_set_options(self._h, int(sort_source), int(sort_target), int(cull)))
 
+    def set_dense_engine(self, mode=0, bound=0.0):
+        """0: vector-pipe sweeps only (default), 1: matrix-core column pass in the dense regime, 2: both sweeps on the
+        matrix cores always (prg_cpd_set_dense_engine)."""
+        check(lib.prg_cpd_set_dense_engine(self._h, int(mode), float(bound)))
+
+    def last_estep_engine(self):
+        """1 if the last E-step ran on the matrix cores, 0 for the vector-pipe sweeps."""
+        e = ctypes.c_int(0)
+        check(lib.prg_cpd_last_estep_engine(self._h, ctypes.byref(e)))
+        return int(e.value)
+
     def set_source(self, source):
         a = self._f32(source)
         self.m, self.dim = int(a.shape[0]), int(a.shape[1])

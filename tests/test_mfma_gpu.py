@@ -1,0 +1,118 @@
+"""The matrix-core (f32 MFMA) E-step sweeps of the dense regime (csrc/cpd_sweeps_mfma.hip) against the
+oracle and against the vector-pipe sweeps on the same state.  Reference: probreg/cpd.py:71-88."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_TF = 1e-4
+TOL_SIGMA2 = 1e-5
+
+
+def _plan_with_state(src, tgt, k_warm, engine):
+    from probreg_amd import _lib, cpd
+
+    reg = cpd.RigidCPD(src)
+    reg._initialize(tgt)
+    plan = reg._plan
+    plan.set_dense_engine(engine)
+    for _ in range(k_warm):
+        plan.estep(0.0)
+        plan.mstep(_lib.PRG_TF_RIGID, True)
+    return reg, plan
+
+
+@pytest.mark.parametrize("n,m,k_warm,w", [(6000, 6000, 1, 0.0), (9000, 5000, 3, 0.1), (3001, 4097, 2, 0.0)])
+def test_mfma_estep_matches_oracle_and_vector_sweeps(n, m, k_warm, w):
+    from oracle import cpd_c, cpd_numpy as co
+    from probreg_amd import synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(n, m=m, seed=17)
+    reg, plan = _plan_with_state(src, tgt, k_warm, 0)  # warm-up on the vector-pipe sweeps: both engines see ONE state
+    state = plan.get_params()
+    out = {}
+    for engine in (0, 2):
+        plan.set_dense_engine(engine)
+        plan.set_params(state)
+        plan.estep(w)
+        assert plan.last_estep_engine() == (1 if engine == 2 else 0)
+        out[engine] = (plan.get_moments(), plan.get_estep())
+    res = reg._result_from_params(state)
+    ts = co.transform("rigid", dict(rot=res.transformation.rot, t=res.transformation.t, scale=res.transformation.scale), src)
+    pt1, p1, px, n_p = cpd_c.expectation_step(ts, tgt, res.sigma2, w)
+    for engine in (0, 2):
+        mom, (g_pt1, g_p1, g_px) = out[engine]
+        g_px = g_px + np.outer(g_p1, reg._cx)  # the plan works on the centred target
+        assert abs(mom[0] - n_p) < 2e-6 * n_p, engine
+        assert np.max(np.abs(g_pt1 - pt1)) < 2e-5, engine
+        assert np.max(np.abs(g_p1 - p1)) < 2e-5 * max(1.0, p1.max()), engine
+        assert np.max(np.abs(g_px - px)) < 2e-5 * max(1.0, np.abs(px).max()), engine
+    # the 23 moments the M-step consumes are sums over ~n_p points of O(1) terms (some cancel to ~0 in the centred
+    # frame): both engines within 2e-6 n_p of each other
+    a, b = out[0][0][:23], out[2][0][:23]
+    assert np.max(np.abs(a - b)) < 2e-6 * n_p
+
+
+def test_auto_engine_registration_matches_oracle_and_switches_engines():
+    """Engine mode 1: matrix-core column pass while |kk| * extent^2 is below the bound, culled vector-pipe sweeps
+    afterwards; the whole trajectory stays within the north-star tolerances of the fp64 oracle."""
+    from oracle import cpd_c, cpd_numpy as co
+    from probreg_amd import _lib, cpd, synthetic
+
+    n, k = 20000, 18
+    src, tgt, _ = synthetic.rigid_pair(n, seed=4)
+    reg = cpd.RigidCPD(src)
+    reg._initialize(tgt)
+    plan = reg._plan
+    plan.set_dense_engine(1)
+    engines = []
+    for _ in range(k):
+        plan.estep(0.0)
+        engines.append(plan.last_estep_engine())
+        plan.mstep(_lib.PRG_TF_RIGID, True)
+    res = reg._result_from_params(plan.get_params())
+    assert engines[0] == 0            # no column minima yet: the first E-step is the vector-pipe one
+    assert sum(engines) >= 4          # the dense regime's column passes ran on the matrix cores ...
+    assert engines[-1] == 0           # ... and the late regime did not
+    first_off = engines[1:].index(0) + 1
+    assert all(e == 0 for e in engines[first_off:])  # once left, never re-entered
+    params = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
+    sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
+    for _ in range(k):
+        es = co.EstepResult(*cpd_c.expectation_step(co.transform("rigid", params, src), tgt, sigma2, 0.0))
+        params, sigma2, q = co.mstep_rigid(src, tgt, es)
+    assert rel_err(res.transformation.rot, params["rot"]) < TOL_TF
+    assert np.max(np.abs(res.transformation.t - params["t"])) < TOL_TF
+    assert abs(res.transformation.scale - params["scale"]) < TOL_TF * params["scale"]
+    assert abs(res.sigma2 - sigma2) <= TOL_SIGMA2 * sigma2
+
+
+def test_forced_matrix_core_engine_through_a_whole_dense_phase_2d():
+    """2-D clouds (z = 0 plane) and an affine M-step on the matrix-core sweeps, forced for 8 iterations."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import _lib, cpd
+
+    rng = np.random.default_rng(3)
+    th = np.linspace(0.0, 2.0 * np.pi, 3000, endpoint=False)
+    src = np.stack([np.cos(th) * (1.0 + 0.3 * np.cos(3 * th)), 0.6 * np.sin(th)], axis=1) + rng.normal(0, 0.01, (3000, 2))
+    a = np.array([[1.05, 0.1], [-0.08, 0.93]])
+    tgt = src[rng.permutation(3000)[:2500]] @ a.T + np.array([0.05, -0.03]) + rng.normal(0, 0.01, (2500, 2))
+    src = src.astype(np.float32).astype(np.float64)
+    tgt = tgt.astype(np.float32).astype(np.float64)
+    reg = cpd.AffineCPD(src)
+    reg._initialize(tgt)
+    plan = reg._plan
+    plan.set_dense_engine(2)
+    used = 0
+    for _ in range(8):
+        plan.estep(0.05)
+        used += plan.last_estep_engine()
+        plan.mstep(_lib.PRG_TF_AFFINE, True)
+    assert used == 7
+    res = reg._result_from_params(plan.get_params())
+    p, s2, q, _ = co.registration("affine", src, tgt, w=0.05, maxiter=8, tol=-1.0, closed_form_init=True)
+    assert rel_err(res.transformation.b, p["b"]) < TOL_TF
+    assert np.max(np.abs(res.transformation.t - p["t"])) < TOL_TF
+    assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
