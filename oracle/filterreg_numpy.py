@@ -186,21 +186,23 @@ def squared_kernel_sum_f32(x, y):
 
 def registration(source, target, sigma2=None, update_sigma2=False, w=0.0, maxiter=50, tol=0.001, min_sigma2=1.0e-4,
                  rot0=None, t0=None, prefer_ref=False, history=None, info=None, target_normals=None,
-                 objective_type="pt2pt"):
-    """filterreg.py:120-147 with identity feature_fn.  Returns (rot, t, sigma2_returned, q, n_iter)."""
+                 objective_type="pt2pt", feature_fn=None):
+    """filterreg.py:120-147 (``feature_fn`` None = the identity).  Returns (rot, t, sigma2_returned, q, n_iter)."""
     source = np.asarray(source, dtype=np.float64)
     target = np.asarray(target, dtype=np.float64)
     dim = source.shape[1]
     rot = np.identity(dim) if rot0 is None else np.asarray(rot0, dtype=np.float64)
     t = np.zeros(dim) if t0 is None else np.asarray(t0, dtype=np.float64)
     q = None
+    feat = (lambda x: x) if feature_fn is None else feature_fn
+    ftarget = feat(target)  # filterreg.py:125
     if sigma2 is None:
-        sigma2 = max(squared_kernel_sum_f32(source, target), min_sigma2)
+        sigma2 = max(squared_kernel_sum_f32(feat(source), ftarget), min_sigma2)
     res = None
     n_iter = 0
     for _ in range(maxiter):
         ts = np.dot(source, rot.T) + t  # RigidTransformation._transform with scale 1 (transformation.py:49-50)
-        es = expectation_step(ts, target, target, sigma2, update_sigma2, prefer_ref=prefer_ref, info=info,
+        es = expectation_step(feat(ts), ftarget, target, sigma2, update_sigma2, prefer_ref=prefer_ref, info=info,
                               target_normals=target_normals if objective_type == "pt2pl" else None)
         res = maximization_step(ts, target, es, rot, t, sigma2, w=w, objective_type=objective_type)
         if res.q is None:

@@ -23,7 +23,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXD 8
+#define MAXD 64 /* feature lattices: FPFH is d = 33 (probreg/features.py:28-51) */
 
 typedef struct {
     int n, d, m, with_blur;

@@ -74,6 +74,14 @@ struct Lattice {
     int64_t n_alloc = 0, nb_alloc = 0;
     float* io = nullptr;                // staging for values / outputs
     size_t io_bytes = 0;
+    // feature lattices (d > 3): keys are d shorts, the table holds a 64-bit hash of them (checked by a second hash)
+    short* rem0s = nullptr;             // [n][d+1] rounded remainders of every point (keys are rebuilt from these)
+    unsigned char* rank8 = nullptr;     // [n][d+1]
+    short* kfull = nullptr;             // [size][d] full key of every lattice vertex
+    unsigned long long* gcheck = nullptr;  // [size] second hash of the vertex key | 1 (0 = not yet written)
+    float* scale_dev = nullptr;         // [kMaxDG] scale factors of the embedding
+    int64_t g_alloc_n = 0, g_alloc_size = 0;
+    int g_alloc_d = 0;
 };
 
 // ---- embedding (permutohedral.cpp:186-276, SSE build) -------------------------------------------------
@@ -165,6 +173,160 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
         pslot[i * D1 + r] = (int)slot;
         bary[i * D1 + r] = bar[r];
     }
+}
+
+// ---- feature-space lattices, d > 3 (filterreg.py:121, 125-133 with feature_fn = FPFH: d = 33) ---------------------
+// The same embedding with run-time d (arrays of d + 1 floats per thread, in scratch).  A key is d shorts and does not fit
+// a machine word, so the table stores a 64-bit hash of it; a SECOND, independent 64-bit hash is recorded per vertex and
+// checked by every point that lands on the vertex and by every neighbour look-up: two different keys that share a table
+// hash are detected (the host then rebuilds with other seeds) instead of silently merged.
+constexpr int kMaxDG = 64;
+__device__ __forceinline__ unsigned long long hash_shorts(const short* key, int d, unsigned long long seed) {
+    unsigned long long h = seed;
+    for (int i = 0; i < d; ++i) {
+        h ^= (unsigned long long)(unsigned short)key[i];
+        h *= 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    h = mix64(h);
+    return h == kEmpty ? h - 1 : h;
+}
+__device__ __forceinline__ short canonical_key(float rem0, int rk, int r, int d) {
+    // canonical[r][rank] = r if rank <= d - r else r - (d + 1)   (permutohedral.cpp:166-171)
+    return (short)(rem0 + (float)(rk <= d - r ? r : r - (d + 1)));
+}
+
+__global__ __launch_bounds__(kBlock) void k_embed_g(const float* __restrict__ feat, int64_t n, int d,
+                                                    const float* __restrict__ scale,
+                                                    unsigned long long* __restrict__ tkeys, unsigned long long mask,
+                                                    unsigned long long seed, int* __restrict__ pslot,
+                                                    float* __restrict__ bary, short* __restrict__ rem0s,
+                                                    unsigned char* __restrict__ rank8, int* __restrict__ overflow) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int d1 = d + 1;
+    float elevated[kMaxDG + 1], rem0[kMaxDG + 1], rank[kMaxDG + 1], bar[kMaxDG + 2];
+    float sm = 0.f;
+    for (int j = d; j > 0; --j) {
+        const float cf = __fmul_rn(feat[i * d + j - 1], scale[j - 1]);
+        elevated[j] = __fsub_rn(sm, __fmul_rn((float)j, cf));
+        sm = __fadd_rn(sm, cf);
+    }
+    elevated[0] = sm;
+    const float invd1 = 1.0f / (float)d1, fd1 = (float)d1;
+    float sum = 0.f;
+    for (int k = 0; k < d1; ++k) {
+        float v = rintf(__fmul_rn(invd1, elevated[k]));  // round half to even, as in k_embed
+        rem0[k] = __fmul_rn(v, fd1);
+        sum = __fadd_rn(sum, v);
+        rank[k] = 0.f;
+    }
+    for (int a = 0; a < d; ++a) {
+        const float da = __fsub_rn(elevated[a], rem0[a]);
+        for (int b = a + 1; b < d1; ++b) {
+            const float db = __fsub_rn(elevated[b], rem0[b]);
+            if (da < db) rank[a] += 1.f; else rank[b] += 1.f;
+        }
+    }
+    for (int k = 0; k < d1; ++k) {
+        rank[k] += sum;
+        if (rank[k] < 0.f) { rank[k] += fd1; rem0[k] += fd1; }
+        else if (rank[k] >= fd1) { rank[k] -= fd1; rem0[k] -= fd1; }
+    }
+    for (int k = 0; k <= d1; ++k) bar[k] = 0.f;
+    for (int k = 0; k < d1; ++k) {
+        const float v = __fmul_rn(__fsub_rn(elevated[k], rem0[k]), invd1);
+        const int p = d - (int)rank[k];
+        bar[p] = __fadd_rn(bar[p], v);
+        bar[p + 1] = __fsub_rn(bar[p + 1], v);
+    }
+    bar[0] = __fadd_rn(bar[0], __fadd_rn(1.0f, bar[d1]));
+    for (int k = 0; k < d1; ++k) {
+        rem0s[i * d1 + k] = (short)rem0[k];
+        rank8[i * d1 + k] = (unsigned char)(int)rank[k];
+    }
+    for (int r = 0; r < d1; ++r) {
+        short key[kMaxDG];
+        for (int k = 0; k < d; ++k) key[k] = canonical_key(rem0[k], (int)rank[k], r, d);
+        const unsigned long long pk = hash_shorts(key, d, seed);
+        unsigned long long slot = mix64(pk) & mask;
+        for (int probes = 0;; ++probes) {
+            if (probes > 4096) {
+                *overflow = 1;
+                slot = 0;
+                break;
+            }
+            unsigned long long cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == kEmpty) cur = atomicCAS(&tkeys[slot], kEmpty, pk);
+            if (cur == kEmpty || cur == pk) break;
+            slot = (slot + 1) & mask;
+        }
+        pslot[i * d1 + r] = (int)slot;
+        bary[i * d1 + r] = bar[r];
+    }
+}
+
+// After compaction / resolve: every (point, remainder) writes its key into its vertex' row of kfull (all writers of a
+// vertex write the same d shorts) and checks the vertex' second hash.  flag[0] = 1 on a table-hash collision.
+__global__ __launch_bounds__(kBlock) void k_store_keys_g(const int* __restrict__ offset, int64_t n, int d,
+                                                         const short* __restrict__ rem0s,
+                                                         const unsigned char* __restrict__ rank8,
+                                                         unsigned long long seed2, short* __restrict__ kfull,
+                                                         unsigned long long* __restrict__ gcheck, int* __restrict__ flag) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int d1 = d + 1;
+    if (t >= n * d1) return;
+    const int64_t i = t / d1;
+    const int r = (int)(t % d1);
+    const int id = offset[t];
+    short key[kMaxDG];
+    for (int k = 0; k < d; ++k) key[k] = canonical_key((float)rem0s[i * d1 + k], (int)rank8[i * d1 + k], r, d);
+    const unsigned long long g = hash_shorts(key, d, seed2) | 1ull;
+    const unsigned long long old = atomicCAS(&gcheck[id], 0ull, g);
+    if (old == 0ull) {
+        for (int k = 0; k < d; ++k) kfull[(int64_t)id * d + k] = key[k];
+    } else if (old != g) {
+        *flag = 1;
+    }
+}
+
+__device__ __forceinline__ int lookup_g(const unsigned long long* __restrict__ tkeys, unsigned long long mask,
+                                        const int* __restrict__ slot_id, const unsigned long long* __restrict__ gcheck,
+                                        const short* key, int d, unsigned long long seed, unsigned long long seed2,
+                                        int* __restrict__ flag) {
+    const unsigned long long pk = hash_shorts(key, d, seed);
+    unsigned long long slot = mix64(pk) & mask;
+    for (;;) {
+        const unsigned long long k = tkeys[slot];
+        if (k == pk) {
+            const int id = slot_id[slot];
+            if (gcheck[id] != (hash_shorts(key, d, seed2) | 1ull)) *flag = 1;  // same table hash, different key
+            return id;
+        }
+        if (k == kEmpty) return -1;
+        slot = (slot + 1) & mask;
+    }
+}
+
+// blur neighbours (permutohedral.cpp:300-324) from the full keys
+__global__ __launch_bounds__(kBlock) void k_neighbours_g(const short* __restrict__ kfull, int size, int d,
+                                                         const unsigned long long* __restrict__ tkeys,
+                                                         unsigned long long mask, const int* __restrict__ slot_id,
+                                                         const unsigned long long* __restrict__ gcheck,
+                                                         unsigned long long seed, unsigned long long seed2,
+                                                         int* __restrict__ nb1, int* __restrict__ nb2,
+                                                         int* __restrict__ flag) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (int64_t)size * (d + 1)) return;
+    const int j = (int)(t / size), v = (int)(t % size);
+    short n1[kMaxDG], n2[kMaxDG];
+    for (int k = 0; k < d; ++k) {
+        const short key = kfull[(int64_t)v * d + k];
+        n1[k] = (short)(k == j ? key + d : key - 1);
+        n2[k] = (short)(k == j ? key - d : key + 1);
+    }
+    nb1[(int64_t)j * size + v] = lookup_g(tkeys, mask, slot_id, gcheck, n1, d, seed, seed2, flag);
+    nb2[(int64_t)j * size + v] = lookup_g(tkeys, mask, slot_id, gcheck, n2, d, seed, seed2, flag);
 }
 
 // Dense vertex ids for the occupied slots.  One atomic per workgroup (wave ballot + LDS prefix): a lattice of a few
@@ -377,7 +539,11 @@ __global__ __launch_bounds__(kBlock) void k_slice(const int* __restrict__ offset
 }
 
 int lat_free(Lattice* L) {
-    void* ptrs[] = {L->feat, L->tkeys, L->slot_id, L->pslot, L->bary, L->dkeys, L->nb, L->count, L->vals, L->io};
+    void* ptrs[] = {L->feat, L->tkeys, L->slot_id, L->pslot, L->bary, L->dkeys, L->nb, L->count, L->vals, L->io,
+                    L->rem0s, L->rank8, L->kfull, L->gcheck, L->scale_dev};
+    L->rem0s = nullptr; L->rank8 = nullptr; L->kfull = nullptr; L->gcheck = nullptr; L->scale_dev = nullptr;
+    L->g_alloc_n = L->g_alloc_size = 0;
+    L->g_alloc_d = 0;
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     L->feat = nullptr; L->tkeys = nullptr; L->slot_id = nullptr; L->pslot = nullptr; L->bary = nullptr;
@@ -406,8 +572,12 @@ int lat_ensure_io(Lattice* L, size_t bytes) {
 // then embedded in two stages (1/16 of them first): the vertices of a subset are a subset of the vertices, so as
 // soon as the count exceeds the threshold the answer is known and the build stops (L->built = false, L->size = a
 // lower bound > decide_above) - no compaction, no neighbour tables, 15/16 of the hashing saved.
+int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur);
+
 int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above = -1) {
-    PRG_REQUIRE(d >= 1 && d <= kMaxD, PRG_ERR_INVALID, "permutohedral lattice: feature dimension %d not in [1, 3]", d);
+    PRG_REQUIRE(d >= 1 && d <= kMaxDG, PRG_ERR_INVALID, "permutohedral lattice: feature dimension %d not in [1, %d]", d,
+                kMaxDG);
+    if (d > kMaxD) return lat_build_generic(L, n, d, with_blur);
     const int d1 = d + 1;
     hipStream_t st = L->stream;
     if (n > L->n_alloc || d != L->d) {
@@ -513,6 +683,102 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         PRG_HIP(hipGetLastError());
     }
     return PRG_OK;
+}
+
+// Feature lattices (3 < d <= 64): the structure of lat_build with the hashed-key kernels above.  Synchronises.
+int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
+    const int d1 = d + 1;
+    hipStream_t st = L->stream;
+    if (n > L->n_alloc || d != L->d) {
+        for (void* p : {(void*)L->tkeys, (void*)L->slot_id, (void*)L->pslot, (void*)L->bary, (void*)L->dkeys})
+            if (p) (void)hipFree(p);
+        L->tkeys = nullptr; L->slot_id = nullptr; L->pslot = nullptr; L->bary = nullptr; L->dkeys = nullptr;
+        int64_t cap = 1;
+        while (cap < 2 * n * d1) cap <<= 1;
+        L->cap = cap;
+        PRG_HIP(hipMalloc((void**)&L->tkeys, cap * sizeof(unsigned long long)));
+        PRG_HIP(hipMalloc((void**)&L->slot_id, cap * sizeof(int)));
+        PRG_HIP(hipMalloc((void**)&L->pslot, n * d1 * sizeof(int)));
+        PRG_HIP(hipMalloc((void**)&L->bary, n * d1 * sizeof(float)));
+        PRG_HIP(hipMalloc((void**)&L->dkeys, n * d1 * sizeof(unsigned long long)));
+        if (!L->count) PRG_HIP(hipMalloc((void**)&L->count, 2 * sizeof(int)));
+        L->n_alloc = n;
+        L->prev_size[0] = L->prev_size[1] = 0;
+    }
+    if (n > L->g_alloc_n || d != L->g_alloc_d) {
+        if (L->rem0s) (void)hipFree(L->rem0s);
+        if (L->rank8) (void)hipFree(L->rank8);
+        L->rem0s = nullptr; L->rank8 = nullptr;
+        PRG_HIP(hipMalloc((void**)&L->rem0s, n * d1 * sizeof(short)));
+        PRG_HIP(hipMalloc((void**)&L->rank8, n * d1));
+        L->g_alloc_n = n;
+        L->g_alloc_d = d;
+    }
+    if (!L->scale_dev) PRG_HIP(hipMalloc((void**)&L->scale_dev, kMaxDG * sizeof(float)));
+    if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
+    L->n = n;
+    L->d = d;
+    L->with_blur = with_blur;
+    // scale_factor[i] = float(1/sqrt((i+2)(i+1)) * inv_std_dev), inv_std_dev a float (permutohedral.cpp:180-183)
+    const float inv_std = with_blur ? (float)(sqrt(2.0 / 3.0) * d1) : (float)(sqrt(1.0 / 6.0) * d1);
+    float sc[kMaxDG];
+    for (int i = 0; i < kMaxDG; ++i) sc[i] = i < d ? (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std) : 0.f;
+    PRG_HIP(hipMemcpyAsync(L->scale_dev, sc, sizeof(sc), hipMemcpyHostToDevice, st));
+    PRG_HIP(hipStreamSynchronize(st));  // (sc lives on this stack frame)
+    volatile int* host = reinterpret_cast<volatile int*>(L->pinned);
+    L->built = false;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        const unsigned long long seed = 0x9e3779b97f4a7c15ull * (2 * attempt + 1), seed2 = 0xc2b2ae3d27d4eb4full * (2 * attempt + 3);
+        const int64_t capu = L->cap;
+        L->cap_used = capu;
+        const unsigned long long mask = (unsigned long long)capu - 1;
+        PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, capu * sizeof(unsigned long long), st));
+        PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
+        k_embed_g<<<(unsigned)prg::ceil_div(n, kBlock), kBlock, 0, st>>>(L->feat, n, d, L->scale_dev, L->tkeys, mask, seed,
+                                                                         L->pslot, L->bary, L->rem0s, L->rank8, L->count + 1);
+        k_compact<<<(unsigned)prg::ceil_div(capu, kBlock), kBlock, 0, st>>>(L->tkeys, capu, L->slot_id, L->dkeys, L->count);
+        PRG_HIP(hipGetLastError());
+        PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        PRG_HIP(hipStreamSynchronize(st));
+        PRG_REQUIRE(host[1] == 0, PRG_ERR_STATE, "permutohedral lattice: hash table overflow at full capacity");
+        L->size = host[0];
+        if ((int64_t)L->size > L->g_alloc_size) {
+            if (L->kfull) (void)hipFree(L->kfull);
+            if (L->gcheck) (void)hipFree(L->gcheck);
+            L->kfull = nullptr; L->gcheck = nullptr;
+            const int64_t want = (int64_t)L->size + L->size / 4 + 1024;
+            PRG_HIP(hipMalloc((void**)&L->kfull, want * d * sizeof(short)));
+            PRG_HIP(hipMalloc((void**)&L->gcheck, want * sizeof(unsigned long long)));
+            L->g_alloc_size = want;
+        }
+        k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id);
+        PRG_HIP(hipMemsetAsync(L->gcheck, 0, (size_t)L->size * sizeof(unsigned long long), st));
+        PRG_HIP(hipMemsetAsync(L->count + 1, 0, sizeof(int), st));  // now the collision flag
+        k_store_keys_g<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n, d, L->rem0s, L->rank8, seed2,
+                                                                                  L->kfull, L->gcheck, L->count + 1);
+        if (with_blur) {
+            const int64_t need = 2 * (int64_t)d1 * L->size;
+            if (need > L->nb_alloc) {
+                if (L->nb) (void)hipFree(L->nb);
+                L->nb = nullptr;
+                PRG_HIP(hipMalloc((void**)&L->nb, need * sizeof(int)));
+                L->nb_alloc = need;
+            }
+            k_neighbours_g<<<(unsigned)prg::ceil_div((int64_t)L->size * d1, kBlock), kBlock, 0, st>>>(
+                L->kfull, L->size, d, L->tkeys, mask, L->slot_id, L->gcheck, seed, seed2, L->nb,
+                L->nb + (int64_t)d1 * L->size, L->count + 1);
+        }
+        PRG_HIP(hipGetLastError());
+        PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        PRG_HIP(hipStreamSynchronize(st));
+        if (host[1] == 0) {
+            L->built = true;
+            return PRG_OK;
+        }
+        // two different keys shared a 64-bit table hash (probability ~1e-7 per build): other seeds, again
+    }
+    prg::set_error("permutohedral lattice: key hash collisions persisted over 4 seeds");
+    return PRG_ERR_STATE;
 }
 
 // Filter `ch` channels: in [n][ch] (device) -> out [n_out][ch] (device); only points >= first are splatted
@@ -1089,8 +1355,8 @@ int prg_ph_destroy(prg_ph* h) {
 
 int prg_ph_init(prg_ph* h, const float* points_hd, int64_t n, int dim, int with_blur) {
     PRG_REQUIRE(h && points_hd, PRG_ERR_INVALID, "prg_ph_init: NULL argument");
-    PRG_REQUIRE(n > 0 && dim >= 1 && dim <= kMaxD, PRG_ERR_INVALID,
-                "prg_ph_init: need n > 0 and feature dimension in [1, 3] (got n=%lld d=%d)", (long long)n, dim);
+    PRG_REQUIRE(n > 0 && dim >= 1 && dim <= kMaxDG, PRG_ERR_INVALID,
+                "prg_ph_init: need n > 0 and feature dimension in [1, %d] (got n=%lld d=%d)", kMaxDG, (long long)n, dim);
     prg::DeviceGuard g(h->L.device);
     Lattice* L = &h->L;
     if (L->feat) (void)hipFree(L->feat);

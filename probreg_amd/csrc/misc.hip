@@ -3,6 +3,8 @@
 //   prg_rbf_kernel             (probreg/math_utils.py:36-37 -> cc/math_utils.cc:17-19)
 //   prg_gauss_transform_direct (probreg/gauss_transform.py:10-25, 46-60)
 #include <math.h>
+
+#include <algorithm>
 #include <stdarg.h>
 
 #include "prg_common.h"
@@ -46,6 +48,31 @@ __global__ __launch_bounds__(kBlock) void k_sums_rowmajor(const float* __restric
     if (threadIdx.x < 4)
         part[(int64_t)blockIdx.x * 4 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] +
                                                      sh[3][threadIdx.x];
+}
+
+// any dimension (feature clouds, d <= 64): out[0..dim) += column sums, out[dim] += sum of squared norms (fp64 atomics)
+__global__ __launch_bounds__(kBlock) void k_sums_generic(const float* __restrict__ p, int64_t n, int dim,
+                                                         double* __restrict__ out) {
+    double sq = 0.0;
+    for (int k = 0; k < dim; ++k) {
+        double a = 0.0;
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+            const double v = p[i * dim + k];
+            a += v;
+            sq += v * v;
+        }
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0 && a != 0.0) atomicAdd(&out[k], a);
+    }
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[dim], sq);
+}
+__global__ void k_sks_final_generic(const double* __restrict__ sx, const double* __restrict__ sy, double m, double n,
+                                    int dim, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double cross = 0.0;
+    for (int k = 0; k < dim; ++k) cross += sx[k] * sy[k];
+    out[0] = (n * sx[dim] + m * sy[dim] - 2.0 * cross) / (m * dim * n);
 }
 
 __global__ void k_sks_final(const double* __restrict__ px, int nbx, const double* __restrict__ py, int nby, double m,
@@ -217,11 +244,29 @@ int prg_device_count(int* count) {
 int prg_squared_kernel_sum(int device, void* hip_stream, const float* x_hd, int64_t m, const float* y_hd, int64_t n,
                            int dim, double* out_host) {
     PRG_REQUIRE(x_hd && y_hd && out_host, PRG_ERR_INVALID, "prg_squared_kernel_sum: NULL argument");
-    PRG_REQUIRE(m > 0 && n > 0 && (dim == 2 || dim == 3), PRG_ERR_INVALID,
-                "prg_squared_kernel_sum: need m, n > 0 and dim in {2,3}");
+    PRG_REQUIRE(m > 0 && n > 0 && dim >= 1 && dim <= 64, PRG_ERR_INVALID,
+                "prg_squared_kernel_sum: need m, n > 0 and dim in [1, 64]");
     prg::DeviceGuard g(device);
     PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_squared_kernel_sum: hipSetDevice(%d) failed", device);
     hipStream_t st = (hipStream_t)hip_stream;
+    if (dim != 2 && dim != 3) {  // feature clouds (FilterReg with a feature_fn, filterreg.py:126-128)
+        TmpBuf fx, fy, fs;
+        PRG_HIP(hipMalloc(&fx.p, (size_t)m * dim * sizeof(float)));
+        PRG_HIP(hipMalloc(&fy.p, (size_t)n * dim * sizeof(float)));
+        PRG_HIP(hipMalloc(&fs.p, (size_t)(2 * (dim + 1) + 1) * sizeof(double)));
+        PRG_HIP(hipMemcpyAsync(fx.p, x_hd, (size_t)m * dim * sizeof(float), hipMemcpyDefault, st));
+        PRG_HIP(hipMemcpyAsync(fy.p, y_hd, (size_t)n * dim * sizeof(float), hipMemcpyDefault, st));
+        PRG_HIP(hipMemsetAsync(fs.p, 0, (size_t)(2 * (dim + 1) + 1) * sizeof(double), st));
+        double* sx = (double*)fs.p;
+        double* sy = sx + dim + 1;
+        k_sums_generic<<<(unsigned)std::min<int64_t>(prg::ceil_div(m, kBlock), 512), kBlock, 0, st>>>((const float*)fx.p, m, dim, sx);
+        k_sums_generic<<<(unsigned)std::min<int64_t>(prg::ceil_div(n, kBlock), 512), kBlock, 0, st>>>((const float*)fy.p, n, dim, sy);
+        k_sks_final_generic<<<1, 64, 0, st>>>(sx, sy, (double)m, (double)n, dim, sy + dim + 1);
+        PRG_HIP(hipGetLastError());
+        PRG_HIP(hipMemcpyAsync(out_host, sy + dim + 1, sizeof(double), hipMemcpyDeviceToHost, st));
+        PRG_HIP(hipStreamSynchronize(st));
+        return PRG_OK;
+    }
     const int nbx = (int)(prg::ceil_div(m, kBlock) < 256 ? prg::ceil_div(m, kBlock) : 256);
     const int nby = (int)(prg::ceil_div(n, kBlock) < 256 ? prg::ceil_div(n, kBlock) : 256);
     TmpBuf bx, by, bp;

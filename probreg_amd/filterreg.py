@@ -6,8 +6,10 @@ The E-step (lattice build over [t_source; target]/sigma, the three Gaussian filt
 ``FilterReg.registration`` (filterreg.py:120-147) line by line, including its quirks: with the defaults
 sigma2 is never updated, the returned ``sigma2`` is the un-clamped one, and the driver stops with the
 previous ``q`` when every ``m0`` is zero.
-Point-to-plane (``objective_type='pt2pl'``, filterreg.py:183-186 + cc/point_to_plane.cc) is built as well.
-Out of scope here: ``feature_fn`` other than identity, ``DeformableKinematicFilterReg``.
+Point-to-plane (``objective_type='pt2pl'``, filterreg.py:183-186 + cc/point_to_plane.cc) is built as well, and so are
+feature-space lattices: a ``feature_fn`` other than the identity (filterreg.py:121, 125-133; e.g. 33-dimensional FPFH
+descriptors) runs the reference's loop - transform, ``feature_fn`` on the host, lattice E-step over the features
+(1 <= d <= 64) and M-step on the GPU.  Out of scope: ``DeformableKinematicFilterReg``.
 """
 import abc
 import ctypes
@@ -148,24 +150,52 @@ class FilterReg(abc.ABC):
         return self._plan
 
     def expectation_step(self, t_source, target, y, sigma2, update_sigma2, objective_type="pt2pt", alpha=0.015):
-        """Expectation step (reference filterreg.py:78-108) on explicit arrays; returns float32 m0, m1, m2."""
+        """Expectation step (reference filterreg.py:78-108) on explicit arrays; returns float32 m0, m1, m2 (, nx).
+
+        ``t_source`` / ``target`` are the FEATURES the lattice is built over (the transformed source and the target
+        themselves for the identity ``feature_fn``, anything up to 64-dimensional otherwise) and ``y`` the target
+        positions whose moments are filtered.
+        """
+        t_source, target, y = np.asarray(t_source), np.asarray(target), np.asarray(y)
         assert t_source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
         if objective_type not in ("pt2pt", "pt2pl"):
             raise ValueError("Unknown objective_type: %s." % objective_type)
-        if y is not target and not np.array_equal(np.asarray(y), np.asarray(target)):
-            raise NotImplementedError("feature-space lattices (y != target) are a next-row (SURVEY.md 8f).")
-        plan = _Plan()
-        try:
-            plan.set_source(t_source)
-            plan.set_target(target)
-            if objective_type == "pt2pl":
-                plan.set_normals(self._target_normals)
-            plan.set_state(np.identity(t_source.shape[1]), np.zeros(t_source.shape[1]), sigma2)
-            plan.estep(alpha)
-            m0, m1, m2 = plan.get_estep(update_sigma2)
-            nx = plan.get_nx() if objective_type == "pt2pl" else None
-        finally:
-            plan.close()
+        if t_source.shape[1] <= 3 and y.shape == target.shape and np.array_equal(y, target):
+            # positions as features: the fused plan (one lattice pass for all channels)
+            plan = _Plan()
+            try:
+                plan.set_source(t_source)
+                plan.set_target(target)
+                if objective_type == "pt2pl":
+                    plan.set_normals(self._target_normals)
+                plan.set_state(np.identity(t_source.shape[1]), np.zeros(t_source.shape[1]), sigma2)
+                plan.estep(alpha)
+                m0, m1, m2 = plan.get_estep(update_sigma2)
+                nx = plan.get_nx() if objective_type == "pt2pl" else None
+            finally:
+                plan.close()
+            return EstepResult(m0, m1, m2, nx)
+        return self._expectation_step_features(t_source, target, y, sigma2, update_sigma2, objective_type, alpha)
+
+    def _expectation_step_features(self, fsource, ftarget, y, sigma2, update_sigma2, objective_type, alpha):
+        """filterreg.py:78-108 line by line on ``gaussian_filtering.Permutohedral`` (GPU lattice of any d <= 64)."""
+        from . import gaussian_filtering as gf
+
+        m, n = fsource.shape[0], ftarget.shape[0]
+        sigma = np.sqrt(sigma2)
+        fin = np.r_[fsource / sigma, ftarget / sigma]
+        ph = gf.Permutohedral(fin)
+        if ph.get_lattice_size() > n * alpha:  # :90-91
+            ph = gf.Permutohedral(fin, False)
+        zeros_m1 = np.zeros((m, 1))
+        m0 = ph.filter(np.r_[zeros_m1, np.ones((n, 1))], m).flatten()[:m]
+        m1 = ph.filter(np.r_[np.zeros((m, y.shape[1])), y], m)[:m]
+        m2 = ph.filter(np.r_[zeros_m1, np.square(y).sum(axis=1)[:, None]], m).flatten()[:m] if update_sigma2 else None
+        nx = None
+        if objective_type == "pt2pl":
+            if self._target_normals is None:
+                raise ValueError("objective_type 'pt2pl' needs target_normals.")
+            nx = ph.filter(np.r_[np.zeros((m, y.shape[1])), np.asarray(self._target_normals)], m)[:m]
         return EstepResult(m0, m1, m2, nx)
 
     def maximization_step(self, t_source, target, estep_res, w=0.0, objective_type="pt2pt"):
@@ -186,11 +216,11 @@ class FilterReg(abc.ABC):
             raise ValueError("Unknown objective_type: %s." % objective_type)
         if objective_type == "pt2pl" and self._target_normals is None:
             raise ValueError("objective_type 'pt2pl' needs target_normals.")
+        target = _as_points(target)
         if feature_fn is not _identity:
             probe = np.asarray(feature_fn(self._source[:2]))
             if probe.shape != self._source[:2].shape or not np.array_equal(probe, self._source[:2]):
-                raise NotImplementedError("feature_fn other than identity is a next-row (SURVEY.md 8f).")
-        target = _as_points(target)
+                return self._registration_features(target, w, objective_type, maxiter, tol, min_sigma2, feature_fn)
         if self._source.shape[1] != target.shape[1] or target.shape[1] not in (2, 3):
             raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
         q = None
@@ -218,6 +248,34 @@ class FilterReg(abc.ABC):
             rot = out[:9].reshape(3, 3)[:dim, :dim].copy()
             t = out[9:9 + dim].copy()
             res = MstepResult(tf.RigidTransformation(rot, t), float(out[15]), float(out[13]))
+            self._tf_result = res.transformation
+            self._sigma2 = max(res.sigma2, min_sigma2)
+            for c in self._callbacks:
+                c(self._tf_result)
+            log.debug("Iteration: {}, Criteria: {}".format(i, res.q))
+            if q is not None and abs(res.q - q) < tol:
+                break
+            q = res.q
+        return res
+
+
+    def _registration_features(self, target, w, objective_type, maxiter, tol, min_sigma2, feature_fn):
+        """The reference's driver verbatim in structure (filterreg.py:120-147) for a non-identity ``feature_fn``:
+        features are evaluated on the host every iteration, the lattice E-step and the M-step run on the GPU."""
+        q = None
+        ftarget = np.asarray(feature_fn(target), dtype=np.float64)
+        if self._sigma2 is None:
+            fsource = np.asarray(feature_fn(self._source), dtype=np.float64)
+            self._sigma2 = max(mu.squared_kernel_sum(fsource, ftarget), min_sigma2)
+        res = MstepResult(self._tf_result, self._sigma2, None)
+        for i in range(maxiter):
+            t_source = self._tf_result.transform(self._source)
+            fsource = np.asarray(feature_fn(t_source), dtype=np.float64)
+            estep_res = self.expectation_step(fsource, ftarget, target, self._sigma2, self._update_sigma2, objective_type)
+            res = self.maximization_step(t_source, target, estep_res, w=w, objective_type=objective_type)
+            if res.q is None:
+                res = res._replace(q=q)
+                break
             self._tf_result = res.transformation
             self._sigma2 = max(res.sigma2, min_sigma2)
             for c in self._callbacks:
@@ -286,7 +344,8 @@ def registration_filterreg(source, target, target_normals=None, sigma2=None, upd
     sigma2          : kernel variance (None = automatic); update_sigma2 re-estimates it every iteration
     w               : outlier mass in [0, 1); objective_type 'pt2pt' (Kabsch) or 'pt2pl' (twist)
     maxiter, tol    : stop after maxiter iterations or when |q - q_prev| < tol; min_sigma2 clamps the variance
-    feature_fn      : only the identity is supported; callbacks get the transformation after every iteration
+    feature_fn      : maps (n, D) points to (n, d <= 64) features the lattice is built over (identity by default; a
+                      host callable, evaluated once per iteration); callbacks get the transformation after every iteration
     **kwargs        : ``tf_init_params`` for the starting rigid transform
     Returns ``MstepResult(transformation, sigma2, q)``.
     """

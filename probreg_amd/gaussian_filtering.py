@@ -11,7 +11,8 @@ from .engine import _current_device_and_stream
 class Permutohedral(object):
     """``Permutohedral(p, with_blur)`` / ``get_lattice_size()`` / ``filter(v, start)`` as in the reference.
 
-    ``p`` is (n, d) with d <= 3 (feature lattices of higher dimension - FPFH - are a next-row).
+    ``p`` is (n, d), 1 <= d <= 64: d <= 3 (positions) takes the packed-key kernels, larger d (feature lattices such as
+    the reference's 33-dimensional FPFH, features.py:28-51) the hashed-key ones.
     """
 
     def __init__(self, p, with_blur=True):

@@ -50,3 +50,26 @@ def rel_err(a, b):
 def mstep_golden():
     """Single M-step calls of the reference on explicit E-step arrays (tests/golden/make_golden.py mstep)."""
     return Golden(os.path.join(GOLDEN_DIR, "mstep_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def fr_golden():
+    return Golden(os.path.join(GOLDEN_DIR, "filterreg_golden.npz"))
+
+
+@pytest.fixture(scope="session")
+def feature_golden():
+    """Feature-space lattices (d = 5, 33) and FilterReg runs with a non-identity feature_fn, from the reference
+    (tests/golden/make_golden.py features)."""
+    return Golden(os.path.join(GOLDEN_DIR, "feature_lattice_golden.npz"))
+
+
+def golden_feature_map(case):
+    """The deterministic position -> feature map stored with a feature-FilterReg fixture (make_golden.feature_map)."""
+    a, ph = case["feat_a"], case["feat_phase"]
+
+    def fn(x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.concatenate([x, 0.3 * np.sin(x @ a + ph)], axis=1)
+
+    return fn

@@ -418,7 +418,65 @@ def main_mstep():
     print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
 
 
+def feature_map(dim_out, seed):
+    """A deterministic position -> feature map standing in for FPFH (probreg/features.py needs Open3D): the positions
+    themselves followed by smooth random-projection features, ``dim_out`` columns in total."""
+    rng = np.random.default_rng(seed)
+    a = rng.normal(size=(3, dim_out - 3)) * 1.5
+    ph = rng.uniform(0.0, 2.0 * np.pi, dim_out - 3)
+
+    def fn(x):
+        x = np.asarray(x, dtype=np.float64)
+        return np.concatenate([x, 0.3 * np.sin(x @ a + ph)], axis=1)
+
+    return fn, a, ph
+
+
+def main_features():
+    """Feature-space lattices: the vendored permutohedral.cpp at d = 5 and d = 33, and the reference's
+    registration_filterreg driven by a non-identity feature_fn (filterreg.py:121, 125-133)."""
+    from oracle import permutohedral as ph
+
+    assert ph.ref_available(), "build oracle/_ref first: make -C oracle ref"
+    ref = ref_import.load(with_filterreg=True)
+    flat = {}
+    rng = np.random.default_rng(23)
+    for d, n in ((5, 2500), (33, 1500)):
+        for blur in (True, False):
+            pts = (rng.normal(size=(n, d)) * (0.9 if d == 33 else 1.6)).astype(np.float32)
+            lat = ph.Lattice(pts, blur, prefer_ref=True)
+            assert lat.is_ref
+            pre = "lattice/d%d_blur%d/" % (d, int(blur))
+            flat[pre + "points"] = pts
+            flat[pre + "size"] = np.asarray(lat.lattice_size)
+            for ch in (1, 3):
+                v = rng.normal(size=(n, ch)).astype(np.float32)
+                flat[pre + "values_ch%d" % ch] = v
+                flat[pre + "out_ch%d" % ch] = lat.filter(v)
+            print("feature lattice d=%d blur=%d size=%d" % (d, blur, lat.lattice_size))
+    for name, dim_out, seed, n, m, kw in (("feat8_update_k5", 8, 41, 2400, 2000, dict(sigma2=0.02, update_sigma2=True, w=0.05, maxiter=5, tol=-1.0)),
+                                          ("feat33_fixed_k4", 33, 43, 1600, 1400, dict(sigma2=0.05, maxiter=4, tol=-1.0)),
+                                          ("feat8_auto_sigma2_k3", 8, 45, 1200, 1000, dict(update_sigma2=True, maxiter=3, tol=-1.0))):
+        fn, a, phs = feature_map(dim_out, seed)
+        src, tgt, _ = synthetic.filterreg_pair(n, m=m, seed=seed)
+        res = ref.filterreg.registration_filterreg(src.copy(), tgt.copy(), feature_fn=fn, **kw)
+        pre = "reg/%s/" % name
+        flat[pre + "source"], flat[pre + "target"] = src, tgt
+        flat[pre + "feat_a"], flat[pre + "feat_phase"] = a, phs
+        flat[pre + "out_rot"], flat[pre + "out_t"] = np.asarray(res.transformation.rot), np.asarray(res.transformation.t)
+        flat[pre + "out_sigma2"], flat[pre + "out_q"] = np.asarray(float(res.sigma2)), np.asarray(float(res.q))
+        for k, v in kw.items():
+            flat[pre + "arg_" + k] = np.asarray(v)
+        print("feature filterreg %-22s sigma2=%.9e q=%.9e" % (name, res.sigma2, res.q))
+    out = os.path.join(HERE, "feature_lattice_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "features":
+        main_features()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "mstep":
         main_mstep()
         sys.exit(0)

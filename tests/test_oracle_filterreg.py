@@ -104,3 +104,36 @@ def test_pt2pl_registration_matches_reference(fr_golden):
         assert np.max(np.abs(rot - c["out_rot"])) < 1e-6 and np.max(np.abs(t - c["out_t"])) < 1e-6, name
         assert abs(s2 - c["out_sigma2"]) <= 1e-6 * abs(c["out_sigma2"]), name
         assert abs(q - c["out_q"]) <= 1e-6 * abs(c["out_q"]), name
+
+
+@pytest.mark.parametrize("d", [5, 33])
+@pytest.mark.parametrize("blur", [1, 0])
+def test_feature_lattice_restatement_is_bit_exact(feature_golden, d, blur):
+    """The plain-C lattice at feature dimensions (FPFH is d = 33, features.py:28-51) against the vendored
+    permutohedral.cpp's own outputs: same vertex count, bit-identical filter results."""
+    from oracle import permutohedral as ph
+
+    c = feature_golden.case("lattice/d%d_blur%d" % (d, blur))
+    lat = ph.Lattice(c["points"], bool(blur))
+    assert lat.lattice_size == int(c["size"])
+    for ch in (1, 3):
+        assert np.array_equal(lat.filter(c["values_ch%d" % ch]), c["out_ch%d" % ch])
+
+
+@pytest.mark.parametrize("name", ["feat8_update_k5", "feat33_fixed_k4", "feat8_auto_sigma2_k3"])
+def test_feature_registration_matches_reference(feature_golden, name):
+    """oracle.filterreg_numpy.registration with a non-identity feature_fn against the reference's
+    registration_filterreg(feature_fn=...) (filterreg.py:121, 125-133)."""
+    from conftest import golden_feature_map
+    from oracle import filterreg_numpy as fo
+
+    c = feature_golden.case("reg/" + name)
+    kw = {k[4:]: c[k] for k in c if k.startswith("arg_")}
+    if "maxiter" in kw:
+        kw["maxiter"] = int(kw["maxiter"])
+    if "update_sigma2" in kw:
+        kw["update_sigma2"] = bool(kw["update_sigma2"])
+    rot, t, s2, q, _ = fo.registration(c["source"], c["target"], feature_fn=golden_feature_map(c), **kw)
+    assert np.max(np.abs(rot - c["out_rot"])) < 2e-6 and np.max(np.abs(t - c["out_t"])) < 2e-6
+    assert abs(s2 - c["out_sigma2"]) <= 2e-6 * c["out_sigma2"]
+    assert abs(q - c["out_q"]) <= 1e-5 * abs(c["out_q"])
