@@ -346,21 +346,27 @@ def test_nonrigid_vs_reference(cpd_golden, name):
     niter = [0]
     res = cpd.registration_cpd(c["source"], c["target"], "nonrigid",
                                callbacks=[lambda t: niter.__setitem__(0, niter[0] + 1)], **_kwargs(c))
+    want_sigma2, want_ts, want_w = c["out_sigma2"], c["out_tsource"], c["out_w"]
     if "default" in name:
         assert abs(niter[0] - c["out_niter"]) <= 2
         if niter[0] != c["out_niter"]:
-            pytest.skip("stopped %d iteration(s) apart from the fp64 reference (absolute tol on q)" %
-                        abs(niter[0] - c["out_niter"]))
-    assert abs(res.sigma2 - c["out_sigma2"]) <= TOL_SIGMA2 * c["out_sigma2"]
+            # stopped an iteration or two apart from the fp64 reference (the default test is absolute, |dq| < 1e-3 on
+            # q = sigma2): compare the state at the iteration count the GPU reached, from the oracle
+            from oracle import cpd_numpy as co
+
+            p, s2, _, _ = co.registration("nonrigid", c["source"], c["target"], maxiter=niter[0], tol=-1.0)
+            g = co.rbf_kernel(c["source"], c["source"], 2.0)
+            want_sigma2, want_ts, want_w = s2, co.transform("nonrigid", p, c["source"], g), p["w"]
+    assert abs(res.sigma2 - want_sigma2) <= TOL_SIGMA2 * want_sigma2
     ts = res.transformation.transform(c["source"])
-    extent = np.max(np.abs(c["out_tsource"] - c["out_tsource"].mean(0)))
+    extent = np.max(np.abs(want_ts - want_ts.mean(0)))
     # bunny.pcd spans 0.08 units, so with beta = 2 every entry of G is within 2.5e-3 of 1.0: the float32
     # kernel carries ~15 significant bits of structure and the reference result itself moves by ~2e-4
     # relative under 1-ulp changes of G (numpy expf vs Eigen expf vs correctly rounded) - looser T there.
     tol_t = 3e-4 if name.startswith("bunny_nonrigid_k5") else TOL_TF
-    assert np.max(np.abs(ts - c["out_tsource"])) < tol_t * extent
-    wmax = np.max(np.abs(c["out_w"]))
-    assert np.max(np.abs(res.transformation.w - c["out_w"])) < 2e-2 * wmax
+    assert np.max(np.abs(ts - want_ts)) < tol_t * extent
+    wmax = np.max(np.abs(want_w))
+    assert np.max(np.abs(res.transformation.w - want_w)) < 2e-2 * wmax
 
 
 def test_nonrigid_g_matches_oracle(cpd_golden):
@@ -465,8 +471,13 @@ def test_constrained_nonrigid_vs_reference():
                                    idx_source=c["idx_source"], idx_target=c["idx_target"],
                                    callbacks=[lambda t: niter.__setitem__(0, niter[0] + 1)], **kw)
         assert abs(niter[0] - c["out_niter"]) <= 2, name
-        if niter[0] != c["out_niter"]:
-            continue
+        if niter[0] != c["out_niter"]:  # compare at the iteration count the GPU reached (oracle, fixed count)
+            from oracle import cpd_numpy as co
+
+            p, s2, _, _ = co.registration("nonrigid_constrained", c["source"], c["target"], maxiter=niter[0], tol=-1.0,
+                                          alpha=float(c["alpha"]), idx_source=c["idx_source"], idx_target=c["idx_target"])
+            c = dict(c, out_sigma2=s2, out_tsource=co.transform("nonrigid", p, c["source"],
+                                                              co.rbf_kernel(c["source"], c["source"], 2.0)))
         # With alpha = 1e-8 the prior rows of the system are weighted by sigma2/alpha ~ 1e7: a 1-ulp change of a
         # float32 G entry (6e-8) moves those rows by ~0.6 against c = lmd*sigma2 ~ 0.1, i.e. the reference's own
         # answer depends on how its expf rounds (numpy here, Eigen's vectorised expf in a real build).  Two steps of
