@@ -14,6 +14,8 @@
 // (float32 round-off only).  Everything here is HBM-latency / atomic bound integer and scatter work.
 #include <math.h>
 
+#include <algorithm>
+
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -47,6 +49,18 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     return x;
 }
 
+// Feature producer of the FilterReg plan (filterreg.py:84-85 fused into the embedding): point i < m is the transformed
+// source z = R y + t (kept as fp64 for the M-step), point i >= m a target point; both are divided by sigma in fp64
+// before the float32 cast, exactly the reference's `t_source / sigma`, `target / sigma` followed by pybind's cast.
+struct FrFeat {
+    const double* src;
+    const double* tgt;
+    const double* state;  // [0..8] rot, [9..11] t, [12] sigma2
+    double* ts;           // [m][3] transformed source (written by whoever embeds a source point)
+    int64_t m;
+    int dim;
+};
+
 struct Lattice {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -74,6 +88,14 @@ struct Lattice {
     int64_t n_alloc = 0, nb_alloc = 0;
     float* io = nullptr;                // staging for values / outputs
     size_t io_bytes = 0;
+    const FrFeat* prod = nullptr;       // non-null: features come from the FilterReg plan's clouds, not from `feat`
+    // side table of the speculative with_blur decision (fr_build): a 1/16 subset of the points, hashed with the
+    // blur scaling while the non-blur lattice is built in the main table; side[0] vertices, side[1] overflow
+    unsigned long long* tkeys2 = nullptr;
+    int64_t cap2 = 0;
+    int* count2 = nullptr;
+    bool side_pending = false;
+    int side_size = 0, side_overflow = 0;
     // feature lattices (d > 3): keys are d shorts, the table holds a 64-bit hash of them (checked by a second hash)
     short* rem0s = nullptr;             // [n][d+1] rounded remainders of every point (keys are rebuilt from these)
     unsigned char* rank8 = nullptr;     // [n][d+1]
@@ -85,18 +107,40 @@ struct Lattice {
 };
 
 // ---- embedding (permutohedral.cpp:186-276, SSE build) -------------------------------------------------
-template <int D>
-__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, int64_t first, int64_t n, float s0,
-                                                  float s1, float s2, unsigned long long* __restrict__ tkeys,
-                                                  unsigned long long mask, int* __restrict__ pslot,
-                                                  float* __restrict__ bary, int* __restrict__ overflow) {
+template <int D, bool FR>
+__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, const FrFeat fr, int64_t first,
+                                                  int64_t n, float s0, float s1, float s2,
+                                                  unsigned long long* __restrict__ tkeys, unsigned long long mask,
+                                                  int* __restrict__ pslot, float* __restrict__ bary,
+                                                  int* __restrict__ overflow) {
     const int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // points [first, n)
     if (i >= n) return;
     constexpr int D1 = D + 1;
     const float scale[3] = {s0, s1, s2};
     float f[D];
+    if (FR) {
+        const double sigma = sqrt(fr.state[12]);
+        if (i < fr.m) {
+            double y[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int k = 0; k < D; ++k) f[k] = feat[i * D + k];
+            for (int k = 0; k < D; ++k) y[k] = fr.src[i * D + k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += y[k] * fr.state[3 * r + k];  // dot(points, rot.T), transformation.py:49-50
+                const double z = r < D ? acc + fr.state[9 + r] : 0.0;
+                fr.ts[i * 3 + r] = z;
+                if (r < D) f[r < D ? r : 0] = (float)(z / sigma);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) f[k] = (float)(fr.tgt[(i - fr.m) * D + k] / sigma);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) f[k] = feat[i * D + k];
+    }
     float elevated[D1], rem0[D1], rank[D1], bar[D1 + 1];
     float sm = 0.f;
 #pragma unroll
@@ -540,7 +584,8 @@ __global__ __launch_bounds__(kBlock) void k_slice(const int* __restrict__ offset
 
 int lat_free(Lattice* L) {
     void* ptrs[] = {L->feat, L->tkeys, L->slot_id, L->pslot, L->bary, L->dkeys, L->nb, L->count, L->vals, L->io,
-                    L->rem0s, L->rank8, L->kfull, L->gcheck, L->scale_dev};
+                    L->rem0s, L->rank8, L->kfull, L->gcheck, L->scale_dev, L->tkeys2, L->count2};
+    L->tkeys2 = nullptr; L->count2 = nullptr; L->cap2 = 0;
     L->rem0s = nullptr; L->rank8 = nullptr; L->kfull = nullptr; L->gcheck = nullptr; L->scale_dev = nullptr;
     L->g_alloc_n = L->g_alloc_size = 0;
     L->g_alloc_d = 0;
@@ -574,6 +619,32 @@ int lat_ensure_io(Lattice* L, size_t bytes) {
 // lower bound > decide_above) - no compaction, no neighbour tables, 15/16 of the hashing saved.
 int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur);
 
+// scale_factor[i] = float(1/sqrt((i+2)(i+1)) * inv_std_dev), inv_std_dev a float (permutohedral.cpp:180-183)
+void lat_scale(int d, int with_blur, float (&sc)[3]) {
+    const int d1 = d + 1;
+    const float inv_std = with_blur ? (float)(sqrt(2.0 / 3.0) * d1) : (float)(sqrt(1.0 / 6.0) * d1);
+    for (int i = 0; i < 3; ++i) sc[i] = i < d ? (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std) : 0.f;
+}
+
+void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&sc)[3], unsigned long long* table,
+                  unsigned long long mask, int* overflow) {
+    const unsigned nb = (unsigned)prg::ceil_div(last - first, kBlock);
+    if (nb == 0) return;
+    hipStream_t st = L->stream;
+    const FrFeat none = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+#define PRG_EMBED(DD)                                                                                              \
+    if (L->prod)                                                                                                    \
+        k_embed<DD, true><<<nb, kBlock, 0, st>>>(nullptr, *L->prod, first, last, sc[0], sc[1], sc[2], table, mask,  \
+                                                 L->pslot, L->bary, overflow);                                      \
+    else                                                                                                            \
+        k_embed<DD, false><<<nb, kBlock, 0, st>>>(L->feat, none, first, last, sc[0], sc[1], sc[2], table, mask,     \
+                                                  L->pslot, L->bary, overflow)
+    if (d == 1) { PRG_EMBED(1); }
+    else if (d == 2) { PRG_EMBED(2); }
+    else { PRG_EMBED(3); }
+#undef PRG_EMBED
+}
+
 int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above = -1) {
     PRG_REQUIRE(d >= 1 && d <= kMaxDG, PRG_ERR_INVALID, "permutohedral lattice: feature dimension %d not in [1, %d]", d,
                 kMaxDG);
@@ -598,10 +669,8 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
     L->n = n;
     L->d = d;
     L->with_blur = with_blur;
-    // scale_factor[i] = float(1/sqrt((i+2)(i+1)) * inv_std_dev), inv_std_dev a float (:180-183)
-    const float inv_std = with_blur ? (float)(sqrt(2.0 / 3.0) * d1) : (float)(sqrt(1.0 / 6.0) * d1);
-    float sc[3] = {0.f, 0.f, 0.f};
-    for (int i = 0; i < d; ++i) sc[i] = (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std);
+    float sc[3];
+    lat_scale(d, with_blur, sc);
     // The table is sized from the previous lattice of the same kind (x8..16 head room: the lattice at most doubles
     // per EM iteration) so that clearing and compacting it costs microseconds; an overflow falls back to the
     // worst-case size.
@@ -613,11 +682,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         if (capu > L->cap) capu = L->cap;
     }
     auto embed = [&](int64_t first, int64_t last, unsigned long long mask) {
-        const unsigned nb = (unsigned)prg::ceil_div(last - first, kBlock);
-        if (nb == 0) return;
-        if (d == 1) k_embed<1><<<nb, kBlock, 0, st>>>(L->feat, first, last, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
-        else if (d == 2) k_embed<2><<<nb, kBlock, 0, st>>>(L->feat, first, last, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
-        else k_embed<3><<<nb, kBlock, 0, st>>>(L->feat, first, last, sc[0], sc[1], sc[2], L->tkeys, mask, L->pslot, L->bary, L->count + 1);
+        launch_embed(L, d, first, last, sc, L->tkeys, mask, L->count + 1);
     };
     L->built = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -644,6 +709,13 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                 return PRG_OK;  // prev_size[mode] keeps the last full count
             }
             PRG_HIP(hipMemsetAsync(L->count, 0, sizeof(int), st));  // the vertex counter restarts for the compaction
+        } else if (n >= 4096) {
+            // no decision to take, but the table is still filled in two launches: the first sixteenth of the points
+            // creates most vertices almost uncontended, the rest then find them with plain reads - one launch over
+            // all points has every wave compare-and-swap the same few hundred empty slots at once (3x slower while
+            // the lattice is small)
+            done = n / 16;
+            embed(0, done, mask);
         }
         if (host[1] == 0) {
             embed(done, n, mask);
@@ -651,7 +723,15 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                                                                                L->count);
             PRG_HIP(hipGetLastError());
             PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+            if (L->side_pending)  // the speculative decision stage rides on the same synchronisation
+                PRG_HIP(hipMemcpyAsync(reinterpret_cast<int*>(L->pinned) + 4, L->count2, 2 * sizeof(int),
+                                       hipMemcpyDeviceToHost, st));
             PRG_HIP(hipStreamSynchronize(st));
+            if (L->side_pending) {
+                L->side_size = reinterpret_cast<volatile int*>(L->pinned)[4];
+                L->side_overflow = reinterpret_cast<volatile int*>(L->pinned)[5];
+                L->side_pending = false;
+            }
         }
         L->size = host[0];
         if (getenv("PRG_DEBUG_LATTICE"))
@@ -682,6 +762,35 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         else k_neighbours<3><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
         PRG_HIP(hipGetLastError());
     }
+    return PRG_OK;
+}
+
+// Decision stage of the blurred lattice into the side table, WITHOUT synchronising: 1/16 of the points are hashed with
+// the blur scaling and counted; the count is read back by the next lat_build on this lattice (side_pending).  A subset's
+// vertices are a subset of the vertices, so side_size > threshold proves that the blurred lattice is too large.
+int lat_side_stage(Lattice* L, int64_t n, int d) {
+    const int d1 = d + 1;
+    hipStream_t st = L->stream;
+    const int64_t n16 = n / 16;
+    int64_t want = 1;
+    while (want < 4 * n16 * d1) want <<= 1;
+    if (want > L->cap2) {
+        if (L->tkeys2) (void)hipFree(L->tkeys2);
+        L->tkeys2 = nullptr;
+        PRG_HIP(hipMalloc((void**)&L->tkeys2, want * sizeof(unsigned long long)));
+        L->cap2 = want;
+    }
+    if (!L->count2) PRG_HIP(hipMalloc((void**)&L->count2, 2 * sizeof(int)));
+    if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
+    float sc[3];
+    lat_scale(d, 1, sc);
+    PRG_HIP(hipMemsetAsync(L->tkeys2, 0xFF, want * sizeof(unsigned long long), st));
+    PRG_HIP(hipMemsetAsync(L->count2, 0, 2 * sizeof(int), st));
+    launch_embed(L, d, 0, n16, sc, L->tkeys2, (unsigned long long)want - 1, L->count2 + 1);
+    k_count_occupied<<<(unsigned)std::min<int64_t>(prg::ceil_div(want, kBlock), 2048), kBlock, 0, st>>>(L->tkeys2, want,
+                                                                                                       L->count2);
+    PRG_HIP(hipGetLastError());
+    L->side_pending = true;
     return PRG_OK;
 }
 
@@ -843,37 +952,13 @@ struct prg_filterreg {
     int64_t part_blocks = 0;
     std::vector<int> tgt_order;  // Morton order of the target (kernel position -> caller's index); see prg_fr_set_target
     bool have_src = false, have_tgt = false, have_estep = false;
+    FrFeat prod;             // feature producer handed to the embedding kernels
+    int last_blur = 1;       // with_blur of the previous E-step: which lattice the next one tries first
 };
 
 namespace {
 
 constexpr int kFrComp = 32;  // 0 sw,1-3 sw*m,4-6 sw*t,7 sw2,8-10 sw2*m,11-13 sw2*t,14-22 sw2*m*t^T,23 q,24 s2num,25 m0m0,26 cnt
-
-__global__ __launch_bounds__(kBlock) void k_fr_transform(const double* __restrict__ src, int64_t m, int dim,
-                                                         const double* __restrict__ state, double* __restrict__ ts,
-                                                         float* __restrict__ feat) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= m) return;
-    const double sigma = sqrt(state[12]);
-    double y[3] = {0, 0, 0}, z[3] = {0, 0, 0};
-    for (int k = 0; k < dim; ++k) y[k] = src[i * dim + k];
-    for (int r = 0; r < dim; ++r) {
-        double acc = 0.0;
-        for (int k = 0; k < dim; ++k) acc += y[k] * state[3 * r + k];  // dot(points, rot.T), transformation.py:49-50
-        z[r] = acc + state[9 + r];
-    }
-    for (int k = 0; k < 3; ++k) ts[i * 3 + k] = z[k];
-    for (int k = 0; k < dim; ++k) feat[i * dim + k] = (float)(z[k] / sigma);  // fx = t_source / sigma, :84
-}
-
-__global__ __launch_bounds__(kBlock) void k_fr_target_features(const double* __restrict__ tgt, int64_t n, int dim,
-                                                               const double* __restrict__ state,
-                                                               float* __restrict__ feat /* at row M */) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const double sigma = sqrt(state[12]);
-    for (int k = 0; k < dim; ++k) feat[i * dim + k] = (float)(tgt[i * dim + k] / sigma);  // fy = target / sigma, :85
-}
 
 // values [M+N][ch]: source rows 0; target rows (1, y, |y|^2 [, normal])   (filterreg.py:92-105)
 __global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__ tgt, const double* __restrict__ nrm,
@@ -907,13 +992,13 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
                                                      const double* __restrict__ ts, int64_t m, int dim, double wfac,
                                                      const double* __restrict__ state, double* __restrict__ part) {
     __shared__ double sh[4][kFrComp];
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     double a[kFrComp];
 #pragma unroll
     for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
     const double sigma2 = state[12];
     const double c = fr_uniform_c(wfac, dim, sigma2);
-    if (i < m) {
+    // grid-stride: a few hundred workgroups, each thread sums several points before the (32-component) reduction
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         const float m0 = vout[i * ch];
         if (m0 != 0.f) {
             const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
@@ -927,15 +1012,15 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
             const double w2 = w * w;
             double mod[3];
             for (int k = 0; k < 3; ++k) mod[k] = k < dim ? (double)(float)z[k] : 0.0;
-            a[0] = w;
-            a[7] = w2;
+            a[0] += w;
+            a[7] += w2;
             double r2 = 0.0, zz = 0.0, zm1 = 0.0;
             for (int k = 0; k < 3; ++k) {
-                a[1 + k] = w * mod[k];
-                a[4 + k] = w * (double)tg[k];
-                a[8 + k] = w2 * mod[k];
-                a[11 + k] = w2 * (double)tg[k];
-                for (int j = 0; j < 3; ++j) a[14 + 3 * k + j] = w2 * mod[k] * (double)tg[j];
+                a[1 + k] += w * mod[k];
+                a[4 + k] += w * (double)tg[k];
+                a[8 + k] += w2 * mod[k];
+                a[11 + k] += w2 * (double)tg[k];
+                for (int j = 0; j < 3; ++j) a[14 + 3 * k + j] += w2 * mod[k] * (double)tg[j];
                 if (k < dim) {
                     const double rx = dr * (z[k] - (double)tg[k]);
                     r2 += rx * rx;
@@ -943,10 +1028,10 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
                     zm1 += z[k] * (double)m1[k];
                 }
             }
-            a[23] = sqrt(r2);                                                          // q term, :181-182
-            a[24] = ((double)m0 * zz - 2.0 * zm1 + (double)m2) / ((double)m0 + c);    // :192-194
-            a[25] = m0m0;
-            a[26] = 1.0;
+            a[23] += sqrt(r2);                                                          // q term, :181-182
+            a[24] += ((double)m0 * zz - 2.0 * zm1 + (double)m2) / ((double)m0 + c);    // :192-194
+            a[25] += m0m0;
+            a[26] += 1.0;
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -969,13 +1054,12 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restri
                                                            int64_t m, double wfac, const double* __restrict__ state,
                                                            double* __restrict__ part) {
     __shared__ double sh[4][kFrComp];
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     double a[kFrComp];
 #pragma unroll
     for (int k = 0; k < kFrComp; ++k) a[k] = 0.0;
     const double sigma2 = state[12];
     const double c = fr_uniform_c(wfac, 3, sigma2);
-    if (i < m) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         const float m0 = vout[i * 8];
         if (m0 != 0.f) {
             const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
@@ -999,13 +1083,13 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restri
 #pragma unroll
             for (int r = 0; r < 6; ++r)
 #pragma unroll
-                for (int q = r; q < 6; ++q) a[idx++] = w * jac[r] * jac[q];
+                for (int q = r; q < 6; ++q) a[idx++] += w * jac[r] * jac[q];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) a[21 + r] = w * residual * jac[r];
-            a[27] = w * w * residual * residual;
-            a[28] = ((double)m0 * zz - 2.0 * zm1 + (double)vout[i * 8 + 4]) / ((double)m0 + c);
-            a[29] = m0m0;
-            a[30] = 1.0;
+            for (int r = 0; r < 6; ++r) a[21 + r] += w * residual * jac[r];
+            a[27] += w * w * residual * residual;
+            a[28] += ((double)m0 * zz - 2.0 * zm1 + (double)vout[i * 8 + 4]) / ((double)m0 + c);
+            a[29] += m0m0;
+            a[30] += 1.0;
         }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1431,15 +1515,14 @@ int prg_fr_destroy(prg_filterreg* h) {
 static int fr_alloc(prg_filterreg* h) {
     if (!(h->have_src && h->have_tgt)) return PRG_OK;
     const int64_t tot = h->M + h->N;
-    for (void* p : {(void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->part, (void*)h->L.feat})
+    for (void* p : {(void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->part})
         if (p) (void)hipFree(p);
-    h->ts = nullptr; h->vin = nullptr; h->vout = nullptr; h->part = nullptr; h->L.feat = nullptr;
+    h->ts = nullptr; h->vin = nullptr; h->vout = nullptr; h->part = nullptr;
     PRG_HIP(hipMalloc((void**)&h->ts, (size_t)h->M * 3 * sizeof(double)));
     PRG_HIP(hipMalloc((void**)&h->vin, (size_t)tot * 8 * sizeof(float)));
     PRG_HIP(hipMalloc((void**)&h->vout, (size_t)h->M * 8 * sizeof(float)));
-    h->part_blocks = prg::ceil_div(h->M, kBlock);
+    h->part_blocks = std::min<int64_t>(prg::ceil_div(h->M, kBlock), 512);  // grid-stride M-step term kernels
     PRG_HIP(hipMalloc((void**)&h->part, (size_t)h->part_blocks * kFrComp * sizeof(double)));
-    PRG_HIP(hipMalloc((void**)&h->L.feat, (size_t)tot * h->D * sizeof(float)));
     k_fr_values<<<(unsigned)prg::ceil_div(tot, kBlock), kBlock, 0, h->L.stream>>>(h->tgt, h->nrm, h->M, h->N, h->D,
                                                                                   h->ch, h->vin);
     PRG_HIP(hipGetLastError());
@@ -1503,28 +1586,43 @@ int prg_fr_set_state(prg_filterreg* h, const double* rot9, const double* t3, dou
     buf[12] = sigma2;
     PRG_HIP(hipMemcpyAsync(h->state, buf, sizeof(buf), hipMemcpyHostToDevice, h->L.stream));
     PRG_HIP(hipStreamSynchronize(h->L.stream));
+    h->last_blur = 1;  // a (re)started registration begins with a large sigma2: try the blurred lattice first
     return PRG_OK;
 }
 
 int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_blur) {
     PRG_REQUIRE(h && h->have_src && h->have_tgt, PRG_ERR_STATE, "prg_fr_estep: clouds not set");
     prg::DeviceGuard g(h->L.device);
-    hipStream_t st = h->L.stream;
     const int64_t tot = h->M + h->N;
-    k_fr_transform<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, st>>>(h->src, h->M, h->D, h->state, h->ts,
-                                                                            h->L.feat);
-    k_fr_target_features<<<(unsigned)prg::ceil_div(h->N, kBlock), kBlock, 0, st>>>(h->tgt, h->N, h->D, h->state,
-                                                                                  h->L.feat + h->M * h->D);
-    PRG_HIP(hipGetLastError());
+    // features are produced inside the embedding kernels (transform, division by sigma, float32 cast)
+    h->prod = FrFeat{h->src, h->tgt, h->state, h->ts, h->M, h->D};
+    h->L.prod = &h->prod;
     int blur = 1;
-    // filterreg.py:90-91: the blurred lattice is used only if it has at most N * alpha vertices
+    // filterreg.py:90-91: the blurred lattice is used only if it has at most N * alpha vertices.  The answer is exact
+    // every time; what changes with the previous E-step's answer is which lattice is built FIRST:
+    //   previous blurred     -> the blurred lattice, whole (one synchronisation); if it came out too large, the other one;
+    //   previous not blurred -> the non-blurred lattice, whole, while a 1/16 subset hashed with the blur scaling proves
+    //                           that the blurred one is still too large (same synchronisation); if the proof fails, the
+    //                           staged decision of round 1 (rare: sigma2 would have to grow again).
     const double thr = (double)h->N * alpha;
     const int64_t decide = thr >= 0.0 && thr < 2.0e9 ? (int64_t)floor(thr) : -1;
-    PRG_TRY(lat_build(&h->L, tot, h->D, 1, decide));
-    if (!h->L.built || (double)h->L.size > thr) {
-        blur = 0;
+    bool done = false;
+    if (h->last_blur == 0 && decide >= 0 && tot >= 4096) {
+        PRG_TRY(lat_side_stage(&h->L, tot, h->D));
         PRG_TRY(lat_build(&h->L, tot, h->D, 0));
+        if (h->L.side_overflow == 0 && h->L.side_size > decide) {
+            blur = 0;
+            done = true;
+        }
     }
+    if (!done) {
+        PRG_TRY(lat_build(&h->L, tot, h->D, 1, h->last_blur == 1 ? -1 : decide));
+        if (!h->L.built || (double)h->L.size > thr) {
+            blur = 0;
+            PRG_TRY(lat_build(&h->L, tot, h->D, 0));
+        }
+    }
+    h->last_blur = blur;
     // one fused 5-channel pass: channels 0 (m0) and 4 (m2) are single-channel filters in the reference
     // (seqCompute arithmetic), channels 1..3 (m1) its 3-channel filter (sseCompute arithmetic)
     PRG_TRY(lat_filter(&h->L, h->vin, h->ch, h->M, h->M, 0x11u, h->vout));  // normals (ch 5..7): 3-channel filter
@@ -1632,7 +1730,7 @@ int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_sourc
     PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_fr_mstep_from_arrays: hipSetDevice(%d) failed", device);
     hipStream_t st = (hipStream_t)hip_stream;
     const int ch = nx_hd ? 8 : 5;
-    const int nblk = (int)prg::ceil_div(m, kBlock);
+    const int nblk = (int)std::min<int64_t>(prg::ceil_div(m, kBlock), 512), npack = (int)prg::ceil_div(m, kBlock);
     struct Tmp {
         void* p = nullptr;
         ~Tmp() { if (p) (void)hipFree(p); }
@@ -1657,7 +1755,7 @@ int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_sourc
     for (int i = 0; i < 3; ++i) host_state[9 + i] = t3[i];
     host_state[12] = sigma2;
     PRG_HIP(hipMemcpyAsync(b_state.p, host_state, sizeof(host_state), hipMemcpyHostToDevice, st));
-    k_fr_pack_estep<<<nblk, kBlock, 0, st>>>((const double*)(in + o_ts), (const float*)(in + o_m0),
+    k_fr_pack_estep<<<npack, kBlock, 0, st>>>((const double*)(in + o_ts), (const float*)(in + o_m0),
                                              (const float*)(in + o_m1), m2_hd ? (const float*)(in + o_m2) : nullptr,
                                              nx_hd ? (const float*)(in + o_nx) : nullptr, m, dim, ch, (double*)b_ts.p,
                                              (float*)b_v.p);
