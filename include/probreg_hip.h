@@ -78,13 +78,13 @@ int prg_cpd_destroy(prg_cpd* h);
  * is an exact zero in fp32.  The non-rigid path keeps the source unsorted. */
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
 
-/* Engine of the E-step's DENSE regime (sigma2 large: every pair contributes).  mode 0 (default): the vector-pipe sweeps.
- * mode 1: the column pass runs on the matrix cores (f32 MFMA distance blocks) while
- * |log2(e) / (2 sigma2)| * (squared diagonal of the target's bounding box) < bound (default 400) and the registration
- * then stays on the culled vector-pipe sweeps; mode 2: BOTH sweeps on the matrix cores whatever the bound says.  On
- * gfx950 f32 MFMA executes on the vector ALUs (tools/mfma_overlap.hip), so modes 1 / 2 are parity-tested alternatives
- * of equal speed, not the default.  bound = 0 keeps the current value.  prg_cpd_last_estep_engine reports which engine
- * the last E-step's column pass used (1 = matrix cores). */
+/* Engine of the E-step's DENSE regime (sigma2 large: every pair contributes).  mode 1 (default): the pair sweeps take
+ * their exponents from the matrix cores (bf16x3-split MFMA distance blocks) while
+ * |log2(e) / (2 sigma2)| * (squared diagonal of the target's bounding box) < bound (default 1100; the row pass leaves
+ * at 0.45 of it) - from there on the culled vector-pipe sweeps skip enough pairs to be faster and the registration
+ * stays on them; mode 0: vector-pipe sweeps only; mode 2: both sweeps on the matrix cores whatever the bound says
+ * (tests, measurements).  bound = 0 keeps the current value.  prg_cpd_last_estep_engine reports which engine the last
+ * E-step's column pass used (1 = matrix cores). */
 int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound);
 int prg_cpd_last_estep_engine(prg_cpd* h, int* engine);
 

@@ -577,6 +577,11 @@ __global__ void k_mstep(const double* __restrict__ mom, double* __restrict__ par
                 Mx[i][j] = in ? YPY[j][i] : ((i == j) ? 1.0 : 0.0);
                 Mx[i][3 + j] = in ? A[j][i] : 0.0;
             }
+        double ypy_scale = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ypy_scale = fmax(ypy_scale, (i < d && j < d) ? fabs(YPY[i][j]) : 0.0);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
 #pragma unroll
@@ -586,6 +591,10 @@ __global__ void k_mstep(const double* __restrict__ mom, double* __restrict__ par
                     for (int j = 0; j < 6; ++j) { const double tmp = Mx[c][j]; Mx[c][j] = Mx[r][j]; Mx[r][j] = tmp; }
                 }
             }
+            // np.linalg.solve raises on a singular matrix (cpd.py:237).  The moments are fp64 sums, so a rank-deficient
+            // Y^T diag(p1) Y (fewer than D + 1 supported points, coplanar ones) shows up as a pivot at round-off
+            // level of the matrix scale: turn it into the non-finite result the host maps to LinAlgError
+            if (c < d && !(fabs(Mx[c][c]) > 1e-12 * ypy_scale)) Mx[c][c] = 0.0;
 #pragma unroll
             for (int r = c + 1; r < 3; ++r) {
                 const double f = Mx[r][c] / Mx[c][c];
@@ -1134,8 +1143,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // 3.1c).  One small read-back per E-step while the registration is in the dense regime; once sigma2 has fallen to
     // where the culled VALU sweeps skip most of the pairs (|kk| * extent^2 above the bound) the registration stays on
     // them and never synchronises again.
-    bool use_mfma = false;
-    if (mfma_possible && !h->mfma_off && h->have_colmin) {
+    bool use_mfma = false, row_mfma = false;  // column pass / row pass on the matrix cores
+    if (mfma_possible && !h->mfma_off) {
         if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
         float* st = reinterpret_cast<float*>(h->pinned + 40);
         PRG_HIP(hipMemcpyAsync(st, h->motion, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
@@ -1144,9 +1153,14 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         const double sigma2 = h->pinned[39], nk = kLog2e / (2.0 * sigma2);
         const double mo = st[slot], cmax = st[4 + (slot ^ 1)], r = sqrt(cmax);
         const double width = r >= mo ? 4.0 * r * mo : (r + mo) * (r + mo);  // of the bracket of a column minimum
-        const bool dense = h->dense_engine >= 2 || nk * h->text2 < h->dense_bound;
+        const bool forced = h->dense_engine >= 2, ok = sigma2 > 0.0 && std::isfinite(sigma2);
+        const bool dense = ok && (forced || nk * h->text2 < h->dense_bound);
         if (!dense) h->mfma_off = true;
-        use_mfma = dense && sigma2 > 0.0 && std::isfinite(cmax) && nk * width < 150.0;
+        // the column pass needs the previous E-step's column minima for its exponent offsets; the row pass does not.
+        // The culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
+        // (profiles/r2_mfma_vs_valu_estep_100k.log): it leaves at 0.45 of the bound.
+        use_mfma = dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0;
+        row_mfma = dense && (forced || nk * h->text2 < 0.45 * h->dense_bound);
     }
     h->last_estep_mfma = use_mfma;
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
@@ -1164,10 +1178,6 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                       h->colmin + h->Ncap,
                                                       use_cull ? h->tmeta : nullptr, use_mfma ? 1 : 0, h->motion, slot);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
-    // (the row pass gains nothing from the matrix cores on gfx950 - f32 MFMA executes on the vector ALUs and its four
-    // contraction MFMAs cost what the FMAs they replace cost, profiles/r2_mfma_valu_overlap_microbench.log - so the
-    // automatic mode keeps the culled vector-pipe row pass; mode 2 runs both sweeps on the matrix cores for the tests)
-    const bool row_mfma = use_mfma && h->dense_engine >= 2;
     if (row_mfma)
         prg::launch_rowpass_mfma(h, mfma_seg);
     else if (use_cull)

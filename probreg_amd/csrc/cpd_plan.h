@@ -52,9 +52,9 @@ struct prg_cpd {
     bool have_colmin = false;
     // matrix-core (dense regime) sweeps
     float4* rorig = nullptr;    // [Mcap/512] origin of each 512-row block of the last matrix-core row pass
-    int dense_engine = 0;       // 0: VALU sweeps only (default: measured as fast), 1: matrix-core column
-                                // pass in the dense regime, 2: both sweeps on the matrix cores, always (tests)
-    double dense_bound = 400.0;  // dense regime = |kk| * (target bounding-box diagonal)^2 below this (C1: sigma2 > ~1e-2)
+    int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
+                                // 2: both sweeps on the matrix cores, always (tests)
+    double dense_bound = 1100.0;  // dense regime = |kk| * (target bounding-box diagonal)^2 below this (C1: sigma2 > ~6e-3)
     bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
     bool last_estep_mfma = false;
     double text2 = 0.0;         // squared diagonal of the local target's bounding box

@@ -1,24 +1,25 @@
-// E-step pair sweeps on the matrix cores (f32 MFMA), MI355X gfx950 - the DENSE regime of CPD's E-step (cpd.py:71-88).
+// E-step pair sweeps with the squared distances on the matrix cores, MI355X gfx950 - the DENSE regime of CPD's E-step
+// (cpd.py:71-88).
 //
 // While sigma2 is large every source-target pair contributes and the VALU sweeps of cpd_sweeps_packed.hip are bound by
-// their ~13 vector instructions per pair.  Here the squared distances come from the matrix pipe instead:
+// their ~13 vector instructions per pair, 7 of which form the exponent.  Here the exponent comes from the matrix pipe:
 //
-//   kk |x - z|^2 + b  =  [x'_x x'_y x'_z 1] . [-2kk z'_x, -2kk z'_y, -2kk z'_z, kk |z'|^2]^T  +  (kk |x'|^2 + b)
+//   kk |x - z|^2 + b  =  x' . (-2kk z')  +  kk |z'|^2  +  (kk |x'|^2 + b)
 //
-// is one v_mfma_f32_16x16x4_f32 per 16 x 16 block of pairs (K = 4 holds the three coordinates and the owned point's
-// constant; the streamed point's constant rides in the C operand), the vector pipe only exponentiates (4 v_exp_f32 per
-// lane per block), and the row pass' contraction P @ [x' 1] is four v_mfma_f32_4x4x1_16b_f32 whose A operand IS the
-// exponentiated accumulator of the first MFMA and whose B operand is a 16-byte LDS read - no cross-lane traffic
-// (lane maps: tools/mfma_layout_probe.hip).  f32 MFMA is an exact k-ordered fmaf chain and runs at the vector rate
-// (157 TFLOP/s) CONCURRENTLY with the vector pipe: a block of 256 pairs costs 32 (column pass) / 64 (row pass) matrix
-// cycles and 4 transcendentals per lane, against ~100 vector cycles in the VALU sweeps.
+// with every f32 factor split into three bf16 pieces (24 significant bits; the six piece products per coordinate that
+// matter, plus the owned point's constant in three pieces, fill 21 of the 32 K slots of ONE v_mfma_f32_16x16x32_bf16 per
+// 16 x 16 block of pairs; every piece product is exact in the f32 accumulator and the streamed point's constant rides
+// in the C operand).  The vector pipe is left with the exponential, the sums and the row pass' contraction.
+// (f32-input MFMA was tried first and is not used: on gfx950 it executes on the vector ALUs - tools/mfma_overlap.hip,
+// profiles/r2_mfma_valu_overlap_microbench.log - so it saves instructions but no time; the bf16 pipe is 2x faster
+// per block and separate.)
 //
 // Work mapping.  A workgroup (4 waves) owns 4 x OWN tiles of 16 consecutive points of one cloud (512 points: one
 // spatially compact patch, the clouds are sorted along a space-filling curve) and streams a segment of the other
-// cloud through LDS in chunks of 512 points: every thread loads two float4 points, shifts them by the workgroup's
-// origin, forms the per-point constant and writes planes x' y' z' 1 c |x'|^2; the waves then read MFMA operands
-// straight out of those planes (one ds_read_b32 + three ds_read_b128 per 16 streamed points, conflict-free).  The
-// next chunk's global loads are in flight while the current one is multiplied; one barrier per chunk.
+// cloud through LDS in chunks of 256 points: every thread loads one float4 point, shifts it by the workgroup's
+// origin, splits it into bf16 pieces and writes the A-operand slots plus f32 planes c x' y' z' |x'|^2; the waves read
+// their MFMA operands straight out of LDS (ds_read_b128, conflict-free).  The next chunk's global loads are in flight
+// while the current one is multiplied; one barrier per chunk.
 //
 // Precision.  The expanded form cancels: its rounding error is eps * |kk| * (|x'|^2 + |z'|^2), not eps * |exponent|.  Every
 // workgroup therefore shifts both clouds by ITS OWN origin o (the first of the points it owns): for the pairs that
@@ -38,19 +39,19 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr double kLog2e = 1.4426950408889634;
 constexpr int kBlock = prg::kSweepBlock;
 constexpr int kOwn = prg::kMfmaOwn;          // tiles of 16 points a wave owns
 constexpr int kWgPoints = 4 * 16 * kOwn;     // points a workgroup owns (512)
-constexpr int kChunk = 512;                  // streamed points staged in LDS at a time (2 per thread)
+constexpr int kChunk = 256;                  // streamed points staged in LDS at a time (1 per thread; 2 x 21 KB of LDS)
 constexpr int kChunkTiles = kChunk / 16;
-constexpr int kPlane = 96;                   // floats per staged tile: x'[16] y'[16] z'[16] 1[16] c[16] |x'|^2[16]
+// staged tile: 4 groups x 16 points x 8 bf16 (the A operand, 1 KB) followed by f32 planes c[16] x'[16] y'[16] z'[16] sq[16]
+constexpr int kTileBytes = 1024 + 5 * 64;
+constexpr int kTileFloats = kTileBytes / 4;
 
 __device__ __forceinline__ float exp2r(float a) { return __builtin_amdgcn_exp2f(a); }
-__device__ __forceinline__ float sel4(int k, float a, float b, float c, float d) {
-    return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d));
-}
 __device__ __forceinline__ float xor_sum(float v) {  // sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48)
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -62,18 +63,58 @@ __device__ __forceinline__ float xor_max(float v) {
     return v;
 }
 
-// one streamed point -> its planes in the staging buffer.  `w` is added to the constant (the row pass' b_n; the source's
-// additive weight is 0 for plain CPD).  Pads (1e18 away) give c = -huge or -inf and every exponential of theirs is 0.
+// a = h + m + l with three bf16 pieces: 24 significant bits, every piece product exact in the f32 accumulator
+struct Split3 { __bf16 h, m, l; };
+__device__ __forceinline__ Split3 split3(float a) {
+    Split3 s;
+    s.h = (__bf16)a;
+    const float r1 = a - (float)s.h;
+    s.m = (__bf16)r1;
+    s.l = (__bf16)(r1 - (float)s.m);
+    return s;
+}
+// K slots of one coordinate: streamed side [h h m h l m 0 0] . owned side [h m h l h m 0 0] = every product of pieces
+// down to 2^-24 of |a||b| (hh, hm, mh, hl, lh, mm)
+__device__ __forceinline__ bf16x8 slots_streamed(const Split3 s) {
+    const __bf16 z = (__bf16)0.f;
+    return (bf16x8){s.h, s.h, s.m, s.h, s.l, s.m, z, z};
+}
+__device__ __forceinline__ bf16x8 slots_owned(const Split3 s) {
+    const __bf16 z = (__bf16)0.f;
+    return (bf16x8){s.h, s.m, s.h, s.l, s.h, s.m, z, z};
+}
+
+// one streamed point -> its A-operand slots (three coordinate groups + the group of ones that picks up the owned
+// point's constant) and its f32 planes.  Pads (1e18 away) give c = -huge or -inf: every exponential of theirs is 0.
 __device__ __forceinline__ void stage_point(float* __restrict__ buf, int p, const float4 v, const float4 o, float kk) {
     const float dx = v.x - o.x, dy = v.y - o.y, dz = v.z - o.z;
     const float sq = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-    float* t = buf + (p >> 4) * kPlane + (p & 15);
-    t[0] = dx;
-    t[16] = dy;
-    t[32] = dz;
-    t[48] = 1.f;
-    t[64] = fmaf(kk, sq, v.w);
-    t[80] = sq;
+    float* tile = buf + (p >> 4) * kTileFloats;
+    bf16x8* a = reinterpret_cast<bf16x8*>(tile);
+    const int j = p & 15;
+    const __bf16 one = (__bf16)1.f, z = (__bf16)0.f;
+    a[0 * 16 + j] = slots_streamed(split3(dx));
+    a[1 * 16 + j] = slots_streamed(split3(dy));
+    a[2 * 16 + j] = slots_streamed(split3(dz));
+    a[3 * 16 + j] = (bf16x8){one, one, one, z, z, z, z, z};
+    float* f = tile + 256 + j;
+    f[0] = fmaf(kk, sq, v.w);
+    f[16] = dx;
+    f[32] = dy;
+    f[48] = dz;
+    f[64] = sq;
+}
+
+// B operand of an owned point (lane l: slots of K group l / 16 for point l % 16): -2kk (x - o) per coordinate, and the
+// point's constant `cst` split in three in the last group
+__device__ __forceinline__ bf16x8 owned_operand(int k, float kk, float dx, float dy, float dz, float cst) {
+    const float m2 = -2.f * kk;
+    if (k == 0) return slots_owned(split3(m2 * dx));
+    if (k == 1) return slots_owned(split3(m2 * dy));
+    if (k == 2) return slots_owned(split3(m2 * dz));
+    const Split3 c = split3(cst);
+    const __bf16 z = (__bf16)0.f;
+    return (bf16x8){c.h, c.m, c.l, z, z, z, z, z};
 }
 
 // ---- sweep 1 on the matrix cores: den_n of cpd.py:80 --------------------------------------------------------------
@@ -84,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          const unsigned* __restrict__ motion, int chunks_per_seg,
                                                          int64_t m_total, const double* __restrict__ params,
                                                          float2* __restrict__ colpart, int64_t ncap) {
-    __shared__ float stage[2][kChunkTiles * kPlane];
+    __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n0wg = (int64_t)blockIdx.x * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
@@ -92,47 +133,45 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     float4 o = tgt4[n0wg];  // the workgroup's origin: a real point of its patch
     o.w = 0.f;
     const int k = lane >> 4, j = lane & 15;
-    float bx[kOwn], s[kOwn], tm[kOwn], off[kOwn];
+    bf16x8 bx[kOwn];
+    float s[kOwn], tm[kOwn], off[kOwn];
 #pragma unroll
     for (int t = 0; t < kOwn; ++t) {
         const float4 x = tgt4[n0 + 16 * t + j];
         const float xx = x.x - o.x, xy = x.y - o.y, xz = x.z - o.z;
         const float xsq = fmaf(xz, xz, fmaf(xy, xy, xx * xx));
         off[t] = prg::col_seed_offset(kk, colmin_prev[n0 + 16 * t + j], mo);
-        const float m2 = -2.f * kk;
-        bx[t] = sel4(k, m2 * xx, m2 * xy, m2 * xz, fmaf(kk, xsq, off[t]));
+        bx[t] = owned_operand(k, kk, xx, xy, xz, fmaf(kk, xsq, off[t]));
         s[t] = 0.f;
         tm[t] = -INFINITY;
     }
     const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
     const int64_t nchunks = (m_total + kChunk - 1) / kChunk;
     const int64_t c1 = c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks;
-    float4 ra = z4[c0 * kChunk + threadIdx.x], rb = z4[c0 * kChunk + kBlock + threadIdx.x];
-    ra.w = rb.w = 0.f;  // (weighted sources do not take this path)
+    float4 ra = z4[c0 * kChunk + threadIdx.x];
+    ra.w = 0.f;  // (weighted sources do not take this path)
     stage_point(stage[0], threadIdx.x, ra, o, kk);
-    stage_point(stage[0], kBlock + threadIdx.x, rb, o, kk);
     __syncthreads();
     for (int64_t c = c0; c < c1; ++c) {
         const float* __restrict__ buf = stage[(c - c0) & 1];
         const bool more = c + 1 < c1;
         if (more) {
             ra = z4[(c + 1) * kChunk + threadIdx.x];
-            rb = z4[(c + 1) * kChunk + kBlock + threadIdx.x];
-            ra.w = rb.w = 0.f;
+            ra.w = 0.f;
         }
         // software pipeline: the MFMA of the NEXT (tile, column tile) pair is issued before the current pair's
-        // accumulator is exponentiated, so the matrix pipe's 40-cycle latency hides under the transcendentals
-        float a1 = buf[lane];
-        f32x4 cz = *reinterpret_cast<const f32x4*>(buf + 64 + 4 * k);
-        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bx[0], cz, 0, 0, 0);
+        // accumulator is exponentiated
+        bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
+        f32x4 cz = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[0], cz, 0, 0, 0);
         for (int t = 0; t < kChunkTiles; ++t) {
-            const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kPlane;
-            const float a1n = tn[lane];
-            const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 64 + 4 * k);
+            const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
+            const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+            const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
 #pragma unroll
             for (int u = 0; u < kOwn; ++u) {
-                const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bx[u + 1], cz, 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_16x16x4f32(a1n, bx[0], czn, 0, 0, 0);
+                const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[u + 1], cz, 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bx[0], czn, 0, 0, 0);
                 tm[u] = fmaxf(fmaxf(tm[u], d[0]), d[1]);
                 tm[u] = fmaxf(fmaxf(tm[u], d[2]), d[3]);
                 s[u] += (exp2r(d[0]) + exp2r(d[1])) + (exp2r(d[2]) + exp2r(d[3]));
@@ -144,7 +183,6 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
         if (more) {
             float* __restrict__ nb = stage[(c + 1 - c0) & 1];
             stage_point(nb, threadIdx.x, ra, o, kk);
-            stage_point(nb, kBlock + threadIdx.x, rb, o, kk);
         }
         __syncthreads();
     }
@@ -163,72 +201,63 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
 }
 
 // ---- sweep 2 on the matrix cores: p1, px and the sigma2 residual of cpd.py:84-87 ----------------------------------
-// Per (row tile, target tile):
-//   D = mfma16x16x4([x' 1], [-2kk z'; kk|z'|^2], kk|x'|^2 + b)      lane l, reg r: pair (n = 4 (l/16) + r, m = l % 16)
-//   P = exp2(D)
-//   acc += mfma4x4x1(P[r], [x' 1][n][c = l % 4])  r = 0..3          block l/4: rows m = 4 ((l/4) % 4) + i, columns c
-//   e   += P[r] |x'_n|^2
-// Output plane blockIdx.y, relative to the workgroup's origin o (stored in rorig[row block of 512]): p1,
-// u' = sum P (x - o), e' = sum P |x - o|^2 - k_row_moments' residual form with o as the reference point.
+// Per (row tile, target tile): D = mfma(streamed slots, owned slots, kk|x'|^2 + b); lane l, reg r holds the pair
+// (n = 4 (l/16) + r, m = l % 16); P = exp2(D); the lane adds P, P x'_n, P |x'_n|^2 into its row's partial sums (the
+// four lanes of a row are added up at the end).  Output plane blockIdx.y, relative to the workgroup's origin o (stored
+// in rorig[row block of 512]): p1, u' = sum P (x - o), e' = sum P |x - o|^2 - k_row_moments' residual form with o as
+// the reference point.
 __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
                                                          int chunks_per_seg, int64_t n_total,
                                                          const double* __restrict__ params, float* __restrict__ rowpart,
                                                          int64_t mcap, float4* __restrict__ rorig) {
-    __shared__ float stage[2][kChunkTiles * kPlane];
+    __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t m0wg = (int64_t)blockIdx.x * kWgPoints, m0 = m0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     float4 o = z4[m0wg];
     o.w = 0.f;
-    const int k = lane >> 4, j = lane & 15, cc = lane & 3;
-    float bz[kOwn], e[kOwn];
-    f32x4 acc[kOwn];
+    const int k = lane >> 4, j = lane & 15;
+    bf16x8 bz[kOwn];
+    float p1[kOwn], ux[kOwn], uy[kOwn], uz[kOwn], e[kOwn];
 #pragma unroll
     for (int t = 0; t < kOwn; ++t) {
         const float4 z = z4[m0 + 16 * t + j];
         const float zx = z.x - o.x, zy = z.y - o.y, zz = z.z - o.z;
-        const float zsq = fmaf(zz, zz, fmaf(zy, zy, zx * zx));
-        const float m2 = -2.f * kk;
-        bz[t] = sel4(k, m2 * zx, m2 * zy, m2 * zz, kk * zsq);
-        e[t] = 0.f;
-        acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bz[t] = owned_operand(k, kk, zx, zy, zz, kk * fmaf(zz, zz, fmaf(zy, zy, zx * zx)));
+        p1[t] = ux[t] = uy[t] = uz[t] = e[t] = 0.f;
     }
     const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
     const int64_t nchunks = (n_total + kChunk - 1) / kChunk;
     const int64_t c1 = c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks;
-    float4 ra = tgt4[c0 * kChunk + threadIdx.x], rb = tgt4[c0 * kChunk + kBlock + threadIdx.x];
+    float4 ra = tgt4[c0 * kChunk + threadIdx.x];
     stage_point(stage[0], threadIdx.x, ra, o, kk);
-    stage_point(stage[0], kBlock + threadIdx.x, rb, o, kk);
     __syncthreads();
     for (int64_t c = c0; c < c1; ++c) {
         const float* __restrict__ buf = stage[(c - c0) & 1];
         const bool more = c + 1 < c1;
         if (more) {
             ra = tgt4[(c + 1) * kChunk + threadIdx.x];
-            rb = tgt4[(c + 1) * kChunk + kBlock + threadIdx.x];
         }
-        // software pipeline as in the column pass: the distance MFMA of the next pair runs under this pair's
-        // exponentials and contraction MFMAs
-        float a1 = buf[lane];
-        f32x4 cx = *reinterpret_cast<const f32x4*>(buf + 64 + 4 * k);
-        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bz[0], cx, 0, 0, 0);
+        bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
+        f32x4 cx = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
+        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[0], cx, 0, 0, 0);
         for (int t = 0; t < kChunkTiles; ++t) {
-            const float* __restrict__ tb = buf + t * kPlane;
-            const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kPlane;
-            const float a1n = tn[lane];
-            const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 64 + 4 * k);
-            const f32x4 xs = *reinterpret_cast<const f32x4*>(tb + 80 + 4 * k);
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(tb + 16 * cc + 4 * k);  // plane cc: x', y', z' or ones
+            const float* __restrict__ tb = buf + t * kTileFloats;
+            const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
+            const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+            const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+            const f32x4 xx = *reinterpret_cast<const f32x4*>(tb + 272 + 4 * k), xy = *reinterpret_cast<const f32x4*>(tb + 288 + 4 * k),
+                        xz = *reinterpret_cast<const f32x4*>(tb + 304 + 4 * k), xs = *reinterpret_cast<const f32x4*>(tb + 320 + 4 * k);
 #pragma unroll
             for (int u = 0; u < kOwn; ++u) {
-                const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bz[u + 1], cx, 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_16x16x4f32(a1n, bz[0], cxn, 0, 0, 0);
-                const float p0 = exp2r(d[0]), p1 = exp2r(d[1]), p2 = exp2r(d[2]), p3 = exp2r(d[3]);
-                acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(p0, b2[0], acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(p1, b2[1], acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(p2, b2[2], acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(p3, b2[3], acc[u], 0, 0, 0);
-                e[u] = fmaf(p3, xs[3], fmaf(p2, xs[2], fmaf(p1, xs[1], fmaf(p0, xs[0], e[u]))));
+                const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[u + 1], cx, 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bz[0], cxn, 0, 0, 0);
+                const float q0 = exp2r(d[0]), q1 = exp2r(d[1]), q2 = exp2r(d[2]), q3 = exp2r(d[3]);
+                p1[u] += (q0 + q1) + (q2 + q3);
+                ux[u] = fmaf(q3, xx[3], fmaf(q2, xx[2], fmaf(q1, xx[1], fmaf(q0, xx[0], ux[u]))));
+                uy[u] = fmaf(q3, xy[3], fmaf(q2, xy[2], fmaf(q1, xy[1], fmaf(q0, xy[0], uy[u]))));
+                uz[u] = fmaf(q3, xz[3], fmaf(q2, xz[2], fmaf(q1, xz[1], fmaf(q0, xz[0], uz[u]))));
+                e[u] = fmaf(q3, xs[3], fmaf(q2, xs[2], fmaf(q1, xs[1], fmaf(q0, xs[0], e[u]))));
                 d = dn;
             }
             a1 = a1n;
@@ -237,22 +266,19 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
         if (more) {
             float* __restrict__ nb = stage[(c + 1 - c0) & 1];
             stage_point(nb, threadIdx.x, ra, o, kk);
-            stage_point(nb, kBlock + threadIdx.x, rb, o, kk);
         }
         __syncthreads();
     }
     float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
 #pragma unroll
     for (int u = 0; u < kOwn; ++u) {
-        f32x4 a = acc[u];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = xor_sum(a[i]);
-        const float et = xor_sum(e[u]);
+        const float a0 = xor_sum(p1[u]), a1s = xor_sum(ux[u]), a2 = xor_sum(uy[u]), a3 = xor_sum(uz[u]), a4 = xor_sum(e[u]);
         if (lane < 16) {
-            const int comp = cc == 3 ? 0 : 1 + cc;  // column 3 of [x' 1] is the row sum p1
-#pragma unroll
-            for (int i = 0; i < 4; ++i) out[(int64_t)comp * mcap + 16 * u + 4 * (lane >> 2) + i] = a[i];
-            out[4 * mcap + 16 * u + lane] = et;
+            out[16 * u + lane] = a0;
+            out[mcap + 16 * u + lane] = a1s;
+            out[2 * mcap + 16 * u + lane] = a2;
+            out[3 * mcap + 16 * u + lane] = a3;
+            out[4 * mcap + 16 * u + lane] = a4;
         }
     }
     if (blockIdx.y == 0 && threadIdx.x == 0) rorig[blockIdx.x] = o;

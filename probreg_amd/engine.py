@@ -65,9 +65,9 @@ class CpdPlan(object):
     def set_options(self, sort_source=True, sort_target=True, cull=True):
         check(lib.prg_cpd_set_options(self._h, int(sort_source), int(sort_target), int(cull)))
 
-    def set_dense_engine(self, mode=0, bound=0.0):
-        """0: vector-pipe sweeps only (default), 1: matrix-core column pass in the dense regime, 2: both sweeps on the
-        matrix cores always (prg_cpd_set_dense_engine)."""
+    def set_dense_engine(self, mode=1, bound=0.0):
+        """0: vector-pipe sweeps only, 1: matrix-core sweeps in the dense regime (default), 2: both sweeps on the matrix
+        cores always (prg_cpd_set_dense_engine)."""
         check(lib.prg_cpd_set_dense_engine(self._h, int(mode), float(bound)))
 
     def last_estep_engine(self):

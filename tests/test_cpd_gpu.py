@@ -514,6 +514,7 @@ def test_culled_sweeps_equal_dense_sweeps(sigma2, w):
     for opts in (dict(sort_source=True, sort_target=True, cull=True), dict(sort_source=False, sort_target=False, cull=False)):
         plan = CpdPlan()
         plan.set_options(**opts)
+        plan.set_dense_engine(0)             # this test is about the CULLED VECTOR sweeps (tests/test_mfma_gpu.py has the others)
         plan.set_source(s32)
         plan.set_target(t32)
         plan.set_params(params)
@@ -545,6 +546,7 @@ def test_culled_registration_tracks_dense_registration():
     for cull in (True, False):
         plan = CpdPlan()
         plan.set_options(sort_source=cull, sort_target=cull, cull=cull)
+        plan.set_dense_engine(0)             # culled vs dense VECTOR sweeps
         plan.set_source(s32)
         plan.set_target(t32)
         plan.init_sums()
