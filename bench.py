@@ -39,9 +39,11 @@ HBM_PEAK_GBS = 8000.0          # HBM3E 8 TB/s
 VALU_F32_PEAK_TFLOPS = 157.3   # 256 CU x 4 SIMD x 32 lanes x 2 flop (FMA) x 2.4 GHz
 F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64
 
-# Flop per EVALUATED source-target pair, counted from the kernels' instruction mix (fma = 2, everything else = 1):
+# Flop per EVALUATED source-target pair, counted from the vector-pipe sweeps' instruction mix (fma = 2, else = 1):
 #   row pass   3 sub + 3 fma (d2) + 1 fma (exponent) + 1 exp + 1 add (p1) + 4 fma (u, e)            = 21
 #   col pass   3 sub + 3 fma (d2) + 1 min + 1 fma (exponent) + 1 exp + 1 add (sum)                  = 14
+# The same count is charged to the dense-regime iterations that take the exponent (8 of the 21 / 14 flop) from the bf16
+# matrix pipe instead (csrc/cpd_sweeps_mfma.hip): `frac` is useful pair-flops per second over the fp32 vector peak.
 FLOP_ROW, FLOP_COL = 21.0, 14.0
 
 WORKLOADS = {
@@ -239,7 +241,8 @@ def bench_cpd(workload, steps, warmup, tuning=""):
     out["late_it_s"] = 1.0 / t_late
     out["roofline"] = {
         "bound": "valu",
-        "kernel": "k_rowpass_cull (E-step sweep 2: P1, PX, sigma2 residual)",
+        "kernel": "row pass (E-step sweep 2: P1, PX, sigma2 residual): k_rowpass_mfma while sigma2 is large, "
+                  "k_rowpass_cull afterwards",
         "achieved": row_tf,
         "peak": VALU_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",

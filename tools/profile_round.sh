@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round profiles on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r2
+# rocprofv3 kernel traces of the default bench line and PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes;
+# never combined with system / runtime traces) for C1, C3 and C4; summaries land in gpurun_out/prof_<tag>/*.txt.
+tag=${1:-r2}
+export TMPDIR=/tmp
+out=gpurun_out/prof_$tag
+mkdir -p $out
+sum() { python tools/rocpd_summary.py "$@"; }
+db() { ls $1/*.db $1/*/*.db 2>/dev/null | head -1; }
+
+rocprofv3 --kernel-trace --stats -d $out/kt_default -o b -- python bench.py --steps 20 --warmup 5 > $out/bench_default_line.json 2> $out/kt_default.err
+sum $(db $out/kt_default) > $out/${tag}_bench_default_kernel_trace.txt
+
+c1="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads"
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --kernel-trace -d $out/c1_$name -o b -- $c1 > $out/c1_$name.log 2>&1
+done
+sum --pmc $(db $out/c1_FETCH_SIZE) $(db $out/c1_WRITE_SIZE) $(db $out/c1_SQ_INSTS_VALU) > $out/${tag}_bench_rigid100k_pmc.txt
+
+c4="python bench.py --workload filterreg_500k --steps 20 --warmup 3"
+rocprofv3 --kernel-trace --stats -d $out/c4_kt -o b -- $c4 > $out/c4_line.json 2> $out/c4_kt.err
+sum $(db $out/c4_kt) > $out/${tag}_filterreg_500k_kernel_trace.txt
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --kernel-trace -d $out/c4_$name -o b -- $c4 > $out/c4_$name.log 2>&1
+done
+sum --pmc $(db $out/c4_FETCH_SIZE) $(db $out/c4_WRITE_SIZE) $(db $out/c4_SQ_INSTS_VALU) > $out/${tag}_filterreg_500k_pmc.txt
+
+c3="python bench.py --workload nonrigid_50k --steps 1 --warmup 1"
+rocprofv3 --kernel-trace --stats -d $out/c3_kt -o b -- $c3 > $out/c3_line.json 2> $out/c3_kt.err
+sum $(db $out/c3_kt) > $out/${tag}_nonrigid_50k_kernel_trace.txt
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
+  name=$(echo $pass | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --kernel-trace -d $out/c3_$name -o b -- $c3 > $out/c3_$name.log 2>&1
+done
+sum --pmc $(db $out/c3_FETCH_SIZE) $(db $out/c3_WRITE_SIZE) $(db $out/c3_SQ_INSTS_VALU) > $out/${tag}_nonrigid_50k_pmc.txt
+ls -la $out/*.txt
+# keep the merged output small: the databases stay on the box
+rm -rf $out/kt_default $out/c1_* $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c4_SQ_INSTS_VALU $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE $out/c3_SQ_INSTS_VALU 2>/dev/null
