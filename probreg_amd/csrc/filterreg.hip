@@ -487,9 +487,13 @@ __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset
 // lattice is small (sigma large: a few hundred vertices shared by 2M point-vertex incidences) this removes
 // the same-address global atomic storm; when a chunk touches more distinct vertices than the table holds,
 // the overflow goes straight to global memory, where contention is low by then.
-constexpr int kSplatSlots = 2048;       // LDS table entries (key + up to 8 channels)
+// (512 points / 512 slots per workgroup: 18 KB of LDS, 8 workgroups per CU.  The first version used 2048 / 2048 = 72 KB:
+// 245 workgroups of one wave per SIMD each, every lane walking 32 incidences through dependent loads and returning LDS
+// atomics with nobody to hide the latency - 52 % of the wave cycles were waits, profiles/r2_filterreg_500k_pmc.txt)
+constexpr int kSplatBits = 8;
+constexpr int kSplatSlots = 1 << kSplatBits;  // LDS table entries (key + up to 8 channels)
 constexpr int kSplatMaxCh = 8;
-constexpr int kSplatPts = 2048;         // points per workgroup
+constexpr int kSplatPts = 256;                // points per workgroup
 __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ offset, const float* __restrict__ bary,
                                                       const float* __restrict__ in, int64_t first, int64_t n, int d1,
                                                       int ch, float* __restrict__ vals) {
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
             any |= p[k] != 0.f;
         }
         if (!any) continue;
-        unsigned h = ((unsigned)o * 2654435761u) >> 21;  // 11 bits
+        unsigned h = ((unsigned)o * 2654435761u) >> (32 - kSplatBits);
         int slot = -1;
         for (int probe = 0; probe < 16; ++probe) {
             int cur = skey[h];
