@@ -870,7 +870,7 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     h->D = dim;
     h->Mcap = cap;
     if (h->opt_sort_src) {
-        PRG_TRY(morton_permutation(h, source_hd, m, dim, &h->perm_src));
+        PRG_TRY(morton_permutation(h, source_hd, m, dim, &h->perm_src, &h->sext2));
     } else if (h->perm_src) {
         (void)hipFree(h->perm_src);
         h->perm_src = nullptr;
@@ -1154,13 +1154,16 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         const double mo = st[slot], cmax = st[4 + (slot ^ 1)], r = sqrt(cmax);
         const double width = r >= mo ? 4.0 * r * mo : (r + mo) * (r + mo);  // of the bracket of a column minimum
         const bool forced = h->dense_engine >= 2, ok = sigma2 > 0.0 && std::isfinite(sigma2);
-        const bool dense = ok && (forced || nk * h->text2 < h->dense_bound);
+        // size of the problem: the (replicated) source's bounding box or the local target's, whichever is larger - a
+        // target shard is a small patch, and every rank should leave the dense regime at the same sigma2
+        const double ext2 = std::max(h->sext2, h->text2);
+        const bool dense = ok && (forced || nk * ext2 < h->dense_bound);
         if (!dense) h->mfma_off = true;
         // the column pass needs the previous E-step's column minima for its exponent offsets; the row pass does not.
         // The culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
         // (profiles/r2_mfma_vs_valu_estep_100k.log): it leaves at 0.45 of the bound.
         use_mfma = dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0;
-        row_mfma = dense && (forced || nk * h->text2 < 0.45 * h->dense_bound);
+        row_mfma = dense && (forced || nk * ext2 < 0.45 * h->dense_bound);
     }
     h->last_estep_mfma = use_mfma;
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));

@@ -54,10 +54,10 @@ struct prg_cpd {
     float4* rorig = nullptr;    // [Mcap/512] origin of each 512-row block of the last matrix-core row pass
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
                                 // 2: both sweeps on the matrix cores, always (tests)
-    double dense_bound = 1100.0;  // dense regime = |kk| * (target bounding-box diagonal)^2 below this (C1: sigma2 > ~6e-3)
+    double dense_bound = 1100.0;  // dense regime = |kk| * (cloud bounding-box diagonal)^2 below this (C1: sigma2 > ~6e-3)
     bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
     bool last_estep_mfma = false;
-    double text2 = 0.0;         // squared diagonal of the local target's bounding box
+    double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     // measurement hook: evaluated (wave, group) blocks per workgroup of the last culled column / row pass
     // ([0, wg_cap) column pass, [wg_cap, 2 wg_cap) row pass); wg_col / wg_row = workgroups of the last launches,
     // dense_pairs_* = pairs covered by the last NON-culled launches (0 when the culled kernels ran)
