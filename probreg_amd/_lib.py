@@ -30,6 +30,14 @@ class ProbregHipError(RuntimeError):
 
 
 def _load():
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so) and the dynamic loader keeps whichever copy
+    # of that soname is loaded FIRST.  If ours came first (the system's /opt/rocm runtime), torch.cuda would later find
+    # "no GPUs" in the same process - and with it RCCL; loading torch first makes both sides share torch's runtime,
+    # whatever the import order of the caller.  torch stays optional.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
     if not os.path.isfile(LIB_PATH):
         raise ImportError(
             "probreg_amd: %s not found. Build it with `python __graft_entry__.py build` "
