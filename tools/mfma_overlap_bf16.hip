@@ -36,6 +36,29 @@ __global__ __launch_bounds__(256) void k(float* out, float a, int mode) {
                 valu_block(d, tm[u], s[u]);
                 d[u & 3] = tm[u] * 1e-30f - s[u] * 1e-30f - 1.f;
             }
+    } else if (mode == 3) {  // half the waves only MFMAs, the other half only vector blocks
+        if (((threadIdx.x >> 6) & 1) == 0) {
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, b[u], acc[u], 0, 0, 0);
+        } else {
+            f4 d = {(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    valu_block(d, tm[u], s[u]);
+                    d[u & 3] = tm[u] * 1e-30f - s[u] * 1e-30f - 1.f;
+                }
+        }
+    } else if (mode == 4) {  // phases: U MFMAs back to back, then the U vector blocks (waves drift out of phase)
+        for (int it = 0; it < ITER; ++it) {
+            f4 d[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) d[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, b[u], c, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) valu_block(d[u], tm[u], s[u]);
+            x[0] = (__bf16)(s[0] * 1e-30f);
+        }
     } else {
         f4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, b[0], c, 0, 0, 0);
         for (int it = 0; it < ITER; ++it)
@@ -55,11 +78,12 @@ int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     float* out;
-    const char* names[3] = {"bf16 mfma 16x16x32 only", "valu only", "both, every wave (pipelined)"};
-    for (int wpsimd = 1; wpsimd <= 4; wpsimd *= 2) {
+    const char* names[5] = {"bf16 mfma 16x16x32 only", "valu only", "both, every wave (pipelined)",
+                            "both, split over waves (half each)", "both, phases of 8 MFMAs then 8 vector blocks"};
+    for (int wpsimd = 2; wpsimd <= 8; wpsimd *= 2) {
         const int blocks = prop.multiProcessorCount * wpsimd;
         hipMalloc(&out, (size_t)blocks * 256 * 4);
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 5; ++mode) {
             hipEvent_t e0, e1;
             hipEventCreate(&e0); hipEventCreate(&e1);
             k<<<blocks, 256>>>(out, 1.0001f, mode);
@@ -71,8 +95,8 @@ int main() {
             float ms;
             hipEventElapsedTime(&ms, e0, e1);
             ms /= 5;
-            printf("%d waves/SIMD  %-34s %.3f ms  %.1f cycles per block per SIMD at 2.4 GHz\n", wpsimd, names[mode], ms,
-                   ms * 1e-3 * 2.4e9 / ((double)ITER * U * wpsimd));
+            printf("%d waves/SIMD  %-46s %.3f ms  %.1f cycles per block per SIMD at 2.4 GHz\n", wpsimd, names[mode], ms,
+                   ms * 1e-3 * 2.4e9 / ((double)ITER * U * wpsimd * (mode == 3 ? 0.5 : 1.0)));
         }
         hipFree(out);
     }
