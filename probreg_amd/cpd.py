@@ -334,19 +334,26 @@ class NonRigidCPD(CoherentPointDrift):
             self._build()
 
     def _centres(self, source, target_full):
-        # G is built from the float32 source exactly as the reference's pybind cast sees it
-        # (cc/math_utils.cc:17-19), so the non-rigid path does not re-centre the clouds.
-        z = np.zeros(source.shape[1])
-        return z, z
+        # one common origin for both clouds (G W is a displacement field over the source's own frame)
+        return self._origin, self._origin
 
     def _build(self):
         self._plan = CpdPlan(self._device)
         # G, W and the per-point all-reduce block are indexed by the caller's source order
         self._plan.set_options(sort_source=False, sort_target=True, cull=False)
-        self._plan.set_source(self._source)
+        # G is built from the float32 source exactly as the reference's pybind cast sees it (cc/math_utils.cc:17-19),
+        # so clouds near the origin are uploaded as they are.  A cloud FAR from the origin (coordinates many times its
+        # own extent, e.g. examples/face-x.txt with z ~ 1277) would lose its fine structure in that cast - in the
+        # E-step's float32 differences as well as in G - so it is shifted by its fp64 mean first: differences, G and the
+        # displacement field are translation invariant, and the reference's own float32 G is no yardstick there.
+        c = self._source.mean(axis=0)
+        ext = float(np.max(self._source.max(axis=0) - self._source.min(axis=0)))
+        self._origin = c if float(np.max(np.abs(c))) > 8.0 * max(ext, 1e-300) else np.zeros(self._source.shape[1])
+        self._plan.set_source(self._source - self._origin)
         self._source_uploaded = True
         self._plan.build_g(self._beta)
-        self._tf_obj = tf.NonRigidTransformation(None, self._source, self._beta, _plan=self._plan)
+        self._tf_obj = tf.NonRigidTransformation(None, self._source, self._beta, _plan=self._plan,
+                                                 _plan_points=self._source - self._origin)
 
     def set_source(self, source):
         self._source = _as_points(source)
@@ -405,7 +412,8 @@ class NonRigidCPD(CoherentPointDrift):
         target = _as_points(target)
         pt1, p1, px, _n_p = estep_res
         plan = self._plan
-        plan.set_target(target, n_global=target.shape[0])
+        plan.set_target(target - self._origin, n_global=target.shape[0])
+        px = np.asarray(px, dtype=np.float64) - np.outer(p1, self._origin)  # P X in the plan's frame
         self._upload_priors(target)
         plan.moments_from_estep(pt1, p1, px)
         p = plan.get_params()
@@ -453,7 +461,8 @@ class ConstrainedNonRigidCPD(NonRigidCPD):
             pairs = np.unique(np.stack([np.asarray(self.idx_source), np.asarray(self.idx_target)], axis=1), axis=0)
             np.add.at(self.p1_tilde, pairs[:, 0], 1.0)
             np.add.at(self.px_tilde, pairs[:, 0], target[pairs[:, 1]])
-        self._plan.set_priors(self.p1_tilde, self.px_tilde, self.alpha)
+        # (the plan works in the shifted frame of NonRigidCPD._build)
+        self._plan.set_priors(self.p1_tilde, self.px_tilde - np.outer(self.p1_tilde, self._origin), self.alpha)
 
     def _initialize(self, target):
         res = super(ConstrainedNonRigidCPD, self)._initialize(target)

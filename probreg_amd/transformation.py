@@ -81,11 +81,13 @@ class NonRigidTransformation(Transformation):
     of ``NonRigidCPD`` the matrix lives on the GPU; ``.g`` downloads it on first access (M*M*4 bytes).
     """
 
-    def __init__(self, w, points, beta=2.0, xp=np, _plan=None):
+    def __init__(self, w, points, beta=2.0, xp=np, _plan=None, _plan_points=None):
         super(NonRigidTransformation, self).__init__(xp)
         self._points = np.asarray(points)
         self._beta = beta
         self._plan = _plan
+        # the control points as the plan holds them (NonRigidCPD shifts far-from-origin clouds before the float32 upload)
+        self._plan_points = self._points if _plan_points is None else np.asarray(_plan_points)
         self._g = None
         self.w = w
 
@@ -105,6 +107,6 @@ class NonRigidTransformation(Transformation):
         if self._plan is not None:
             # G W on the GPU (fp64 accumulation over the float32 G), never through a host copy of G
             self._plan.set_w(np.asarray(self.w, dtype=np.float64))
-            disp = self._plan.nonrigid_apply() - self._points.astype(np.float32).astype(np.float64)
+            disp = self._plan.nonrigid_apply() - self._plan_points.astype(np.float32).astype(np.float64)
             return np.asarray(points) + disp
         return points + np.dot(self.g, self.w)

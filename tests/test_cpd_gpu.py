@@ -609,3 +609,29 @@ def test_single_rank_process_group_exercises_the_collective_path():
         assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
     finally:
         tdist.destroy_process_group()
+
+
+def test_far_from_origin_nonrigid_clouds():
+    """Non-rigid CPD on clouds with a large common offset (advisor, round 1): the float32 upload happens in a frame
+    shifted by the source's fp64 mean, so the E-step's differences and G keep their structure.  The problem is
+    translation invariant, so the yardstick is the oracle on the SAME clouds without the offset (the reference's own
+    float32 G of the offset coordinates has lost the fine structure and is no reference there)."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(1300, m=1100, seed=31)
+    off = np.array([1277.0, -350.0, 80.0])
+    p, s2, q, _ = co.registration("nonrigid", src, tgt, maxiter=4, tol=-1.0, closed_form_init=True)
+    want = co.transform("nonrigid", p, src, co.rbf_kernel(src, src, 2.0)) + off
+    res = cpd.registration_cpd(src + off, tgt + off, "nonrigid", maxiter=4, tol=-1.0)
+    assert abs(res.sigma2 - s2) <= 1e-4 * s2      # the shifted float32 coordinates are not bit-identical to the unshifted ones
+    got = res.transformation.transform(src + off)
+    assert np.max(np.abs(got - want)) < 2e-4 * np.max(np.abs(want - want.mean(0)))
+    # public maximization_step in the same frame
+    reg = cpd.NonRigidCPD(src + off)
+    s2_0 = co.squared_kernel_sum_closed_form(src, tgt)
+    es = reg.expectation_step(src + off, tgt + off, s2_0, 0.0)
+    r1 = reg.maximization_step(tgt + off, es, s2_0)
+    eo = co.expectation_step(src, tgt, s2_0, 0.0)
+    po, s2o, _ = co.mstep_nonrigid(src, tgt, eo, s2_0, co.rbf_kernel(src, src, 2.0), 2.0)
+    assert abs(r1.sigma2 - s2o) <= 1e-4 * s2o
