@@ -190,7 +190,7 @@ class CombinedBCPD(BayesianCoherentPointDrift):
         plan = self._ensure_plan()
         self._cx = target.mean(axis=0)
         plan.set_target(target - self._cx)
-        plan.bcpd_build_g(1.0)  # also resets v_hat to 0 for a fresh registration
+        plan.set_w(np.zeros((m, dim)))  # v_hat = 0 for a fresh registration (G and the solve workspace stay as built)
         sigma2 = self.gamma * mu.squared_kernel_sum(self._source, target)
         return MstepResult(self._tf_type(np.identity(dim), np.zeros(dim)), None, np.ones(m), 1.0 / m, sigma2)
 
