@@ -703,9 +703,10 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount, (void*)h->rorig})
+                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount, (void*)h->rorig, (void*)h->zchunk, (void*)h->tchunk})
         if (q) (void)hipFree(q);
     h->rorig = nullptr;
+    h->zchunk = h->tchunk = nullptr;
     h->wgcount = nullptr;
     h->wg_cap = 0;
     h->perm_src = h->perm_tgt = nullptr;
@@ -865,6 +866,7 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
             PRG_HIP(hipMemsetAsync(h->motion, 0, 8 * sizeof(unsigned), h->stream));
         }
         PRG_TRY(ensure_exact(&h->rorig, (size_t)(cap / prg::kMfmaWgPoints) + 4));
+        PRG_TRY(ensure_exact(&h->zchunk, (size_t)(cap / prg::kSuper) * 8));
     }
     h->M = m;
     h->D = dim;
@@ -943,6 +945,7 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     }
     if (cap != h->Ncap || !h->tmeta) {
         PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
+        PRG_TRY(ensure_exact(&h->tchunk, (size_t)(cap / prg::kSuper) * 8));
         PRG_TRY(ensure_exact(&h->colmin, (size_t)cap + (size_t)cap / prg::kGroup));  // + per-group maxima
         PRG_HIP(hipMemsetAsync(h->colmin, 0, ((size_t)cap + (size_t)cap / prg::kGroup) * sizeof(float), h->stream));
     }
@@ -1116,7 +1119,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)std::max(PB, PBm) * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
     if (use_cull) {  // per-workgroup counters of evaluated (wave, group) blocks (prg_cpd_pair_counts)
-        const int64_t need = std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->M, 128) * PB);
+        const int64_t need = std::max<int64_t>(
+            std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->M, 128) * PB),
+            std::max<int64_t>(prg::ceil_div(h->N, prg::kMfmaWgPoints) * PAm, prg::ceil_div(h->M, prg::kMfmaWgPoints) * PBm));
         if (need > h->wg_cap) {
             if (h->wgcount) {
                 PRG_HIP(hipStreamSynchronize(h->stream));
@@ -1161,11 +1166,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         if (!dense) h->mfma_off = true;
         // the column pass needs the previous E-step's column minima for its exponent offsets; the row pass does not.
         // The culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
-        // (profiles/r2_mfma_vs_valu_estep_100k.log): it leaves at 0.45 of the bound.
+        // (profiles/r2_mfma_cull_vs_valu_100k.log): it leaves at 1/8 of the bound.
         use_mfma = dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0;
-        row_mfma = dense && (forced || nk * ext2 < 0.45 * h->dense_bound);
+        row_mfma = dense && (forced || nk * ext2 < 0.125 * h->dense_bound);
     }
     h->last_estep_mfma = use_mfma;
+    h->wg_col_pairs = h->wg_row_pairs = 128.0 * prg::kGroup;  // a (wave, group) block of the culled vector-pipe sweeps
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_mfma)
         prg::launch_colpass_mfma(h, mfma_seg);
@@ -1182,7 +1188,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                       use_cull ? h->tmeta : nullptr, use_mfma ? 1 : 0, h->motion, slot);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
-        prg::launch_rowpass_mfma(h, mfma_seg);
+        prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap));
     else if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);
     else if (rb < 0)
@@ -1193,8 +1199,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
     k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, row_mfma ? PBm : PB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart,
-                                                  use_cull && !row_mfma ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)PB * 5 * h->Mcap)
-                                                                        : nullptr,
+                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)(row_mfma ? PBm : PB) * 5 * h->Mcap)
+                                                           : nullptr,
                                                   row_mfma ? h->rorig : nullptr);
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
@@ -1238,16 +1244,15 @@ int prg_cpd_pair_counts(prg_cpd* h, double* col_pairs, double* row_pairs) {
         std::vector<unsigned> host((size_t)h->wg_cap * 2);
         PRG_HIP(hipMemcpyAsync(host.data(), h->wgcount, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         PRG_HIP(hipStreamSynchronize(h->stream));
-        const double block_pairs = 128.0 * prg::kGroup;  // a (wave, group) block: 128 lane points x 32 streamed points
         if (h->wg_col > 0) {
             double s = 0.0;
             for (int64_t i = 0; i < h->wg_col; ++i) s += host[(size_t)i];
-            *col_pairs = s * block_pairs;
+            *col_pairs = s * h->wg_col_pairs;
         }
         if (h->wg_row > 0) {
             double s = 0.0;
             for (int64_t i = 0; i < h->wg_row; ++i) s += host[(size_t)(h->wg_cap + i)];
-            *row_pairs = s * block_pairs;
+            *row_pairs = s * h->wg_row_pairs;
         }
     }
     return PRG_OK;

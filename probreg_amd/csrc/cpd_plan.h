@@ -52,9 +52,11 @@ struct prg_cpd {
     bool have_colmin = false;
     // matrix-core (dense regime) sweeps
     float4* rorig = nullptr;    // [Mcap/512] origin of each 512-row block of the last matrix-core row pass
+    float* zchunk = nullptr;    // [Mcap/256][8] box of every 256-point chunk of the transformed source (per E-step)
+    float* tchunk = nullptr;    // [Ncap/256][8] box + largest b_n of every 256-point chunk of the target (per E-step)
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
                                 // 2: both sweeps on the matrix cores, always (tests)
-    double dense_bound = 1100.0;  // dense regime = |kk| * (cloud bounding-box diagonal)^2 below this (C1: sigma2 > ~6e-3)
+    double dense_bound = 4000.0;  // matrix-core column pass while |kk| * (cloud bounding-box diagonal)^2 is below this (C1: sigma2 > ~1.5e-3)
     bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
     bool last_estep_mfma = false;
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
@@ -63,6 +65,7 @@ struct prg_cpd {
     // dense_pairs_* = pairs covered by the last NON-culled launches (0 when the culled kernels ran)
     unsigned* wgcount = nullptr;
     int64_t wg_cap = 0, wg_col = 0, wg_row = 0;
+    double wg_col_pairs = 128.0 * 32.0, wg_row_pairs = 128.0 * 32.0;  // pairs one counted block stands for
     double dense_pairs_col = 0.0, dense_pairs_row = 0.0;
     uint64_t estep_count = 0;   // parity selects the motion slot of the current E-step
 

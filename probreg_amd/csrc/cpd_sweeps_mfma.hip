@@ -63,6 +63,39 @@ __device__ __forceinline__ float xor_max(float v) {
     return v;
 }
 
+// bounding boxes: one per group of 32 points (zmeta / tmeta of the culled vector sweeps) and one per chunk of 256 points
+struct alignas(32) BoxMeta { float lo[3]; float hi[3]; float aux; float pad; };
+
+__device__ __forceinline__ float box_gap2(const float (&alo)[3], const float (&ahi)[3], const BoxMeta& g) {
+    float d2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float gap = fmaxf(fmaxf(alo[k] - g.hi[k], g.lo[k] - ahi[k]), 0.f);
+        d2 = fmaf(gap, gap, d2);
+    }
+    return d2;
+}
+
+// Box of the 512 points a workgroup owns = union of its 16 group boxes (groups that hold pads are left out: pads sit
+// 1e18 away), and its centre as the workgroup's origin.  Every wave computes the same numbers.
+__device__ __forceinline__ bool wg_box(const BoxMeta* __restrict__ gmeta, int64_t first_point, int64_t n_points, int lane,
+                                       float (&lo)[3], float (&hi)[3]) {
+    const int64_t g = first_point / 32 + (lane & 15);
+    const bool valid = (g + 1) * 32 <= n_points;
+    const BoxMeta m = gmeta[g];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = valid ? m.lo[k] : INFINITY;
+        hi[k] = valid ? m.hi[k] : -INFINITY;
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], sh, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], sh, 64));
+        }
+    }
+    return hi[0] >= lo[0];
+}
+
 // a = h + m + l with three bf16 pieces: 24 significant bits, every piece product exact in the f32 accumulator
 struct Split3 { __bf16 h, m, l; };
 __device__ __forceinline__ Split3 split3(float a) {
@@ -121,17 +154,40 @@ __device__ __forceinline__ bf16x8 owned_operand(int k, float kk, float dx, float
 // grid = (ceil(N / 512), S); plane blockIdx.y receives (min d^2 over the segment, sum of exp2(kk d^2 + L_n)) with
 // L_n = prg::col_seed_offset - the same for every segment of a column.
 __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
+                                                         const BoxMeta* __restrict__ tmeta,
+                                                         const BoxMeta* __restrict__ zchunk,
                                                          const float* __restrict__ colmin_prev,
+                                                         const float* __restrict__ colmin_g,
                                                          const unsigned* __restrict__ motion, int chunks_per_seg,
-                                                         int64_t m_total, const double* __restrict__ params,
-                                                         float2* __restrict__ colpart, int64_t ncap) {
+                                                         int64_t m_total, int64_t n_total,
+                                                         const double* __restrict__ params,
+                                                         float2* __restrict__ colpart, int64_t ncap,
+                                                         unsigned* __restrict__ wgcount) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n0wg = (int64_t)blockIdx.x * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const float mo = __uint_as_float(*motion);
-    float4 o = tgt4[n0wg];  // the workgroup's origin: a real point of its patch
-    o.w = 0.f;
+    // the workgroup's patch: box (for the cull test) and origin (its centre).  A workgroup that holds pads has no usable
+    // box: it evaluates everything and takes its first point as origin.
+    float lo[3], hi[3];
+    float4 o;
+    float thr = INFINITY;  // skip a chunk when its box is farther than thr (squared) from the patch
+    if (n0wg + kWgPoints <= n_total && wg_box(tmeta, n0wg, n_total, lane, lo, hi)) {
+        o = make_float4(0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), 0.f);
+        // as in k_colpass_cull: (sqrt(largest column minimum of the previous E-step) + source motion)^2 bounds this
+        // E-step's minima from above; a chunk beyond that by 127 / |kk| adds < 2^-127 of any column's largest term
+        float cmax = colmin_g[n0wg / 32 + (lane & 15)];
+#pragma unroll
+        for (int sh = 1; sh < 16; sh <<= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, sh, 64));
+        const float r = sqrtf(cmax) + mo;
+        thr = r * r * 1.00001f + (-127.0f) / kk;
+    } else {
+        o = tgt4[n0wg];
+        o.w = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { lo[q] = -INFINITY; hi[q] = INFINITY; }
+    }
     const int k = lane >> 4, j = lane & 15;
     bf16x8 bx[kOwn];
     float s[kOwn], tm[kOwn], off[kOwn];
@@ -147,45 +203,54 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     }
     const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
     const int64_t nchunks = (m_total + kChunk - 1) / kChunk;
-    const int64_t c1 = c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks;
-    float4 ra = z4[c0 * kChunk + threadIdx.x];
-    ra.w = 0.f;  // (weighted sources do not take this path)
-    stage_point(stage[0], threadIdx.x, ra, o, kk);
-    __syncthreads();
-    for (int64_t c = c0; c < c1; ++c) {
-        const float* __restrict__ buf = stage[(c - c0) & 1];
-        const bool more = c + 1 < c1;
-        if (more) {
-            ra = z4[(c + 1) * kChunk + threadIdx.x];
-            ra.w = 0.f;
-        }
-        // software pipeline: the MFMA of the NEXT (tile, column tile) pair is issued before the current pair's
-        // accumulator is exponentiated
-        bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
-        f32x4 cz = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
-        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[0], cz, 0, 0, 0);
-        for (int t = 0; t < kChunkTiles; ++t) {
-            const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
-            const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
-            const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
-#pragma unroll
-            for (int u = 0; u < kOwn; ++u) {
-                const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[u + 1], cz, 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bx[0], czn, 0, 0, 0);
-                tm[u] = fmaxf(fmaxf(tm[u], d[0]), d[1]);
-                tm[u] = fmaxf(fmaxf(tm[u], d[2]), d[3]);
-                s[u] += (exp2r(d[0]) + exp2r(d[1])) + (exp2r(d[2]) + exp2r(d[3]));
-                d = dn;
-            }
-            a1 = a1n;
-            cz = czn;
-        }
-        if (more) {
-            float* __restrict__ nb = stage[(c + 1 - c0) & 1];
-            stage_point(nb, threadIdx.x, ra, o, kk);
-        }
+    const int nc = (int)((c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks) - c0);  // <= 64
+    // which chunks of the segment are needed: one box test per lane, one ballot (identical in all four waves)
+    const BoxMeta cm = zchunk[c0 + (lane < nc ? lane : nc - 1)];
+    unsigned long long mask = __ballot(lane < nc && !(box_gap2(lo, hi, cm) > thr));
+    int evaluated = 0;
+    if (mask) {
+        int cur = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        float4 ra = z4[(c0 + cur) * kChunk + threadIdx.x];
+        ra.w = 0.f;  // (weighted sources do not take this path)
+        stage_point(stage[0], threadIdx.x, ra, o, kk);
         __syncthreads();
+        for (int bsel = 0;; bsel ^= 1) {
+            const float* __restrict__ buf = stage[bsel];
+            const int nxt = mask ? __builtin_ctzll(mask) : -1;
+            mask &= mask - 1;
+            if (nxt >= 0) {
+                ra = z4[(c0 + nxt) * kChunk + threadIdx.x];
+                ra.w = 0.f;
+            }
+            // software pipeline: the MFMA of the NEXT (tile, column tile) pair is issued before the current pair's
+            // accumulator is exponentiated
+            bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
+            f32x4 cz = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[0], cz, 0, 0, 0);
+            for (int t = 0; t < kChunkTiles; ++t) {
+                const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
+                const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+                const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+#pragma unroll
+                for (int u = 0; u < kOwn; ++u) {
+                    const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[u + 1], cz, 0, 0, 0)
+                                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bx[0], czn, 0, 0, 0);
+                    tm[u] = fmaxf(fmaxf(tm[u], d[0]), d[1]);
+                    tm[u] = fmaxf(fmaxf(tm[u], d[2]), d[3]);
+                    s[u] += (exp2r(d[0]) + exp2r(d[1])) + (exp2r(d[2]) + exp2r(d[3]));
+                    d = dn;
+                }
+                a1 = a1n;
+                cz = czn;
+            }
+            ++evaluated;
+            if (nxt >= 0) stage_point(stage[bsel ^ 1], threadIdx.x, ra, o, kk);
+            __syncthreads();
+            if (nxt < 0) break;
+        }
     }
+    if (threadIdx.x == 0) wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned)evaluated;
     float2* __restrict__ out = colpart + (int64_t)blockIdx.y * ncap + n0;
 #pragma unroll
     for (int u = 0; u < kOwn; ++u) {
@@ -207,15 +272,27 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
 // in rorig[row block of 512]): p1, u' = sum P (x - o), e' = sum P |x - o|^2 - k_row_moments' residual form with o as
 // the reference point.
 __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
-                                                         int chunks_per_seg, int64_t n_total,
+                                                         const BoxMeta* __restrict__ zmeta,
+                                                         const BoxMeta* __restrict__ tchunk, int chunks_per_seg,
+                                                         int64_t n_total, int64_t m_total,
                                                          const double* __restrict__ params, float* __restrict__ rowpart,
-                                                         int64_t mcap, float4* __restrict__ rorig) {
+                                                         int64_t mcap, float4* __restrict__ rorig,
+                                                         unsigned char* __restrict__ rowflag,
+                                                         unsigned* __restrict__ wgcount) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t m0wg = (int64_t)blockIdx.x * kWgPoints, m0 = m0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
-    float4 o = z4[m0wg];
-    o.w = 0.f;
+    float lo[3], hi[3];
+    float4 o;
+    if (m0wg + kWgPoints <= m_total && wg_box(zmeta, m0wg, m_total, lane, lo, hi)) {
+        o = make_float4(0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), 0.f);
+    } else {  // a workgroup that holds pads: no usable box, nothing is skipped
+        o = z4[m0wg];
+        o.w = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { lo[q] = -INFINITY; hi[q] = INFINITY; }
+    }
     const int k = lane >> 4, j = lane & 15;
     bf16x8 bz[kOwn];
     float p1[kOwn], ux[kOwn], uy[kOwn], uz[kOwn], e[kOwn];
@@ -228,60 +305,91 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     }
     const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
     const int64_t nchunks = (n_total + kChunk - 1) / kChunk;
-    const int64_t c1 = c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks;
-    float4 ra = tgt4[c0 * kChunk + threadIdx.x];
-    stage_point(stage[0], threadIdx.x, ra, o, kk);
-    __syncthreads();
-    for (int64_t c = c0; c < c1; ++c) {
-        const float* __restrict__ buf = stage[(c - c0) & 1];
-        const bool more = c + 1 < c1;
-        if (more) {
-            ra = tgt4[(c + 1) * kChunk + threadIdx.x];
-        }
-        bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
-        f32x4 cx = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
-        f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[0], cx, 0, 0, 0);
-        for (int t = 0; t < kChunkTiles; ++t) {
-            const float* __restrict__ tb = buf + t * kTileFloats;
-            const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
-            const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
-            const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
-            const f32x4 xx = *reinterpret_cast<const f32x4*>(tb + 272 + 4 * k), xy = *reinterpret_cast<const f32x4*>(tb + 288 + 4 * k),
-                        xz = *reinterpret_cast<const f32x4*>(tb + 304 + 4 * k), xs = *reinterpret_cast<const f32x4*>(tb + 320 + 4 * k);
-#pragma unroll
-            for (int u = 0; u < kOwn; ++u) {
-                const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[u + 1], cx, 0, 0, 0)
-                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bz[0], cxn, 0, 0, 0);
-                const float q0 = exp2r(d[0]), q1 = exp2r(d[1]), q2 = exp2r(d[2]), q3 = exp2r(d[3]);
-                p1[u] += (q0 + q1) + (q2 + q3);
-                ux[u] = fmaf(q3, xx[3], fmaf(q2, xx[2], fmaf(q1, xx[1], fmaf(q0, xx[0], ux[u]))));
-                uy[u] = fmaf(q3, xy[3], fmaf(q2, xy[2], fmaf(q1, xy[1], fmaf(q0, xy[0], uy[u]))));
-                uz[u] = fmaf(q3, xz[3], fmaf(q2, xz[2], fmaf(q1, xz[1], fmaf(q0, xz[0], uz[u]))));
-                e[u] = fmaf(q3, xs[3], fmaf(q2, xs[2], fmaf(q1, xs[1], fmaf(q0, xs[0], e[u]))));
-                d = dn;
-            }
-            a1 = a1n;
-            cx = cxn;
-        }
-        if (more) {
-            float* __restrict__ nb = stage[(c + 1 - c0) & 1];
-            stage_point(nb, threadIdx.x, ra, o, kk);
-        }
+    const int nc = (int)((c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks) - c0);  // <= 64
+    // a chunk is skipped when every P of the (patch, chunk) block is an exact zero: kk dist^2(boxes) + max b_n < -127
+    const BoxMeta cm = tchunk[c0 + (lane < nc ? lane : nc - 1)];
+    unsigned long long mask = __ballot(lane < nc && !(fmaf(box_gap2(lo, hi, cm), kk, cm.aux) < -127.0f));
+    const bool touched = mask != 0;
+    int evaluated = 0;
+    if (mask) {
+        int cur = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        float4 ra = tgt4[(c0 + cur) * kChunk + threadIdx.x];
+        stage_point(stage[0], threadIdx.x, ra, o, kk);
         __syncthreads();
-    }
-    float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
+        for (int bsel = 0;; bsel ^= 1) {
+            const float* __restrict__ buf = stage[bsel];
+            const int nxt = mask ? __builtin_ctzll(mask) : -1;
+            mask &= mask - 1;
+            if (nxt >= 0) ra = tgt4[(c0 + nxt) * kChunk + threadIdx.x];
+            bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
+            f32x4 cx = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
+            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[0], cx, 0, 0, 0);
+            for (int t = 0; t < kChunkTiles; ++t) {
+                const float* __restrict__ tb = buf + t * kTileFloats;
+                const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
+                const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+                const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+                const f32x4 xx = *reinterpret_cast<const f32x4*>(tb + 272 + 4 * k), xy = *reinterpret_cast<const f32x4*>(tb + 288 + 4 * k),
+                            xz = *reinterpret_cast<const f32x4*>(tb + 304 + 4 * k), xs = *reinterpret_cast<const f32x4*>(tb + 320 + 4 * k);
 #pragma unroll
-    for (int u = 0; u < kOwn; ++u) {
-        const float a0 = xor_sum(p1[u]), a1s = xor_sum(ux[u]), a2 = xor_sum(uy[u]), a3 = xor_sum(uz[u]), a4 = xor_sum(e[u]);
-        if (lane < 16) {
-            out[16 * u + lane] = a0;
-            out[mcap + 16 * u + lane] = a1s;
-            out[2 * mcap + 16 * u + lane] = a2;
-            out[3 * mcap + 16 * u + lane] = a3;
-            out[4 * mcap + 16 * u + lane] = a4;
+                for (int u = 0; u < kOwn; ++u) {
+                    const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[u + 1], cx, 0, 0, 0)
+                                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bz[0], cxn, 0, 0, 0);
+                    const float q0 = exp2r(d[0]), q1 = exp2r(d[1]), q2 = exp2r(d[2]), q3 = exp2r(d[3]);
+                    p1[u] += (q0 + q1) + (q2 + q3);
+                    ux[u] = fmaf(q3, xx[3], fmaf(q2, xx[2], fmaf(q1, xx[1], fmaf(q0, xx[0], ux[u]))));
+                    uy[u] = fmaf(q3, xy[3], fmaf(q2, xy[2], fmaf(q1, xy[1], fmaf(q0, xy[0], uy[u]))));
+                    uz[u] = fmaf(q3, xz[3], fmaf(q2, xz[2], fmaf(q1, xz[1], fmaf(q0, xz[0], uz[u]))));
+                    e[u] = fmaf(q3, xs[3], fmaf(q2, xs[2], fmaf(q1, xs[1], fmaf(q0, xs[0], e[u]))));
+                    d = dn;
+                }
+                a1 = a1n;
+                cx = cxn;
+            }
+            ++evaluated;
+            if (nxt >= 0) stage_point(stage[bsel ^ 1], threadIdx.x, ra, o, kk);
+            __syncthreads();
+            if (nxt < 0) break;
+        }
+    }
+    if (threadIdx.x == 0) wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned)evaluated;
+    // k_row_moments skips (128-row block, plane) partials that were never touched: neither written nor read
+    if (threadIdx.x < 4) rowflag[((int64_t)blockIdx.x * 4 + threadIdx.x) * 64 + blockIdx.y] = touched ? 1 : 0;
+    if (touched) {
+        float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
+#pragma unroll
+        for (int u = 0; u < kOwn; ++u) {
+            const float a0 = xor_sum(p1[u]), a1s = xor_sum(ux[u]), a2 = xor_sum(uy[u]), a3 = xor_sum(uz[u]), a4 = xor_sum(e[u]);
+            if (lane < 16) {
+                out[16 * u + lane] = a0;
+                out[mcap + 16 * u + lane] = a1s;
+                out[2 * mcap + 16 * u + lane] = a2;
+                out[3 * mcap + 16 * u + lane] = a3;
+                out[4 * mcap + 16 * u + lane] = a4;
+            }
         }
     }
     if (blockIdx.y == 0 && threadIdx.x == 0) rorig[blockIdx.x] = o;
+}
+
+// one box per chunk of 256 points = union of its 8 group boxes (+ the largest aux of the groups)
+__global__ __launch_bounds__(kBlock) void k_chunk_meta(const BoxMeta* __restrict__ gmeta, int64_t nchunk,
+                                                       BoxMeta* __restrict__ cmeta) {
+    const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (c >= nchunk) return;
+    BoxMeta o = gmeta[c * 8];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) {
+        const BoxMeta m = gmeta[c * 8 + g];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o.lo[k] = fminf(o.lo[k], m.lo[k]);
+            o.hi[k] = fmaxf(o.hi[k], m.hi[k]);
+        }
+        o.aux = fmaxf(o.aux, m.aux);
+    }
+    cmeta[c] = o;
 }
 
 }  // namespace
@@ -289,8 +397,9 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
 namespace prg {
 
 // Segments of whole chunks.  The chip holds 768 of these workgroups at a time (3 per CU: 43 KB of LDS, 131 / 160 VGPRs) and
-// all of them take the same time, so the grid runs in ceil(blocks * S / 768) rounds: S is chosen in [4, 32] to waste the
-// least of the last round (C1: 196 blocks x 19 segments = 4.85 rounds; the first version's 196 x 5 = 1.28 rounds lost 36 %).
+// all of them take the same time in the dense regime, so the grid runs in ceil(blocks * S / 768) rounds: S is chosen in
+// [4, 32] to waste the least of the last round (C1: 196 blocks x 19 segments = 4.85 rounds; the first version's 196 x 5 =
+// 1.28 rounds lost 36 %); a segment holds at most 64 chunks (one ballot of box tests).
 static int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S) {
     const int64_t chunks = ceil_div(streamed_points, kChunk);
     if (S <= 0) {
@@ -307,7 +416,8 @@ static int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, in
             }
         }
     }
-    return (int)ceil_div(chunks, std::min<int64_t>(S, chunks));
+    const int64_t cps = ceil_div(chunks, std::min<int64_t>(S, chunks));
+    return (int)std::min<int64_t>(cps, 64);
 }
 
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S) {
@@ -315,21 +425,35 @@ int mfma_planes(int64_t owned_points, int64_t streamed_points, int S) {
     return (int)ceil_div(ceil_div(streamed_points, kChunk), cps);
 }
 
+void launch_chunk_meta(prg_cpd* h, const float* gmeta, int64_t cap, float* cmeta) {
+    const int64_t nchunk = cap / kChunk;
+    k_chunk_meta<<<(unsigned)ceil_div(nchunk, kBlock), kBlock, 0, h->stream>>>(reinterpret_cast<const BoxMeta*>(gmeta), nchunk,
+                                                                             reinterpret_cast<BoxMeta*>(cmeta));
+}
+
 void launch_colpass_mfma(prg_cpd* h, int S) {
     const int cps = mfma_chunks_per_seg(h->N, h->M, S);
     dim3 grid((unsigned)ceil_div(h->N, kWgPoints), (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
-    k_colpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, h->colmin, h->motion + ((h->estep_count - 1) & 1), cps,
-                                                   h->M, h->params, h->colpart, h->Ncap);
-    h->wg_col = 0;
-    h->dense_pairs_col = (double)grid.x * kWgPoints * (double)ceil_div(h->M, kChunk) * kChunk;
+    launch_chunk_meta(h, h->zmeta, h->Mcap, h->zchunk);  // boxes of this E-step's transformed source
+    k_colpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
+                                                   reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
+                                                   h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
+                                                   h->colpart, h->Ncap, h->wgcount);
+    h->wg_col = (int64_t)grid.x * grid.y;
+    h->wg_col_pairs = (double)kWgPoints * kChunk;
+    h->dense_pairs_col = 0.0;
 }
 
-void launch_rowpass_mfma(prg_cpd* h, int S) {
+void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag) {
     const int cps = mfma_chunks_per_seg(h->M, h->N, S);
     dim3 grid((unsigned)ceil_div(h->M, kWgPoints), (unsigned)ceil_div(ceil_div(h->N, kChunk), cps));
-    k_rowpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, cps, h->N, h->params, h->rowpart, h->Mcap, h->rorig);
-    h->wg_row = 0;
-    h->dense_pairs_row = (double)grid.x * kWgPoints * (double)ceil_div(h->N, kChunk) * kChunk;
+    launch_chunk_meta(h, h->tmeta, h->Ncap, h->tchunk);  // target boxes with this E-step's b_n ranges (after k_colfinal)
+    k_rowpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const BoxMeta*>(h->zmeta),
+                                                   reinterpret_cast<const BoxMeta*>(h->tchunk), cps, h->N, h->M, h->params,
+                                                   h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap);
+    h->wg_row = (int64_t)grid.x * grid.y;
+    h->wg_row_pairs = (double)kWgPoints * kChunk;
+    h->dense_pairs_row = 0.0;
 }
 
 }  // namespace prg

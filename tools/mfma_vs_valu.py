@@ -28,13 +28,15 @@ for it in range(1, iters):
         plan.set_params(state)
         ms = plan.estep_timed(0.0)
         used = plan.last_estep_engine()
+        pc = plan.pair_counts()
         plan.mstep(_lib.PRG_TF_RIGID, True)
-        res[eng] = (ms, plan.get_params(), used)
+        res[eng] = (ms, plan.get_params(), used, pc)
     a, b = res[0][1], res[2][1]
     nk = 1.4426950408889634 / (2.0 * state[13])
     print("%3d  %.3e %8.1f | %.3f %.3f %.3f | %.3f %.3f %.3f (mfma %d) | %.2e %.2e %.2e" % (
         it, state[13], nk, res[0][0]["colpass"], res[0][0]["rowpass"], res[0][0]["total"], res[2][0]["colpass"],
         res[2][0]["rowpass"], res[2][0]["total"], res[2][2], abs(a[13] - b[13]) / a[13], np.max(np.abs(a[:9] - b[:9])),
-        np.max(np.abs(a[9:12] - b[9:12]))))
+        np.max(np.abs(a[9:12] - b[9:12]))), "| pairs/1e9 valu %.2f %.2f mfma %.2f %.2f" % (
+        res[0][3][0] / 1e9, res[0][3][1] / 1e9, res[2][3][0] / 1e9, res[2][3][1] / 1e9))
     plan.set_dense_engine(0)   # advance along the vector-pipe trajectory
     plan.set_params(a)
