@@ -165,11 +165,22 @@ int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p
 int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_row);
 
 /* ---- non-rigid CPD ------------------------------------------------------------------- */
-/* Build G_ij = exp(-|y_i-y_j|^2/(2*beta)) (float32, M x M) once per source.
+/* Build G_ij = exp(-|y_i-y_j|^2/(2*beta)) once per source.
  * Replaces: NonRigidTransformation.__init__ transformation.py:91-99 -> mu.rbf_kernel
- * math_utils.py:36-37 -> cc/math_utils.cc:17-19. */
+ * math_utils.py:36-37 -> cc/math_utils.cc:17-19.
+ * The plan does not store the M x M matrix when it does not have to: a Gaussian kernel matrix of a point cloud is
+ * numerically low rank, and the plan keeps its pivoted-Cholesky factor G = F F^T (fp64, M x r, columns evaluated on the
+ * fly; the factorisation stops when every entry of G - F F^T is below `tol`, default 1e-14).  Every later product with
+ * G and the M-step's solve then cost O(M r) / O(M r^2).  When the rank would exceed max_rank the plan
+ * falls back to the dense float32 matrix and the M x M fp64 Cholesky. */
 int prg_cpd_nonrigid_build_g(prg_cpd* h, double beta);
-/* Copy G (m*m float32, row-major) out - parity tests / `tf.g` attribute. */
+/* Solver of the next prg_cpd_nonrigid_build_g.  mode 1 (default): low-rank factor when the rank allows; mode 0: always
+ * the dense matrix.  max_rank: 0 = min(2048, M / 2); tol: 0 keeps the current value. */
+int prg_cpd_nonrigid_set_solver(prg_cpd* h, int mode, int max_rank, double tol);
+/* Rank of the factor the plan holds (0: it holds the dense matrix). */
+int prg_cpd_nonrigid_rank(prg_cpd* h, int* rank);
+/* Copy G (m*m float32, row-major) out - parity tests / `tf.g` attribute (evaluated on the spot when the plan holds only
+ * the factor). */
 int prg_cpd_nonrigid_get_g(prg_cpd* h, float* g_hd);
 /* Set / get W (m x dim float64).  W = 0 after build_g (cpd.py:281). */
 int prg_cpd_nonrigid_set_w(prg_cpd* h, const double* w_hd);

@@ -84,6 +84,8 @@ SIGNATURES = {
     "prg_cpd_moments_from_estep": [_vp, _vp, _vp, _vp],
     "prg_cpd_set_tuning": [_vp, _i, _i, _i, _i],
     "prg_cpd_nonrigid_build_g": [_vp, _d],
+    "prg_cpd_nonrigid_set_solver": [_vp, _i, _i, _d],
+    "prg_cpd_nonrigid_rank": [_vp, _c.POINTER(_i)],
     "prg_cpd_nonrigid_get_g": [_vp, _vp],
     "prg_cpd_nonrigid_set_w": [_vp, _vp],
     "prg_cpd_nonrigid_get_w": [_vp, _vp],

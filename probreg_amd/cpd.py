@@ -319,10 +319,12 @@ class NonRigidCPD(CoherentPointDrift):
 
     beta : width parameter of the Gaussian kernel ``G = exp(-d^2 / (2 beta))`` (note: beta, not beta^2)
     lmd  : weight of the smoothness regulariser
-    The M x M kernel is built on the GPU when the source is set and stays there.
+    The kernel is factorised on the GPU when the source is set (``G = F F^T`` by pivoted Cholesky, exact to 1e-14; the
+    M x M matrix itself is only kept when its rank is too high for that - see ``prg_cpd_nonrigid_build_g``).
     """
 
     _kind = _lib.PRG_TF_NONRIGID
+    _solver_mode = 1  # prg_cpd_nonrigid_set_solver: 1 = low-rank factor when the rank allows, 0 = always the dense matrix
 
     def __init__(self, source=None, beta=2.0, lmd=2.0, use_cuda=False, device=None):
         super(NonRigidCPD, self).__init__(source, use_cuda, device)
@@ -351,6 +353,7 @@ class NonRigidCPD(CoherentPointDrift):
         self._origin = c if float(np.max(np.abs(c))) > 8.0 * max(ext, 1e-300) else np.zeros(self._source.shape[1])
         self._plan.set_source(self._source - self._origin)
         self._source_uploaded = True
+        self._plan.set_nonrigid_solver(self._solver_mode)
         self._plan.build_g(self._beta)
         self._tf_obj = tf.NonRigidTransformation(None, self._source, self._beta, _plan=self._plan,
                                                  _plan_points=self._source - self._origin)

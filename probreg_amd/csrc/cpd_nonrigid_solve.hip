@@ -498,6 +498,106 @@ __global__ void k_nonrigid_finish(const double* __restrict__ part, int nblk, con
     }
 }
 
+// ---- low-rank M-step (G = F F^T, cpd_nonrigid.hip) ---------------------------------------------------------------
+// (D G + c I) W = B with G = F F^T:   W = (B - D F Z) / c,   (c I + F^T D F) Z = F^T B     (push-through identity again,
+// now with an r x r SPD system, r = rank of the factor: M r^2 flop instead of M^3 / 3 and no M x M matrix at all).
+// T = F^T D F on 64 x 64 tiles of the lower triangle; the sum over the points is split over workgroups, each of which
+// writes its partial tile; k_lr_gram_reduce adds them up in a fixed order (reproducible) and puts c on the diagonal.
+constexpr int GT = 64;    // tile edge
+constexpr int GS = 32;    // points per LDS slab
+constexpr int GLD = GT + 1;
+
+__global__ __launch_bounds__(kBlock) void k_lr_gram(const double* __restrict__ f, int64_t ld, int64_t m, int rank,
+                                                    const double* __restrict__ sp, int64_t chunk,
+                                                    double* __restrict__ part) {
+    __shared__ double as[GS][GLD], bs[GS][GLD];
+    // tile (ta >= tb) of the lower triangle from the linear index
+    int ta = 0, rem = blockIdx.x;
+    while (rem > ta) {
+        rem -= ta + 1;
+        ++ta;
+    }
+    const int tb = rem;
+    const int a0 = ta * GT, b0 = tb * GT;
+    const int64_t i_begin = (int64_t)blockIdx.y * chunk, i_end = i_begin + chunk < m ? i_begin + chunk : m;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // thread owns rows a0 + 4 ty .. + 3, columns b0 + 4 tx .. + 3
+    const int lk = threadIdx.x & 31, lr = threadIdx.x >> 5;  // staging: point lk of the slab, factor rows lr + 8 q
+    double acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += GS) {
+        const int64_t i = i0 + lk;
+        const bool in = i < i_end;
+        const double pw = in ? sp[i] * sp[i] : 0.0;  // D_ii (k_rhs left sqrt(D) in sp)
+#pragma unroll
+        for (int q = 0; q < GT / 8; ++q) {
+            const int r = lr + 8 * q;
+            as[lk][r] = (in && a0 + r < rank) ? f[(int64_t)(a0 + r) * ld + i] : 0.0;
+            bs[lk][r] = (in && b0 + r < rank) ? pw * f[(int64_t)(b0 + r) * ld + i] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < GS; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                av[r] = as[k][4 * ty + r];
+                bv[r] = bs[k][4 * tx + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+    double* __restrict__ out = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GT * GT);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) out[(4 * ty + r) * GT + 4 * tx + c] = acc[r][c];
+}
+
+// S[a][b] = c [a == b] + sum over the splits of T's tile entry (a, b) for a, b < rank; identity in the pad (rp x rp)
+__global__ __launch_bounds__(kBlock) void k_lr_gram_reduce(const double* __restrict__ part, int ntile, int nsplit,
+                                                           int rank, int64_t rp, const double* __restrict__ params,
+                                                           double lmd, double* __restrict__ s) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= rp * rp) return;
+    const int a = (int)(e / rp), b = (int)(e % rp);
+    double v;
+    if (a < rank && b < rank) {
+        const int hi = a > b ? a : b, lo = a > b ? b : a;  // lower triangle holds (hi, lo)
+        const int ta = hi / GT, tb = lo / GT;
+        const int tile = ta * (ta + 1) / 2 + tb;
+        // inside a diagonal tile both orders exist; off the diagonal only (row in ta, column in tb)
+        const int r = hi - ta * GT, c = lo - tb * GT;
+        const double* __restrict__ src = part + (int64_t)tile * (GT * GT) + r * GT + c;
+        v = 0.0;
+        for (int q = 0; q < nsplit; ++q) v += src[(int64_t)q * ntile * (GT * GT)];
+        if (a == b) v += lmd * params[13];
+    } else {
+        v = a == b ? 1.0 : 0.0;
+    }
+    s[e] = v;
+}
+
+// w = (b - D F z) / c
+__global__ __launch_bounds__(kBlock) void k_lr_form_w(const double* __restrict__ b3, const double* __restrict__ sp,
+                                                      const double* __restrict__ fz, int64_t m,
+                                                      const double* __restrict__ params, double lmd,
+                                                      double* __restrict__ w) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const double rc = 1.0 / (lmd * params[13]);
+    const double d = sp[i] * sp[i];
+    w[i * 3] = (b3[i * 3] - d * fz[i * 3]) * rc;
+    w[i * 3 + 1] = (b3[i * 3 + 1] - d * fz[i * 3 + 1]) * rc;
+    w[i * 3 + 2] = (b3[i * 3 + 2] - d * fz[i * 3 + 2]) * rc;
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); }
 
 // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128; the inverses
@@ -561,14 +661,112 @@ int cholesky_lookahead(prg_cpd* h, double* S, int64_t mp, double* linv, int* inf
     return PRG_OK;
 }
 
+// L L^T u = v in place for 3 right-hand sides (v [mp][3]) with the factor cholesky_lookahead left in S / linv
+int cholesky_solve3(prg_cpd* h, const double* S, int64_t mp, const double* linv, double* v) {
+    hipStream_t st = h->stream;
+    const int64_t nblk = mp / NB;
+    for (int64_t kb = 0; kb < nblk; ++kb) {  // L u' = v
+        const int64_t k0 = kb * NB;
+        k_diag_solve<0><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+        const int64_t rows = mp - k0 - NB;
+        if (rows > 0) k_fwd_update<<<(unsigned)prg::ceil_div(rows, 64), kBlock, 0, st>>>(S, mp, k0, mp, v);
+    }
+    for (int64_t kb = nblk - 1; kb >= 0; --kb) {  // L^T u = u'
+        const int64_t k0 = kb * NB;
+        k_diag_solve<1><<<1, 384, 0, st>>>(linv + (size_t)kb * NB * NB, v, k0);
+        if (k0 > 0) k_bwd_update<<<grid1(k0), kBlock, 0, st>>>(S, mp, k0, v);
+    }
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int ensure_solve_workspace(prg_cpd* h, size_t need) {
+    if (h->nr_solve_bytes >= need) return PRG_OK;
+    if (h->nr_solve) {
+        PRG_HIP(hipStreamSynchronize(h->stream));
+        (void)hipFree(h->nr_solve);
+    }
+    h->nr_solve = nullptr;
+    h->nr_solve_bytes = 0;
+    PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
+    h->nr_solve_bytes = need;
+    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                NB * LDP * (int)sizeof(double)));
+    return PRG_OK;
+}
+
+int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
+    const int64_t m = h->M, ld = h->f_ld;
+    const int rank = h->f_rank;
+    const int64_t rp = prg::round_up(rank, NB), nblk = rp / NB;
+    const int tiles1 = (int)prg::ceil_div(rank, GT), ntile = tiles1 * (tiles1 + 1) / 2;
+    // split the sum over the points so that the chip is full (~1024 workgroups), in whole slabs
+    int nsplit = (int)std::min<int64_t>(std::max(1, 1024 / ntile), prg::ceil_div(m, 4 * GS));
+    const int64_t chunk = prg::round_up(prg::ceil_div(m, nsplit), GS);
+    nsplit = (int)prg::ceil_div(m, chunk);
+    const size_t n_s = (size_t)rp * rp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)ld * 3,
+                 n_part = (size_t)nsplit * ntile * GT * GT;
+    const int tr_blk = (int)prg::ceil_div(m, kBlock);
+    PRG_TRY(ensure_solve_workspace(h, (n_s + n_linv + n_part + 7 * n_vec + (size_t)rp * 3 + 2 * (size_t)tr_blk + 16) * sizeof(double)));
+    double* S = h->nr_solve;
+    double* linv = S + n_s;
+    double* part = linv + n_linv;
+    double* b3 = part + n_part;
+    double* sp = b3 + n_vec;
+    double* fz = sp + n_vec;
+    double* gb = fz + n_vec;
+    double* r3 = gb + n_vec;
+    double* dw = r3 + n_vec;
+    double* z = dw + n_vec;  // [rp][3]
+    double* trpart = z + (size_t)rp * 3 + n_vec;
+    int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
+    hipStream_t st = h->stream;
+
+    PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    k_rhs<<<grid1(ld), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, ld, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
+                                        h->nr_alpha, h->params, b3, sp);
+    k_lr_gram<<<dim3((unsigned)ntile, (unsigned)nsplit), kBlock, 0, st>>>(h->F, ld, m, rank, sp, chunk, part);
+    k_lr_gram_reduce<<<grid1((int64_t)rp * rp), kBlock, 0, st>>>(part, ntile, nsplit, rank, rp, h->params, lmd, S);
+    PRG_TRY(cholesky_lookahead(h, S, rp, linv, info));
+    auto solve_with_factor = [&](const double* rhs, double* wout) -> int {
+        if (rp > rank) PRG_HIP(hipMemsetAsync(z + (size_t)rank * 3, 0, (size_t)(rp - rank) * 3 * sizeof(double), st));
+        PRG_TRY(prg::lowrank_ft3(h, rhs, z));        // F^T rhs
+        PRG_TRY(cholesky_solve3(h, S, rp, linv, z));  // z = (c I + F^T D F)^-1 F^T rhs
+        PRG_TRY(prg::lowrank_apply(h, z, fz));        // F z
+        k_lr_form_w<<<grid1(m), kBlock, 0, st>>>(rhs, sp, fz, m, h->params, lmd, wout);
+        PRG_HIP(hipGetLastError());
+        return PRG_OK;
+    };
+    PRG_TRY(solve_with_factor(b3, h->W));
+    const int nrefine = h->nr_alpha > 0.0 ? 2 : 0;  // (see prg_cpd_mstep_nonrigid)
+    for (int it = 0; it < nrefine; ++it) {
+        PRG_TRY(prg::nonrigid_gw(h, h->W, gb));
+        k_residual<<<grid1(ld), kBlock, 0, st>>>(b3, sp, gb, h->W, m, ld, h->params, lmd, r3);
+        PRG_TRY(solve_with_factor(r3, dw));
+        k_axpy3<<<grid1(m * 3), kBlock, 0, st>>>(dw, m, h->W);
+    }
+    PRG_TRY(prg::nonrigid_gw(h, h->W, gb));
+    k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, gb, m, trpart);
+    k_nonrigid_finish<<<1, 64, 0, st>>>(trpart, tr_blk, h->moments, h->params, h->D);
+    PRG_HIP(hipGetLastError());
+    int host_info = 0;
+    PRG_HIP(hipMemcpyAsync(&host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    PRG_REQUIRE(host_info == 0, PRG_ERR_STATE,
+                "prg_cpd_mstep_nonrigid: the reduced system is not positive definite at pivot %d (sigma2 or lmd <= 0?)",
+                host_info - 1);
+    return PRG_OK;
+}
+
 
 }  // namespace
 
 extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
-    PRG_REQUIRE(h && h->G && h->W && h->have_estep, PRG_ERR_STATE,
+    PRG_REQUIRE(h && (h->G || h->F) && h->W && h->have_estep, PRG_ERR_STATE,
                 "prg_cpd_mstep_nonrigid: needs build_g and an E-step first");
     PRG_REQUIRE(lmd > 0.0, PRG_ERR_INVALID, "prg_cpd_mstep_nonrigid: lmd must be > 0 (got %g)", lmd);
     prg::DeviceGuard g(h->device);
+    if (h->F) return mstep_nonrigid_lowrank(h, lmd);
     const int64_t m = h->M, mp = prg::round_up(m, NB), nblk = mp / NB;
     // workspace: S [mp*mp] | Linv [nblk*128*128] | b3, gb, v, sp (each <= 3 mp) | trace partials | info
     const size_t n_s = (size_t)mp * mp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)mp * 3;

@@ -76,6 +76,13 @@ struct prg_cpd {
     // non-rigid state
     float* G = nullptr;        // [M][M] float32 (row-major)
     double* W = nullptr;       // [M][3] float64 (row-major, 3 columns always)
+    // ... or its pivoted-Cholesky factor G = F F^T (non-rigid CPD): F[k * f_ld + i], k < f_rank
+    double* F = nullptr;
+    int64_t f_ld = 0;          // round_up(M, 256)
+    int f_rank = 0, f_cap = 0;
+    int nr_solver = 1;         // 1: low-rank factor when the rank allows (default), 0: dense G + M x M Cholesky
+    int nr_max_rank = 0;       // 0: min(2048, M / 2)
+    double nr_tol = 1.0e-14;   // the factor stops when the largest residual diagonal entry of G - F F^T is below this
     double beta = 0.0;
     bool nonrigid = false;
     double* nr_work = nullptr;  // [16 M] doubles: G.W product and scratch
@@ -106,4 +113,7 @@ int nonrigid_transform(prg_cpd* h);          // z4 = y + G W
 int nonrigid_gw(prg_cpd* h, const double* w3, double* out3);  // out3[m][3] = G * w3[m][3] (fp64)
 int nonrigid_free(prg_cpd* h);
 int build_kernel_matrix(prg_cpd* h, int kind, double param);  // kind 0: rbf(beta), 1: inverse multiquadric(c)
+// low-rank factor (cpd_nonrigid.hip): out[k][0..2] = sum_i F[k][i] x3[i][0..2]  /  out3[i][0..2] = sum_k F[k][i] v[k][0..2]
+int lowrank_ft3(prg_cpd* h, const double* x3, double* out);
+int lowrank_apply(prg_cpd* h, const double* v, double* out3);
 }  // namespace prg

@@ -180,6 +180,16 @@ class CpdPlan(object):
     def build_g(self, beta):
         check(lib.prg_cpd_nonrigid_build_g(self._h, float(beta)))
 
+    def set_nonrigid_solver(self, mode=1, max_rank=0, tol=0.0):
+        """Before build_g: 1 = low-rank factor of G when its rank allows (default), 0 = dense G + M x M Cholesky."""
+        check(lib.prg_cpd_nonrigid_set_solver(self._h, int(mode), int(max_rank), float(tol)))
+
+    def nonrigid_rank(self):
+        """Rank of the kernel factor the plan holds; 0 when it holds the dense matrix."""
+        r = ctypes.c_int(0)
+        check(lib.prg_cpd_nonrigid_rank(self._h, ctypes.byref(r)))
+        return int(r.value)
+
     def get_g(self):
         out = np.empty((self.m, self.m), dtype=np.float32)
         check(lib.prg_cpd_nonrigid_get_g(self._h, ptr(out)))

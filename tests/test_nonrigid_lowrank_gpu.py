@@ -1,0 +1,100 @@
+"""Low-rank form of the non-rigid path (include/probreg_hip.h: prg_cpd_nonrigid_build_g / _set_solver / _rank).
+
+The plan replaces the M x M kernel matrix G (reference: transformation.py:91-99) by its pivoted-Cholesky factor
+G = F F^T.  The factor is exact to the tolerance of the factorisation (1e-14 per entry), so everything computed with it
+must agree with fp64 numpy on the EXACT G - much closer than with the float32 G of the reference - and the registration
+must stay inside the non-rigid tolerances against the oracle, exactly like the dense solver."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _exact_g(y, beta):
+    y = np.asarray(y, dtype=np.float32).astype(np.float64)
+    d = y[:, None, :] - y[None, :, :]
+    return np.exp(-np.einsum("mnd,mnd->mn", d, d) / (2.0 * beta))
+
+
+def _plan_for(src, beta, mode=1, max_rank=0):
+    from probreg_amd import engine
+
+    plan = engine.CpdPlan()
+    plan.set_options(sort_source=False, sort_target=True, cull=False)
+    plan.set_source(src)
+    plan.set_nonrigid_solver(mode, max_rank)
+    plan.build_g(beta)
+    return plan
+
+
+def test_factor_reproduces_the_exact_kernel_matrix():
+    from probreg_amd import synthetic
+
+    src, _ = synthetic.nonrigid_pair(2100, m=1900, seed=5)
+    plan = _plan_for(src, 2.0)
+    rank = plan.nonrigid_rank()
+    assert 50 < rank < 400  # smooth kernel on a unit-sized cloud: ~180 whatever M is
+    w = np.random.default_rng(0).standard_normal(src.shape)
+    plan.set_w(w)
+    got = plan.nonrigid_apply() - src.astype(np.float32).astype(np.float64)
+    want = _exact_g(src, 2.0) @ w
+    assert np.max(np.abs(got - want)) < 1e-10 * np.max(np.abs(want))
+    # the float32 matrix handed to callers is still the reference's
+    from oracle import cpd_numpy as co
+
+    assert np.max(np.abs(plan.get_g() - co.rbf_kernel(src, src, 2.0))) <= 1.2e-7
+
+
+def test_rank_cap_falls_back_to_the_dense_matrix():
+    from probreg_amd import synthetic
+
+    src, _ = synthetic.nonrigid_pair(700, m=600, seed=6)
+    assert _plan_for(src, 2.0, max_rank=40).nonrigid_rank() == 0    # needs ~170 columns: refused
+    assert _plan_for(src, 2.0, mode=0).nonrigid_rank() == 0         # dense on request
+    assert _plan_for(src, 0.002).nonrigid_rank() == 0               # kernel narrower than the point spacing: full rank
+    assert _plan_for(src, 2.0).nonrigid_rank() > 0
+
+
+@pytest.mark.parametrize("seed,beta,lmd", [(11, 2.0, 2.0), (12, 0.3, 1.0), (13, 5.0, 0.5)])
+def test_lowrank_mstep_equals_fp64_solve_on_the_exact_matrix(seed, beta, lmd):
+    """One E-step + M-step from W = 0: the low-rank solve against numpy's solve on the exact fp64 G, from the plan's own
+    E-step arrays (so only the M-step is compared)."""
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(1700, m=1500, seed=seed)
+    reg = cpd.NonRigidCPD(src, beta=beta, lmd=lmd)
+    reg._initialize(tgt)
+    plan = reg._plan
+    assert plan.nonrigid_rank() > 0
+    sigma2 = plan.get_params()[13]
+    plan.estep(0.0)
+    pt1, p1, px = plan.get_estep()
+    plan.mstep_nonrigid(lmd)
+    w = plan.get_w()
+    g = _exact_g(src, beta)
+    y = src.astype(np.float32).astype(np.float64) - reg._origin
+    want = np.linalg.solve(p1[:, None] * g + lmd * sigma2 * np.identity(len(src)), px - p1[:, None] * y)
+    assert np.max(np.abs(w - want)) < 1e-7 * np.max(np.abs(want))
+    t = y + g @ want
+    x = tgt.astype(np.float32).astype(np.float64) - reg._origin
+    s2 = (np.sum(pt1 * np.sum(x * x, axis=1)) - 2.0 * np.sum(px * t) + np.sum(p1 * np.sum(t * t, axis=1))) / (p1.sum() * 3)
+    assert abs(plan.get_params()[13] - s2) < 1e-9 * s2 + 1e-7 * sigma2  # (the trace difference cancels ~1e2)
+
+
+def test_lowrank_and_dense_registrations_agree():
+    """Same registration through both solvers: they differ only by the float32 rounding of the dense G."""
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(2300, m=2000, seed=21)
+    out = {}
+    class DenseNonRigidCPD(cpd.NonRigidCPD):
+        _solver_mode = 0
+
+    for mode, cls in ((1, cpd.NonRigidCPD), (0, DenseNonRigidCPD)):
+        reg = cls(src)
+        res = reg.registration(tgt, maxiter=8, tol=-1.0)
+        out[mode] = (res.sigma2, res.transformation.transform(src), reg._plan.nonrigid_rank())
+    assert out[1][2] > 0 and out[0][2] == 0
+    ext = np.max(np.abs(out[0][1] - out[0][1].mean(0)))
+    assert np.max(np.abs(out[1][1] - out[0][1])) < 1e-4 * ext
+    assert abs(out[1][0] - out[0][0]) < 1e-5 * out[0][0]
