@@ -78,7 +78,8 @@ int prg_cpd_destroy(prg_cpd* h);
  * is an exact zero in fp32.  The non-rigid path keeps the source unsorted. */
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
 
-/* Engine of the E-step's DENSE regime (sigma2 large: every pair contributes).  mode 1 (default): the pair sweeps take
+/* Engine of the E-step's DENSE regime (sigma2 large: every pair contributes).  mode 1 (default; clouds of >= 8192 points
+ * each): the pair sweeps take
  * their exponents from the matrix cores (bf16x3-split MFMA distance blocks) while
  * |log2(e) / (2 sigma2)| * (squared diagonal of the larger of the source's / local target's bounding box) < bound (default
  * 4000; the row pass leaves at 1/8 of it; both skip whole 512 x 256 blocks of exact zeros) - from there on the culled

@@ -341,8 +341,10 @@ class NonRigidCPD(CoherentPointDrift):
 
     def _build(self):
         self._plan = CpdPlan(self._device)
-        # G, W and the per-point all-reduce block are indexed by the caller's source order
-        self._plan.set_options(sort_source=False, sort_target=True, cull=False)
+        # both clouds are Morton-sorted inside the plan (culled / matrix-core sweeps); W, the priors and the transformed
+        # points cross the C-ABI in the caller's order, and every rank sorts the replicated source the same way, so the
+        # per-point all-reduce block lines up across ranks
+        self._plan.set_options(sort_source=True, sort_target=True, cull=True)
         # G is built from the float32 source exactly as the reference's pybind cast sees it (cc/math_utils.cc:17-19),
         # so clouds near the origin are uploaded as they are.  A cloud FAR from the origin (coordinates many times its
         # own extent, e.g. examples/face-x.txt with z ~ 1277) would lose its fine structure in that cast - in the

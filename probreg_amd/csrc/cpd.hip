@@ -1077,7 +1077,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int RA = ra < 0 ? -ra : ra, RB = rb < 0 ? -rb : rb;
     const int64_t nblkA = prg::ceil_div(h->N, kBlock * RA), nblkB = prg::ceil_div(h->M, kBlock * RB);
     // Culled sweeps need both clouds Morton-sorted (compact waves / groups); they walk the stream in groups of 32.
-    const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0 && !h->nonrigid;  // (segment counts stay tunable)
+    const bool use_cull = h->opt_cull && h->perm_src && h->perm_tgt && h->r_col == 0 && h->r_row == 0;  // (segment counts stay tunable)
     // segment lengths are multiples of the loop trip (8 points, or 256 points = 8 groups); the pads absorb the
     // overshoot and the prefetch over-read of the last segment
     const int quantum = use_cull ? prg::kSuper : 8;
@@ -1111,7 +1111,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int PA = use_cull ? (int)prg::ceil_div(SA, 4) : SA, PB = use_cull ? (int)prg::ceil_div(SB, 4) : SB;
     PRG_REQUIRE(!use_cull || PB <= 64, PRG_ERR_INVALID, "prg_cpd_estep: at most 256 row-pass segments with culling");
     // matrix-core sweeps (dense regime, decided per E-step below): segments of whole 512-point chunks, one plane each
-    const bool mfma_possible = use_cull && h->dense_engine > 0 && !h->srcw;
+    // ... for clouds large enough that the sweeps are worth it: below ~8k points an E-step is launch bound whatever the
+    // engine, and a 512-point patch of a small cloud spans most of it (the patch-local origin buys no precision)
+    const bool mfma_possible = use_cull && h->dense_engine > 0 && !h->srcw &&
+                               (h->dense_engine >= 2 || (h->M >= 8192 && h->N >= 8192));
     static const int mfma_seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;  // 0: fill the chip once
     const int PAm = mfma_possible ? prg::mfma_planes(h->N, h->M, mfma_seg) : 0,
               PBm = mfma_possible ? prg::mfma_planes(h->M, h->N, mfma_seg) : 0;
@@ -1137,12 +1140,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[0], h->stream));
     const int slot = (int)(h->estep_count & 1);
     ++h->estep_count;
-    if (h->nonrigid)
-        PRG_TRY(prg::nonrigid_transform(h));
-    else  // one fused kernel: transform, source motion, group boxes of the transformed cloud
-        k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
-            h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw,
-            h->bcpd ? h->W : nullptr);  // pad-only blocks are static
+    // one fused kernel: transform, source motion, group boxes of the transformed cloud.  Non-rigid: z = y + G W with the
+    // parameter block's identity linear part (the fp64 sum is rounded once, transformation.py:101-102)
+    const double* disp = h->bcpd ? h->W : nullptr;
+    if (h->nonrigid) PRG_TRY(prg::nonrigid_displacement(h, &disp));
+    k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
+        h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw, disp);  // pad-only blocks are static
     // Dense regime on the matrix cores?  The host decides per E-step from three numbers the device already has:
     // sigma2, the source motion of this transform and the largest column minimum of the previous E-step (DESIGN.md
     // 3.1c).  One small read-back per E-step while the registration is in the dense regime; once sigma2 has fallen to
@@ -1206,7 +1209,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());
     h->have_estep = true;
-    h->have_colmin = !h->nonrigid;  // colmin now describes the z4 of this E-step (motion is measured against it)
+    h->have_colmin = true;  // colmin now describes the z4 of this E-step (motion is measured against it)
     h->last_w = w;
     return PRG_OK;
 }

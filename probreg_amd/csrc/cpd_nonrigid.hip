@@ -96,43 +96,36 @@ __global__ __launch_bounds__(kBlock) void k_gw(const float* __restrict__ g, int6
     }
 }
 
-// z4 = y + GW (float32 result of an fp64 sum), pads to sentinel
-__global__ __launch_bounds__(kBlock) void k_add_disp(const float4* __restrict__ src4, const double* __restrict__ gw,
-                                                     int64_t m, int64_t cap, float4* __restrict__ z4) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= cap) return;
-    float4 o;
-    if (i < m) {
-        const float4 y = src4[i];
-        o.x = (float)((double)y.x + gw[i * 3]);
-        o.y = (float)((double)y.y + gw[i * 3 + 1]);
-        o.z = (float)((double)y.z + gw[i * 3 + 2]);
-        o.w = 0.f;
-    } else {
-        o.x = o.y = o.z = prg::kSrcPad;
-        o.w = 0.f;
-    }
-    z4[i] = o;
-}
-
+// caller's [m][dim] (original point order) <-> the plan's [m][3] (kernel order: sorted position i = original perm[i])
 __global__ __launch_bounds__(kBlock) void k_pack_w(const double* __restrict__ in, int64_t m, int dim,
-                                                   double* __restrict__ w3, int to_w3) {
+                                                   double* __restrict__ w3, int to_w3, const int* __restrict__ perm) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
+    const int64_t j = perm ? perm[i] : i;
     if (to_w3) {
-        for (int k = 0; k < 3; ++k) w3[i * 3 + k] = k < dim ? in[i * dim + k] : 0.0;
+        for (int k = 0; k < 3; ++k) w3[i * 3 + k] = k < dim ? in[j * dim + k] : 0.0;
     } else {
         double* out = const_cast<double*>(in);
-        for (int k = 0; k < dim; ++k) out[i * dim + k] = w3[i * 3 + k];
+        for (int k = 0; k < dim; ++k) out[j * dim + k] = w3[i * 3 + k];
     }
 }
 
-// [m][dim] row-major -> 3 planes of m (missing dims zero)
-__global__ __launch_bounds__(kBlock) void k_unpack_planes(const double* __restrict__ in, int64_t m, int dim,
-                                                          double* __restrict__ planes) {
+// caller's p1 [m] and px [m][dim] -> 4 planes of m in kernel order (missing dims zero)
+__global__ __launch_bounds__(kBlock) void k_unpack_planes(const double* __restrict__ p1, const double* __restrict__ in,
+                                                          int64_t m, int dim, double* __restrict__ planes,
+                                                          const int* __restrict__ perm) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
-    for (int k = 0; k < 3; ++k) planes[(int64_t)k * m + i] = k < dim ? in[i * dim + k] : 0.0;
+    const int64_t j = perm ? perm[i] : i;
+    planes[i] = p1[j];
+    for (int k = 0; k < 3; ++k) planes[(int64_t)(k + 1) * m + i] = k < dim ? in[j * dim + k] : 0.0;
+}
+
+// kernel-order points back in the caller's order (float4 layout kept)
+__global__ __launch_bounds__(kBlock) void k_unsort4(const float4* __restrict__ in, int64_t m, const int* __restrict__ perm,
+                                                    float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) out[perm ? perm[i] : i] = in[i];
 }
 
 // ---- low-rank factor of the Gaussian kernel matrix -------------------------------------------------------------
@@ -305,12 +298,11 @@ inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); 
 namespace prg {
 
 // workspace layout inside h->nr_work (doubles): [0, 3M) GW / scratch
-int nonrigid_transform(prg_cpd* h) {
+// displacement field G W of the current W -> nr_work[0, 3M); the E-step's transform kernel adds it to the source
+int nonrigid_displacement(prg_cpd* h, const double** gw_out) {
     PRG_REQUIRE((h->G || h->F) && h->W, PRG_ERR_STATE, "non-rigid transform: G has not been built");
-    double* gw = h->nr_work;
-    PRG_TRY(nonrigid_gw(h, h->W, gw));
-    k_add_disp<<<grid1(h->Mcap), kBlock, 0, h->stream>>>(h->src4, gw, h->M, h->Mcap, h->z4);
-    PRG_HIP(hipGetLastError());
+    PRG_TRY(nonrigid_gw(h, h->W, h->nr_work));
+    *gw_out = h->nr_work;
     return PRG_OK;
 }
 
@@ -507,22 +499,30 @@ int prg_cpd_bcpd_build_g(prg_cpd* h, double c) {
 }
 
 int prg_cpd_nonrigid_get_g(prg_cpd* h, float* g_hd) {
-    PRG_REQUIRE(h && (h->G || h->F) && g_hd, PRG_ERR_STATE, "prg_cpd_nonrigid_get_g: G has not been built");
+    PRG_REQUIRE(h && (h->G || h->F) && !h->bcpd && g_hd, PRG_ERR_STATE, "prg_cpd_nonrigid_get_g: G has not been built");
     prg::DeviceGuard g(h->device);
     const size_t bytes = (size_t)h->M * h->M * sizeof(float);
-    if (h->G) {
+    if (h->G && !h->perm_src) {
         PRG_HIP(hipMemcpyAsync(g_hd, h->G, bytes, hipMemcpyDefault, h->stream));
         PRG_HIP(hipStreamSynchronize(h->stream));
         return PRG_OK;
     }
-    // the plan keeps only the factor: evaluate the matrix for the caller (float32, like the reference's own G)
+    // the plan keeps the factor only, or the matrix of the SORTED source: evaluate the float32 matrix of the caller's
+    // order on the spot (entry (i, j) depends on the two points alone, so this is the same matrix)
     float* tmp = nullptr;
+    float4* pts = nullptr;
     PRG_HIP(hipMalloc((void**)&tmp, bytes));
+    if (hipMalloc((void**)&pts, (size_t)h->M * sizeof(float4)) != hipSuccess) {
+        (void)hipFree(tmp);
+        PRG_REQUIRE(false, PRG_ERR_HIP, "prg_cpd_nonrigid_get_g: out of device memory");
+    }
+    k_unsort4<<<grid1(h->M), kBlock, 0, h->stream>>>(h->src4, h->M, h->perm_src, pts);
     dim3 grid((unsigned)prg::ceil_div(h->M, kBlock), (unsigned)prg::ceil_div(h->M, 16));
-    k_build_g<0><<<grid, kBlock, 0, h->stream>>>(h->src4, h->M, (float)(2.0 * h->beta), tmp);
+    k_build_g<0><<<grid, kBlock, 0, h->stream>>>(pts, h->M, (float)(2.0 * h->beta), tmp);
     hipError_t e = hipMemcpyAsync(g_hd, tmp, bytes, hipMemcpyDefault, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     (void)hipFree(tmp);
+    (void)hipFree(pts);
     PRG_HIP(e);
     return PRG_OK;
 }
@@ -532,7 +532,7 @@ int prg_cpd_nonrigid_set_w(prg_cpd* h, const double* w_hd) {
     prg::DeviceGuard g(h->device);
     PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(double)));
     PRG_HIP(hipMemcpyAsync(h->stage, w_hd, (size_t)h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
-    k_pack_w<<<grid1(h->M), kBlock, 0, h->stream>>>((const double*)h->stage, h->M, h->D, h->W, 1);
+    k_pack_w<<<grid1(h->M), kBlock, 0, h->stream>>>((const double*)h->stage, h->M, h->D, h->W, 1, h->perm_src);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
     return PRG_OK;
@@ -542,7 +542,7 @@ int prg_cpd_nonrigid_get_w(prg_cpd* h, double* w_hd) {
     PRG_REQUIRE(h && h->W && w_hd, PRG_ERR_STATE, "prg_cpd_nonrigid_get_w: G has not been built");
     prg::DeviceGuard g(h->device);
     PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(double)));
-    k_pack_w<<<grid1(h->M), kBlock, 0, h->stream>>>((const double*)h->stage, h->M, h->D, h->W, 0);
+    k_pack_w<<<grid1(h->M), kBlock, 0, h->stream>>>((const double*)h->stage, h->M, h->D, h->W, 0, h->perm_src);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipMemcpyAsync(w_hd, h->stage, (size_t)h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));
@@ -559,10 +559,12 @@ int prg_cpd_nonrigid_set_priors(prg_cpd* h, const double* p1_tilde_hd, const dou
     PRG_REQUIRE(alpha > 0.0, PRG_ERR_INVALID, "prg_cpd_nonrigid_set_priors: alpha must be > 0 (got %g)", alpha);
     const int64_t m = h->M;
     if (!h->nr_prior) PRG_HIP(hipMalloc((void**)&h->nr_prior, (size_t)m * 4 * sizeof(double)));
-    PRG_TRY(prg::ensure_stage(h, (size_t)m * h->D * sizeof(double)));
-    PRG_HIP(hipMemcpyAsync(h->nr_prior, p1_tilde_hd, (size_t)m * sizeof(double), hipMemcpyDefault, h->stream));
-    PRG_HIP(hipMemcpyAsync(h->stage, px_tilde_hd, (size_t)m * h->D * sizeof(double), hipMemcpyDefault, h->stream));
-    k_unpack_planes<<<grid1(m), kBlock, 0, h->stream>>>((const double*)h->stage, m, h->D, h->nr_prior + m);
+    PRG_TRY(prg::ensure_stage(h, (size_t)m * (h->D + 1) * sizeof(double)));
+    double* st_p1 = (double*)h->stage;
+    double* st_px = st_p1 + m;
+    PRG_HIP(hipMemcpyAsync(st_p1, p1_tilde_hd, (size_t)m * sizeof(double), hipMemcpyDefault, h->stream));
+    PRG_HIP(hipMemcpyAsync(st_px, px_tilde_hd, (size_t)m * h->D * sizeof(double), hipMemcpyDefault, h->stream));
+    k_unpack_planes<<<grid1(m), kBlock, 0, h->stream>>>(st_p1, st_px, m, h->D, h->nr_prior, h->perm_src);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
     h->nr_alpha = alpha;
@@ -580,12 +582,14 @@ int prg_cpd_rowacc_ptr(prg_cpd* h, double** rowacc_dev, int64_t* count) {
 
 namespace {
 __global__ __launch_bounds__(kBlock) void k_apply_out(const float4* __restrict__ src4, const double* __restrict__ gw,
-                                                      int64_t m, int dim, double* __restrict__ out) {
+                                                      int64_t m, int dim, double* __restrict__ out,
+                                                      const int* __restrict__ perm) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
     const float4 y = src4[i];
     const double yy[3] = {y.x, y.y, y.z};
-    for (int k = 0; k < dim; ++k) out[i * dim + k] = yy[k] + gw[i * 3 + k];
+    const int64_t j = perm ? perm[i] : i;
+    for (int k = 0; k < dim; ++k) out[j * dim + k] = yy[k] + gw[i * 3 + k];
 }
 }  // namespace
 
@@ -595,7 +599,7 @@ extern "C" int prg_cpd_nonrigid_apply(prg_cpd* h, double* t_hd) {
     double* gw = h->nr_work;
     PRG_TRY(prg::nonrigid_gw(h, h->W, gw));
     PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(double)));
-    k_apply_out<<<grid1(h->M), kBlock, 0, h->stream>>>(h->src4, gw, h->M, h->D, (double*)h->stage);
+    k_apply_out<<<grid1(h->M), kBlock, 0, h->stream>>>(h->src4, gw, h->M, h->D, (double*)h->stage, h->perm_src);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipMemcpyAsync(t_hd, h->stage, (size_t)h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));

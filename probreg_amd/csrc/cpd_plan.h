@@ -109,7 +109,7 @@ struct prg_cpd {
 namespace prg {
 int ensure_stage(prg_cpd* h, size_t bytes);
 // non-rigid (cpd_nonrigid.hip)
-int nonrigid_transform(prg_cpd* h);          // z4 = y + G W
+int nonrigid_displacement(prg_cpd* h, const double** gw_out);  // G W of the current W (device, [M][3])
 int nonrigid_gw(prg_cpd* h, const double* w3, double* out3);  // out3[m][3] = G * w3[m][3] (fp64)
 int nonrigid_free(prg_cpd* h);
 int build_kernel_matrix(prg_cpd* h, int kind, double param);  // kind 0: rbf(beta), 1: inverse multiquadric(c)
