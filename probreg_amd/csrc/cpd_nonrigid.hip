@@ -251,6 +251,7 @@ __global__ __launch_bounds__(kBlock) void k_lr_ft3(const double* __restrict__ f,
     __shared__ double sh[kBlock / 64][3];
     const double* __restrict__ col = f + (int64_t)blockIdx.x * ld;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll 4
     for (int64_t i = threadIdx.x; i < m; i += kBlock) {
         const double c = col[i];
         a0 = fma(c, x3[i * 3], a0);
@@ -301,7 +302,10 @@ namespace prg {
 // displacement field G W of the current W -> nr_work[0, 3M); the E-step's transform kernel adds it to the source
 int nonrigid_displacement(prg_cpd* h, const double** gw_out) {
     PRG_REQUIRE((h->G || h->F) && h->W, PRG_ERR_STATE, "non-rigid transform: G has not been built");
-    PRG_TRY(nonrigid_gw(h, h->W, h->nr_work));
+    if (!h->gw_valid) {
+        PRG_TRY(nonrigid_gw(h, h->W, h->nr_work));
+        h->gw_valid = true;
+    }
     *gw_out = h->nr_work;
     return PRG_OK;
 }
@@ -334,8 +338,11 @@ int nonrigid_gw(prg_cpd* h, const double* w3, double* out3) {
 // max_rank the factor is dropped and *ok = false (the caller falls back to the dense matrix).
 static int build_lowrank_factor(prg_cpd* h, double beta, int max_rank, double tol, bool* ok) {
     *ok = false;
-    const int64_t m = h->M, ld = round_up(m, kBlock);
-    const int nblk = (int)(ld / kBlock);
+    // rows of the factor are 256 bytes out of step with each other: kernels that walk many columns of F at the same
+    // point offset (k_lr_gram's staging, k_lr_ft3, this file's k_pchol_step) would otherwise hit the same memory
+    // channels with every row (row stride = a multiple of 8 KB)
+    const int64_t m = h->M, mp = round_up(m, kBlock), ld = mp + 32;
+    const int nblk = (int)(mp / kBlock);
     int cap = std::min(max_rank, 256);
     double* f = nullptr;
     double* work = nullptr;  // d [ld] | part [2][nblk] double2 | state | piv [kMaxRank]
@@ -355,7 +362,7 @@ static int build_lowrank_factor(prg_cpd* h, double beta, int max_rank, double to
         prg::set_error("non-rigid kernel factor: %s", what);
         return PRG_ERR_HIP;
     };
-    k_pchol_init<<<nblk, kBlock, 0, h->stream>>>(m, ld, d, part, state);
+    k_pchol_init<<<nblk, kBlock, 0, h->stream>>>(m, mp, d, part, state);
     PcholState host = {0, 0, 1.0};
     int j = 0;
     const int limit = (int)std::min<int64_t>(max_rank, m);
@@ -455,6 +462,7 @@ int nonrigid_free(prg_cpd* h) {
     h->nr_work_bytes = 0;
     h->nonrigid = false;
     h->bcpd = false;
+    h->gw_valid = false;
     return PRG_OK;
 }
 
@@ -533,6 +541,7 @@ int prg_cpd_nonrigid_set_w(prg_cpd* h, const double* w_hd) {
     PRG_TRY(prg::ensure_stage(h, (size_t)h->M * h->D * sizeof(double)));
     PRG_HIP(hipMemcpyAsync(h->stage, w_hd, (size_t)h->M * h->D * sizeof(double), hipMemcpyDefault, h->stream));
     k_pack_w<<<grid1(h->M), kBlock, 0, h->stream>>>((const double*)h->stage, h->M, h->D, h->W, 1, h->perm_src);
+    h->gw_valid = false;
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
     return PRG_OK;

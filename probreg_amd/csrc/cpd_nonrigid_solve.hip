@@ -94,6 +94,17 @@ __global__ __launch_bounds__(kBlock) void k_build_s(const float* __restrict__ g,
 // thread then owns one row below it, and the rank-8 trailing update is register tiled 4 x 4.
 constexpr int PB = 8;
 
+// 1 / sqrt(d) for d > 0 to ~1 ulp: v_rsq_f64 (2^-26) + two Newton-Raphson steps, scaled against under/overflow of d y^2
+__device__ __forceinline__ double rsqrt_newton(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-d * y, y, 1.0);  // 1 - d y^2
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 __device__ __forceinline__ void load_diag8(const double* a, int jb, double (&l)[PB][PB]) {
 #pragma unroll
     for (int r = 0; r < PB; ++r)
@@ -101,22 +112,27 @@ __device__ __forceinline__ void load_diag8(const double* a, int jb, double (&l)[
         for (int c = 0; c < PB; ++c) l[r][c] = (c <= r) ? a[(jb + r) * LDP + jb + c] : 0.0;
 }
 
+// nreal: rows / columns of S that are not identity padding (>= k0 + 1): the block's trailing identity part is skipped.
 __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, int64_t ld, int64_t k0,
-                                                      double* __restrict__ linv, int* __restrict__ info) {
+                                                      double* __restrict__ linv, int* __restrict__ info,
+                                                      int64_t nreal) {
     extern __shared__ double a[];  // [NB][LDP]
+    __shared__ double rdiag[NB];   // 1 / L_jj
     const int tid = threadIdx.x;
     double* sblk = s + k0 * ld + k0;
+    // active part of the block, in whole panels of 8 (the rest is identity and stays identity)
+    const int nb = (int)((nreal - k0 >= NB) ? NB : ((nreal - k0 + PB - 1) / PB) * PB);
     for (int idx = tid; idx < NB * NB; idx += kBlock) {
         const int i = idx >> 7, j = idx & 127;
-        a[i * LDP + j] = sblk[(int64_t)i * ld + j];
+        if (i < nb && j < nb) a[i * LDP + j] = sblk[(int64_t)i * ld + j];
     }
     // ---------------- Cholesky, 16 panels of 8 columns ----------------
-    for (int jb = 0; jb < NB; jb += PB) {
+    for (int jb = 0; jb < nb; jb += PB) {
         __syncthreads();
         double l[PB][PB];
         load_diag8(a, jb, l);
         const int i = jb + PB + tid;  // the row below the diagonal block this thread owns (if any)
-        const bool has_row = i < NB;
+        const bool has_row = i < nb;
         double x[PB];
         if (has_row) {
 #pragma unroll
@@ -131,8 +147,10 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 #pragma unroll
             for (int k = 0; k < c; ++k) d -= l[c][k] * l[c][k];
             if (!(d > 0.0)) { bad = true; d = fabs(d) > 0.0 ? fabs(d) : 1.0; }
-            l[c][c] = sqrt(d);
-            inv[c] = 1.0 / l[c][c];
+            // this chain is the sequential part of the whole factorisation: 1 / sqrt(d) from the hardware estimate and
+            // two Newton steps (a dozen dependent operations) instead of a correctly rounded sqrt followed by a divide
+            inv[c] = rsqrt_newton(d);
+            l[c][c] = d * inv[c];
 #pragma unroll
             for (int r = c + 1; r < PB; ++r) {
                 double t = l[r][c];
@@ -154,13 +172,15 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
         }
         if (tid == kBlock - 1) {
 #pragma unroll
-            for (int r = 0; r < PB; ++r)
+            for (int r = 0; r < PB; ++r) {
+                rdiag[jb + r] = inv[r];
 #pragma unroll
                 for (int c = 0; c <= r; ++c) a[(jb + r) * LDP + jb + c] = l[r][c];
+            }
         }
         __syncthreads();
         // rank-8 update of the trailing lower triangle, 4 x 4 register tiles
-        const int t0 = jb + PB, nt = (NB - t0 + 3) >> 2;
+        const int t0 = jb + PB, nt = (nb - t0 + 3) >> 2;
         for (int t = tid; t < nt * nt; t += kBlock) {
             const int ti = t / nt, tk = t % nt;
             if (tk > ti) continue;
@@ -170,14 +190,14 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int c = 0; c < PB; ++c) {
-                    ai[r][c] = (i0 + r < NB) ? a[(i0 + r) * LDP + jb + c] : 0.0;
-                    ak[r][c] = (kk0 + r < NB) ? a[(kk0 + r) * LDP + jb + c] : 0.0;
+                    ai[r][c] = (i0 + r < nb) ? a[(i0 + r) * LDP + jb + c] : 0.0;
+                    ak[r][c] = (kk0 + r < nb) ? a[(kk0 + r) * LDP + jb + c] : 0.0;
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (i0 + r < NB && kk0 + q <= i0 + r) {
+                    if (i0 + r < nb && kk0 + q <= i0 + r) {
                         double acc = 0.0;
 #pragma unroll
                         for (int c = 0; c < PB; ++c) acc += ai[r][c] * ak[q][c];
@@ -189,15 +209,17 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
     __syncthreads();
     for (int idx = tid; idx < NB * NB; idx += kBlock) {
         const int i = idx >> 7, j = idx & 127;
-        if (j <= i) sblk[(int64_t)i * ld + j] = a[i * LDP + j];
+        if (j <= i && i < nb) sblk[(int64_t)i * ld + j] = a[i * LDP + j];
     }
     // ---------------- in-place inverse of the lower triangle, block columns from last to first ----------------
     // with A11 the 8 x 8 diagonal block, A21 the rows below it and X22 = inv(A22) already in place:
     //   new A21 = -X22 * A21 * inv(A11),  new A11 = inv(A11)
-    for (int jb = NB - PB; jb >= 0; jb -= PB) {
+    for (int jb = nb - PB; jb >= 0; jb -= PB) {
         __syncthreads();
-        double l[PB][PB], li[PB][PB];
+        double l[PB][PB], li[PB][PB], dinv[PB];
         load_diag8(a, jb, l);
+#pragma unroll
+        for (int r = 0; r < PB; ++r) dinv[r] = rdiag[jb + r];
 #pragma unroll
         for (int c = 0; c < PB; ++c) {  // li = inv(l), column by column (forward substitution)
 #pragma unroll
@@ -207,20 +229,35 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
 #pragma unroll
                 for (int k = 0; k < PB; ++k)
                     if (k >= c && k < r) t -= l[r][k] * li[k][c];
-                li[r][c] = t / l[r][r];
+                li[r][c] = t * dinv[r];
             }
         }
         const int i = jb + PB + tid;
-        const bool has_row = i < NB;
+        const bool has_row = i < nb;
         double z[PB];
         if (has_row) {
             double y[PB];
 #pragma unroll
             for (int c = 0; c < PB; ++c) y[c] = 0.0;
-            for (int k = jb + PB; k <= i; ++k) {  // y = X22[i, :] * A21   (X22 lower triangular)
+            // y = X22[i, :] * A21 (X22 lower triangular); four rows per trip so that their LDS reads are in flight together
+            int k = jb + PB;
+            for (; k + 3 <= i; k += 4) {
+                double xk[4], ar[4][PB];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xk[u] = a[i * LDP + k + u];
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) ar[u][c] = a[(k + u) * LDP + jb + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < PB; ++c) y[c] = fma(xk[u], ar[u][c], y[c]);
+            }
+            for (; k <= i; ++k) {
                 const double xik = a[i * LDP + k];
 #pragma unroll
-                for (int c = 0; c < PB; ++c) y[c] += xik * a[k * LDP + jb + c];
+                for (int c = 0; c < PB; ++c) y[c] = fma(xik, a[k * LDP + jb + c], y[c]);
             }
 #pragma unroll
             for (int c = 0; c < PB; ++c) {  // z = -y * inv(A11)
@@ -246,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
     __syncthreads();
     for (int idx = tid; idx < NB * NB; idx += kBlock) {
         const int i = idx >> 7, j = idx & 127;
-        linv[idx] = (j <= i) ? a[i * LDP + j] : 0.0;
+        linv[idx] = (i < nb) ? ((j <= i) ? a[i * LDP + j] : 0.0) : (i == j ? 1.0 : 0.0);
     }
 }
 
@@ -507,10 +544,14 @@ constexpr int GT = 64;    // tile edge
 constexpr int GS = 32;    // points per LDS slab
 constexpr int GLD = GT + 1;
 
+// The tile products run on the f64 matrix cores (v_mfma_f64_16x16x4_f64: wave w owns the 32 x 32 quadrant (w >> 1, w & 1)
+// as 2 x 2 MFMA tiles, operands from the LDS slab).  Workgroups of the first tile column (tb == 0) also form their rows of
+// u = F^T B with one more MFMA per k-step (B = [b | 0] as a 16-column operand), so the right-hand side of the reduced
+// system costs no pass of its own.
 __global__ __launch_bounds__(kBlock) void k_lr_gram(const double* __restrict__ f, int64_t ld, int64_t m, int rank,
-                                                    const double* __restrict__ sp, int64_t chunk,
-                                                    double* __restrict__ part) {
-    __shared__ double as[GS][GLD], bs[GS][GLD];
+                                                    const double* __restrict__ sp, const double* __restrict__ b3,
+                                                    int64_t chunk, double* __restrict__ part, double* __restrict__ upart) {
+    __shared__ double as[GS][GLD], bs[GS][GLD], xs[GS][16];
     // tile (ta >= tb) of the lower triangle from the linear index
     int ta = 0, rem = blockIdx.x;
     while (rem > ta) {
@@ -520,51 +561,111 @@ __global__ __launch_bounds__(kBlock) void k_lr_gram(const double* __restrict__ f
     const int tb = rem;
     const int a0 = ta * GT, b0 = tb * GT;
     const int64_t i_begin = (int64_t)blockIdx.y * chunk, i_end = i_begin + chunk < m ? i_begin + chunk : m;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // thread owns rows a0 + 4 ty .. + 3, columns b0 + 4 tx .. + 3
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wr = wv >> 1, wc = wv & 1, li = lane & 15, kq = lane >> 4;
     const int lk = threadIdx.x & 31, lr = threadIdx.x >> 5;  // staging: point lk of the slab, factor rows lr + 8 q
-    double acc[4][4];
+    const bool with_u = tb == 0;
+    d4 acc[2][2], uacc[2];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int i = 0; i < 2; ++i) {
+        uacc[i] = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0;
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += GS) {
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    (&xs[0][0])[threadIdx.x] = 0.0;  // columns 3..15 of the right-hand-side operand stay zero
+    (&xs[0][0])[threadIdx.x + kBlock] = 0.0;
+    // software pipeline: the global loads of slab t + 1 are in flight while the matrix cores work on slab t (all loads of
+    // a slab are issued before the first LDS store - interleaved, every store would wait for its own load's round trip)
+    double ra[GT / 8], rb[GT / 8], rx = 0.0;
+    auto fetch = [&](int64_t i0) {
         const int64_t i = i0 + lk;
         const bool in = i < i_end;
         const double pw = in ? sp[i] * sp[i] : 0.0;  // D_ii (k_rhs left sqrt(D) in sp)
 #pragma unroll
         for (int q = 0; q < GT / 8; ++q) {
             const int r = lr + 8 * q;
-            as[lk][r] = (in && a0 + r < rank) ? f[(int64_t)(a0 + r) * ld + i] : 0.0;
-            bs[lk][r] = (in && b0 + r < rank) ? pw * f[(int64_t)(b0 + r) * ld + i] : 0.0;
+            ra[q] = (in && a0 + r < rank) ? f[(int64_t)(a0 + r) * ld + i] : 0.0;
+            rb[q] = (in && b0 + r < rank) ? f[(int64_t)(b0 + r) * ld + i] : 0.0;
         }
-        __syncthreads();
-#pragma unroll 8
-        for (int k = 0; k < GS; ++k) {
-            double av[4], bv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                av[r] = as[k][4 * ty + r];
-                bv[r] = bs[k][4 * tx + r];
+        for (int q = 0; q < GT / 8; ++q) rb[q] *= pw;
+        if (with_u && lr < 3) rx = in ? b3[i * 3 + lr] : 0.0;
+    };
+    fetch(i_begin);
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += GS) {
+        __syncthreads();  // the previous slab has been consumed
+#pragma unroll
+        for (int q = 0; q < GT / 8; ++q) {
+            as[lk][lr + 8 * q] = ra[q];
+            bs[lk][lr + 8 * q] = rb[q];
+        }
+        if (with_u && lr < 3) xs[lk][lr] = rx;
+        __syncthreads();
+        if (i0 + GS < i_end) fetch(i0 + GS);
+#pragma unroll
+        for (int k4 = 0; k4 < GS; k4 += 4) {
+            double av[2], bv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                av[t] = as[k4 + kq][wr * 32 + 16 * t + li];
+                bv[t] = bs[k4 + kq][wc * 32 + 16 * t + li];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+                for (int j2 = 0; j2 < 2; ++j2)
+                    acc[i2][j2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i2], bv[j2], acc[i2][j2], 0, 0, 0);
+            if (with_u && wc == 0) {
+                const double xv = xs[k4 + kq][li];
+                uacc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], xv, uacc[0], 0, 0, 0);
+                uacc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], xv, uacc[1], 0, 0, 0);
+            }
         }
-        __syncthreads();
     }
+    // C/D map of the MFMA: row = (lane >> 4) + 4 reg, column = lane & 15
     double* __restrict__ out = part + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (GT * GT);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) out[(4 * ty + r) * GT + 4 * tx + c] = acc[r][c];
+        for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(wr * 32 + 16 * i2 + kq + 4 * r) * GT + wc * 32 + 16 * j2 + li] = acc[i2][j2][r];
+    if (with_u && wc == 0 && li < 3) {  // upart[split][row][3]
+        double* __restrict__ uo = upart + (int64_t)blockIdx.y * ((int64_t)rank * 3);
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = a0 + wr * 32 + 16 * i2 + kq + 4 * r;
+                if (row < rank) uo[(int64_t)row * 3 + li] = uacc[i2][r];
+            }
+    }
 }
 
-// S[a][b] = c [a == b] + sum over the splits of T's tile entry (a, b) for a, b < rank; identity in the pad (rp x rp)
-__global__ __launch_bounds__(kBlock) void k_lr_gram_reduce(const double* __restrict__ part, int ntile, int nsplit,
-                                                           int rank, int64_t rp, const double* __restrict__ params,
-                                                           double lmd, double* __restrict__ s) {
+// S[a][b] = c [a == b] + sum over the splits of T's tile entry (a, b) for a, b < rank; identity in the pad (rp x rp).
+// The splits are summed in four interleaved chains (fixed order: reproducible) so that the loads overlap.
+__global__ __launch_bounds__(kBlock) void k_lr_gram_reduce(const double* __restrict__ part, const double* __restrict__ upart,
+                                                           int ntile, int nsplit, int rank, int64_t rp,
+                                                           const double* __restrict__ params, double lmd,
+                                                           double* __restrict__ s, double* __restrict__ u) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e < (int64_t)rp * 3) {  // u = F^T B (zero rows in the pad)
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        if (e < (int64_t)rank * 3) {
+            const double* __restrict__ src = upart + e;
+            const int64_t st = (int64_t)rank * 3;
+            int q = 0;
+            for (; q + 4 <= nsplit; q += 4) {
+                v0 += src[q * st];
+                v1 += src[(q + 1) * st];
+                v2 += src[(q + 2) * st];
+                v3 += src[(q + 3) * st];
+            }
+            for (; q < nsplit; ++q) v0 += src[q * st];
+        }
+        u[e] = (v0 + v1) + (v2 + v3);
+    }
     if (e >= rp * rp) return;
     const int a = (int)(e / rp), b = (int)(e % rp);
     double v;
@@ -572,11 +673,19 @@ __global__ __launch_bounds__(kBlock) void k_lr_gram_reduce(const double* __restr
         const int hi = a > b ? a : b, lo = a > b ? b : a;  // lower triangle holds (hi, lo)
         const int ta = hi / GT, tb = lo / GT;
         const int tile = ta * (ta + 1) / 2 + tb;
-        // inside a diagonal tile both orders exist; off the diagonal only (row in ta, column in tb)
         const int r = hi - ta * GT, c = lo - tb * GT;
         const double* __restrict__ src = part + (int64_t)tile * (GT * GT) + r * GT + c;
-        v = 0.0;
-        for (int q = 0; q < nsplit; ++q) v += src[(int64_t)q * ntile * (GT * GT)];
+        const int64_t st = (int64_t)ntile * (GT * GT);
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int q = 0;
+        for (; q + 4 <= nsplit; q += 4) {
+            v0 += src[q * st];
+            v1 += src[(q + 1) * st];
+            v2 += src[(q + 2) * st];
+            v3 += src[(q + 3) * st];
+        }
+        for (; q < nsplit; ++q) v0 += src[q * st];
+        v = (v0 + v1) + (v2 + v3);
         if (a == b) v += lmd * params[13];
     } else {
         v = a == b ? 1.0 : 0.0;
@@ -603,7 +712,7 @@ inline dim3 grid1(int64_t n) { return dim3((unsigned)prg::ceil_div(n, kBlock)); 
 // blocked Cholesky S = L L^T (lower, in place): outer panels of 512 columns, inner blocks of 128; the inverses
 // of the diagonal blocks go to linv.  Enqueued on the plan stream (+ the side stream of the look-ahead); on
 // return the plan stream waits for everything.
-int cholesky_lookahead(prg_cpd* h, double* S, int64_t mp, double* linv, int* info) {
+int cholesky_lookahead(prg_cpd* h, double* S, int64_t mp, double* linv, int* info, int64_t nreal) {
     hipStream_t st = h->stream;
     // Look-ahead over two streams: the trailing update of outer panel J is split into U1 (the 512 columns of
     // the next panel, plan stream) and U2 (everything to the right, side stream), so the latency-bound panel
@@ -626,7 +735,7 @@ int cholesky_lookahead(prg_cpd* h, double* S, int64_t mp, double* linv, int* inf
         const int64_t kend = std::min<int64_t>(K0 + NBO, mp);
         for (int64_t k0 = K0; k0 < kend; k0 += NB) {
             double* lk = linv + (size_t)(k0 / NB) * NB * NB;
-            k_potrf_inv<<<1, kBlock, lds, st>>>(S, mp, k0, lk, info);
+            k_potrf_inv<<<1, kBlock, lds, st>>>(S, mp, k0, lk, info, nreal);
             const int64_t below = (mp - k0 - NB) / NB;
             if (below > 0) {
                 double* a21 = S + (k0 + NB) * mp + k0;
@@ -700,17 +809,18 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
     const int rank = h->f_rank;
     const int64_t rp = prg::round_up(rank, NB), nblk = rp / NB;
     const int tiles1 = (int)prg::ceil_div(rank, GT), ntile = tiles1 * (tiles1 + 1) / 2;
-    // split the sum over the points so that the chip is full (~1024 workgroups), in whole slabs
-    int nsplit = (int)std::min<int64_t>(std::max(1, 1024 / ntile), prg::ceil_div(m, 4 * GS));
+    // split the sum over the points so that the chip is full (~512 workgroups of >= 8 slabs), in whole slabs
+    int nsplit = (int)std::min<int64_t>(std::max(1, 512 / ntile), prg::ceil_div(m, 8 * GS));
     const int64_t chunk = prg::round_up(prg::ceil_div(m, nsplit), GS);
     nsplit = (int)prg::ceil_div(m, chunk);
     const size_t n_s = (size_t)rp * rp, n_linv = (size_t)nblk * NB * NB, n_vec = (size_t)ld * 3,
-                 n_part = (size_t)nsplit * ntile * GT * GT;
+                 n_part = (size_t)nsplit * ntile * GT * GT + (size_t)nsplit * rank * 3;
     const int tr_blk = (int)prg::ceil_div(m, kBlock);
-    PRG_TRY(ensure_solve_workspace(h, (n_s + n_linv + n_part + 7 * n_vec + (size_t)rp * 3 + 2 * (size_t)tr_blk + 16) * sizeof(double)));
+    PRG_TRY(ensure_solve_workspace(h, (n_s + n_linv + n_part + 6 * n_vec + (size_t)rp * 3 + 2 * (size_t)tr_blk + 16) * sizeof(double)));
     double* S = h->nr_solve;
     double* linv = S + n_s;
     double* part = linv + n_linv;
+    double* upart = part + (size_t)nsplit * ntile * GT * GT;
     double* b3 = part + n_part;
     double* sp = b3 + n_vec;
     double* fz = sp + n_vec;
@@ -718,46 +828,51 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
     double* r3 = gb + n_vec;
     double* dw = r3 + n_vec;
     double* z = dw + n_vec;  // [rp][3]
-    double* trpart = z + (size_t)rp * 3 + n_vec;
+    double* trpart = z + (size_t)rp * 3;
     int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
     hipStream_t st = h->stream;
+    const dim3 ggrid((unsigned)ntile, (unsigned)nsplit);
+    const dim3 rgrid = grid1(std::max<int64_t>((int64_t)rp * rp, rp * 3));
 
     PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
     k_rhs<<<grid1(ld), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, ld, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
                                         h->nr_alpha, h->params, b3, sp);
-    k_lr_gram<<<dim3((unsigned)ntile, (unsigned)nsplit), kBlock, 0, st>>>(h->F, ld, m, rank, sp, chunk, part);
-    k_lr_gram_reduce<<<grid1((int64_t)rp * rp), kBlock, 0, st>>>(part, ntile, nsplit, rank, rp, h->params, lmd, S);
-    PRG_TRY(cholesky_lookahead(h, S, rp, linv, info));
-    auto solve_with_factor = [&](const double* rhs, double* wout) -> int {
-        if (rp > rank) PRG_HIP(hipMemsetAsync(z + (size_t)rank * 3, 0, (size_t)(rp - rank) * 3 * sizeof(double), st));
-        PRG_TRY(prg::lowrank_ft3(h, rhs, z));        // F^T rhs
-        PRG_TRY(cholesky_solve3(h, S, rp, linv, z));  // z = (c I + F^T D F)^-1 F^T rhs
-        PRG_TRY(prg::lowrank_apply(h, z, fz));        // F z
-        k_lr_form_w<<<grid1(m), kBlock, 0, st>>>(rhs, sp, fz, m, h->params, lmd, wout);
-        PRG_HIP(hipGetLastError());
-        return PRG_OK;
-    };
-    PRG_TRY(solve_with_factor(b3, h->W));
-    const int nrefine = h->nr_alpha > 0.0 ? 2 : 0;  // (see prg_cpd_mstep_nonrigid)
+    // S = c I + F^T D F and z = F^T B in one pass over the factor
+    k_lr_gram<<<ggrid, kBlock, 0, st>>>(h->F, ld, m, rank, sp, b3, chunk, part, upart);
+    k_lr_gram_reduce<<<rgrid, kBlock, 0, st>>>(part, upart, ntile, nsplit, rank, rp, h->params, lmd, S, z);
+    PRG_TRY(cholesky_lookahead(h, S, rp, linv, info, rank));
+    PRG_TRY(cholesky_solve3(h, S, rp, linv, z));  // z = (c I + F^T D F)^-1 F^T B
+    double* gw = h->nr_work;                      // [M][3]: G W, kept for the next E-step's transform
+    // W = (B - D F z) / c ... and G W = F (F^T W) = F z exactly: F^T W = (F^T B - F^T D F z) / c = (S z - (S - c I) z) / c
+    PRG_TRY(prg::lowrank_apply(h, z, gw));
+    k_lr_form_w<<<grid1(m), kBlock, 0, st>>>(b3, sp, gw, m, h->params, lmd, h->W);
+    // With correspondence priors the diagonal scaling spans sigma2/alpha ~ 1e7 and the push-through form loses digits
+    // to cancellation: two steps of fp64 iterative refinement on the original system (see prg_cpd_mstep_nonrigid)
+    const int nrefine = h->nr_alpha > 0.0 ? 2 : 0;
     for (int it = 0; it < nrefine; ++it) {
         PRG_TRY(prg::nonrigid_gw(h, h->W, gb));
         k_residual<<<grid1(ld), kBlock, 0, st>>>(b3, sp, gb, h->W, m, ld, h->params, lmd, r3);
-        PRG_TRY(solve_with_factor(r3, dw));
+        if (rp > rank) PRG_HIP(hipMemsetAsync(z + (size_t)rank * 3, 0, (size_t)(rp - rank) * 3 * sizeof(double), st));
+        PRG_TRY(prg::lowrank_ft3(h, r3, z));
+        PRG_TRY(cholesky_solve3(h, S, rp, linv, z));
+        PRG_TRY(prg::lowrank_apply(h, z, fz));
+        k_lr_form_w<<<grid1(m), kBlock, 0, st>>>(r3, sp, fz, m, h->params, lmd, dw);
         k_axpy3<<<grid1(m * 3), kBlock, 0, st>>>(dw, m, h->W);
     }
-    PRG_TRY(prg::nonrigid_gw(h, h->W, gb));
-    k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, gb, m, trpart);
+    if (nrefine > 0) PRG_TRY(prg::nonrigid_gw(h, h->W, gw));
+    k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, gw, m, trpart);
     k_nonrigid_finish<<<1, 64, 0, st>>>(trpart, tr_blk, h->moments, h->params, h->D);
     PRG_HIP(hipGetLastError());
-    int host_info = 0;
-    PRG_HIP(hipMemcpyAsync(&host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
+    h->gw_valid = true;
+    if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
+    int* host_info = reinterpret_cast<int*>(h->pinned + 48);
+    PRG_HIP(hipMemcpyAsync(host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
-    PRG_REQUIRE(host_info == 0, PRG_ERR_STATE,
+    PRG_REQUIRE(*host_info == 0, PRG_ERR_STATE,
                 "prg_cpd_mstep_nonrigid: the reduced system is not positive definite at pivot %d (sigma2 or lmd <= 0?)",
-                host_info - 1);
+                *host_info - 1);
     return PRG_OK;
 }
-
 
 }  // namespace
 
@@ -798,7 +913,7 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
                                         h->nr_alpha, h->params, b3, sp);
     k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, h->params, lmd, S);
 
-    PRG_TRY(cholesky_lookahead(h, S, mp, linv, info));
+    PRG_TRY(cholesky_lookahead(h, S, mp, linv, info, m));
     // w = (rhs - D^1/2 S^-1 D^1/2 (G rhs)) / c with the factor above: two blocked triangular sweeps, 3 RHS
     auto solve_with_factor = [&](const double* rhs, double* wout) -> int {
         PRG_TRY(prg::nonrigid_gw(h, rhs, gb));                    // G rhs
@@ -830,10 +945,11 @@ extern "C" int prg_cpd_mstep_nonrigid(prg_cpd* h, double lmd) {
         PRG_TRY(solve_with_factor(r3, dw));
         k_axpy3<<<grid1(m * 3), kBlock, 0, st>>>(dw, m, h->W);
     }
-    PRG_TRY(prg::nonrigid_gw(h, h->W, gb));                     // G W
-    k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, gb, m, trpart);
+    PRG_TRY(prg::nonrigid_gw(h, h->W, h->nr_work));            // G W, kept for the next E-step's transform
+    k_traces<<<tr_blk, kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, h->nr_work, m, trpart);
     k_nonrigid_finish<<<1, 64, 0, st>>>(trpart, tr_blk, h->moments, h->params, h->D);
     PRG_HIP(hipGetLastError());
+    h->gw_valid = true;
     int host_info = 0;
     PRG_HIP(hipMemcpyAsync(&host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
     PRG_HIP(hipStreamSynchronize(st));
@@ -960,7 +1076,7 @@ extern "C" int prg_cpd_bcpd_solve(prg_cpd* h, double lmd, double cfac, const dou
                                             sp);
     k_build_s<<<dim3((unsigned)nblk, (unsigned)nblk), kBlock, 0, st>>>(h->G, m, mp, sp, nullptr, lmd / cfac, S);
     k_build_bt<<<dim3((unsigned)prg::ceil_div(mp, kBlock), (unsigned)std::min<int64_t>(mp, 32768)), kBlock, 0, st>>>(h->G, m, mp, sp, wt);
-    PRG_TRY(cholesky_lookahead(h, S, mp, linv, info));
+    PRG_TRY(cholesky_lookahead(h, S, mp, linv, info, m));
 
     // Wt <- Wt L^-T, left-looking over panels of k 128-column blocks: one K-deep rectangular update with everything
     // to the left of the panel, then k (update inside the panel, multiply by the inverted diagonal block) steps.

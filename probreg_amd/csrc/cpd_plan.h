@@ -78,7 +78,7 @@ struct prg_cpd {
     double* W = nullptr;       // [M][3] float64 (row-major, 3 columns always)
     // ... or its pivoted-Cholesky factor G = F F^T (non-rigid CPD): F[k * f_ld + i], k < f_rank
     double* F = nullptr;
-    int64_t f_ld = 0;          // round_up(M, 256)
+    int64_t f_ld = 0;          // round_up(M, 256) + 32
     int f_rank = 0, f_cap = 0;
     int nr_solver = 1;         // 1: low-rank factor when the rank allows (default), 0: dense G + M x M Cholesky
     int nr_max_rank = 0;       // 0: min(2048, M / 2)
@@ -86,6 +86,7 @@ struct prg_cpd {
     double beta = 0.0;
     bool nonrigid = false;
     double* nr_work = nullptr;  // [16 M] doubles: G.W product and scratch
+    bool gw_valid = false;      // nr_work[0, 3M) holds G W of the current W (left by the M-step, consumed by the transform)
     size_t nr_work_bytes = 0;
     double* nr_solve = nullptr;  // M-step workspace: S (fp64 M x M), block inverses, vectors
     size_t nr_solve_bytes = 0;
