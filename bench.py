@@ -460,7 +460,7 @@ def bench_filterreg(workload, steps, warmup):
 def _slim(line):
     """What an `other_workloads` entry keeps of a workload's own line."""
     keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "result",
-            "dense_it_s", "late_it_s")
+            "dense_it_s", "late_it_s", "kernel_ms", "kernel_factor", "dense_solver")
     out = {k: line[k] for k in keep if k in line}
     rf = out.get("roofline", {})
     for k in ("how", "effective_hbm", "late_regime"):
@@ -516,7 +516,7 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(n)
         if world == 1 and args.workload == "rigid_100k" and not args.no_other_workloads:
             others = {}
-            for name, fn, k, w in (("affine_200k", bench_cpd, 5, 1), ("nonrigid_50k", bench_nonrigid, 2, 1),
+            for name, fn, k, w in (("affine_200k", bench_cpd, 5, 1), ("nonrigid_50k", bench_nonrigid, 20, 2),
                                    ("filterreg_500k", bench_filterreg, 20, 3)):
                 try:
                     others[name] = _slim(fn(name, k, w))
