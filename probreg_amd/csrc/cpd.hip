@@ -275,7 +275,8 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
     if (seed_mode) {
         // matrix-core column pass: every segment's sum is relative to the SAME offset, known before the sweep
         // (prg::col_seed_offset from the previous E-step's minimum, still in colmin[i], and this E-step's motion)
-        goff = prg::col_seed_offset(kkf, colmin[i], __uint_as_float(stat[slot]));
+        // (seed_mode 2: the first E-step's sweep ran without offsets)
+        goff = seed_mode == 2 ? 0.f : prg::col_seed_offset(kkf, colmin[i], __uint_as_float(stat[slot]));
         for (int s0 = 0; s0 < nseg; ++s0) {
             const float2 p = colpart[(int64_t)s0 * ncap + i];
             gmin = fminf(gmin, p.x);
@@ -738,18 +739,24 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
 int cap_for(int64_t n) { return (int)prg::round_up(n + 64 * prg::kSuper + 1024, 1024); }
 
 // Morton (Z-curve) order of a cloud: sorted position -> original index (morton.h), uploaded as the plan's permutation.
-int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev, double* ext2 = nullptr) {
+int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev, double* ext2 = nullptr,
+                       float* box = nullptr) {
     std::vector<float> host((size_t)n * dim);
     PRG_HIP(hipMemcpy(host.data(), pts_hd, host.size() * sizeof(float), hipMemcpyDefault));
-    if (ext2) {  // squared diagonal of the cloud's bounding box (scale of the dense-regime criterion)
+    if (ext2) {  // squared diagonal of the cloud's bounding box (scale of the dense-regime criterion); box = lo.xyz, hi.xyz
         *ext2 = 0.0;
-        for (int k = 0; k < dim; ++k) {
+        for (int k = 0; k < 3; ++k) {
             float lo = INFINITY, hi = -INFINITY;
-            for (int64_t i = 0; i < n; ++i) {
+            for (int64_t i = 0; i < n && k < dim; ++i) {
                 lo = std::min(lo, host[(size_t)i * dim + k]);
                 hi = std::max(hi, host[(size_t)i * dim + k]);
             }
+            if (k >= dim) lo = hi = 0.f;
             *ext2 += (double)(hi - lo) * (double)(hi - lo);
+            if (box) {
+                box[k] = lo;
+                box[3 + k] = hi;
+            }
         }
     }
     const std::vector<int> perm = prg::morton_order(host.data(), n, dim);
@@ -862,8 +869,8 @@ int prg_cpd_set_source(prg_cpd* h, const float* source_hd, int64_t m, int dim) {
     if (cap != h->Mcap || !h->zmeta) {
         PRG_TRY(ensure_exact(&h->zmeta, (size_t)(cap / prg::kGroup) * 8));
         if (!h->motion) {
-            PRG_TRY(ensure_exact(&h->motion, 8));
-            PRG_HIP(hipMemsetAsync(h->motion, 0, 8 * sizeof(unsigned), h->stream));
+            PRG_TRY(ensure_exact(&h->motion, 16));
+            PRG_HIP(hipMemsetAsync(h->motion, 0, 16 * sizeof(unsigned), h->stream));
         }
         PRG_TRY(ensure_exact(&h->rorig, (size_t)(cap / prg::kMfmaWgPoints) + 4));
         PRG_TRY(ensure_exact(&h->zchunk, (size_t)(cap / prg::kSuper) * 8));
@@ -950,15 +957,15 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
         PRG_HIP(hipMemsetAsync(h->colmin, 0, ((size_t)cap + (size_t)cap / prg::kGroup) * sizeof(float), h->stream));
     }
     if (!h->motion) {
-        PRG_TRY(ensure_exact(&h->motion, 8));
-        PRG_HIP(hipMemsetAsync(h->motion, 0, 8 * sizeof(unsigned), h->stream));
+        PRG_TRY(ensure_exact(&h->motion, 16));
+        PRG_HIP(hipMemsetAsync(h->motion, 0, 16 * sizeof(unsigned), h->stream));
     }
     h->N = n_local;
     h->Nglobal = n_global;
     h->D = dim;
     h->Ncap = cap;
     if (h->opt_sort_tgt) {
-        PRG_TRY(morton_permutation(h, target_hd, n_local, dim, &h->perm_tgt, &h->text2));
+        PRG_TRY(morton_permutation(h, target_hd, n_local, dim, &h->perm_tgt, &h->text2, h->tbox));
     } else if (h->perm_tgt) {
         (void)hipFree(h->perm_tgt);
         h->perm_tgt = nullptr;
@@ -1152,10 +1159,13 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // where the culled VALU sweeps skip most of the pairs (|kk| * extent^2 above the bound) the registration stays on
     // them and never synchronises again.
     bool use_mfma = false, row_mfma = false;  // column pass / row pass on the matrix cores
+    bool first_mfma = false;                  // ... column pass without seeds (first E-step of a registration)
     if (mfma_possible && !h->mfma_off) {
+        // chunk boxes of this E-step's transformed source (the matrix-core sweeps cull with them) and its bounding box
+        prg::launch_chunk_meta_bbox(h);
         if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
         float* st = reinterpret_cast<float*>(h->pinned + 40);
-        PRG_HIP(hipMemcpyAsync(st, h->motion, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        PRG_HIP(hipMemcpyAsync(st, h->motion, 14 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         PRG_HIP(hipMemcpyAsync(h->pinned + 39, h->params + 13, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         PRG_HIP(hipStreamSynchronize(h->stream));
         const double sigma2 = h->pinned[39], nk = kLog2e / (2.0 * sigma2);
@@ -1167,17 +1177,25 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         const double ext2 = std::max(h->sext2, h->text2);
         const bool dense = ok && (forced || nk * ext2 < h->dense_bound);
         if (!dense) h->mfma_off = true;
-        // the column pass needs the previous E-step's column minima for its exponent offsets; the row pass does not.
+        // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or -
+        // first E-step, no minima yet - none at all when the farthest target / source pair is still above the flush
+        // threshold (farthest corners of the two bounding boxes: every term of every column is >= 2^-110).
         // The culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
         // (profiles/r2_mfma_cull_vs_valu_100k.log): it leaves at 1/8 of the bound.
-        use_mfma = dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0;
+        double far2 = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double a = fabs((double)h->tbox[3 + k] - (double)st[8 + k]), b = fabs((double)st[11 + k] - (double)h->tbox[k]);
+            far2 += std::max(a, b) * std::max(a, b);
+        }
+        first_mfma = dense && !h->have_colmin && std::isfinite(far2) && nk * far2 < 110.0;
+        use_mfma = first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0);
         row_mfma = dense && (forced || nk * ext2 < 0.125 * h->dense_bound);
     }
     h->last_estep_mfma = use_mfma;
     h->wg_col_pairs = h->wg_row_pairs = 128.0 * prg::kGroup;  // a (wave, group) block of the culled vector-pipe sweeps
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_mfma)
-        prg::launch_colpass_mfma(h, mfma_seg);
+        prg::launch_colpass_mfma(h, mfma_seg, first_mfma);
     else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, h->have_colmin && !h->srcw);  // the seed bound assumes unweighted distances
     else if (ra < 0)
@@ -1188,7 +1206,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, use_mfma ? PAm : PA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
                                                       h->colmin + h->Ncap,
-                                                      use_cull ? h->tmeta : nullptr, use_mfma ? 1 : 0, h->motion, slot);
+                                                      use_cull ? h->tmeta : nullptr, use_mfma ? (first_mfma ? 2 : 1) : 0, h->motion, slot);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
         prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap));

@@ -122,9 +122,19 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
     double* sblk = s + k0 * ld + k0;
     // active part of the block, in whole panels of 8 (the rest is identity and stays identity)
     const int nb = (int)((nreal - k0 >= NB) ? NB : ((nreal - k0 + PB - 1) / PB) * PB);
-    for (int idx = tid; idx < NB * NB; idx += kBlock) {
-        const int i = idx >> 7, j = idx & 127;
-        if (i < nb && j < nb) a[i * LDP + j] = sblk[(int64_t)i * ld + j];
+    // block -> LDS, 16 loads in flight per thread (a load / LDS-store pair per trip would pay one global round trip each)
+    for (int base = 0; base < NB * NB; base += 16 * kBlock) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * kBlock + tid, i = idx >> 7, j = idx & 127;
+            v[u] = (i < nb && j < nb) ? sblk[(int64_t)i * ld + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * kBlock + tid, i = idx >> 7, j = idx & 127;
+            if (i < nb && j < nb) a[i * LDP + j] = v[u];
+        }
     }
     // ---------------- Cholesky, 16 panels of 8 columns ----------------
     for (int jb = 0; jb < nb; jb += PB) {

@@ -46,9 +46,10 @@ struct prg_cpd {
     float* tmeta = nullptr;     // [Ncap/32][8] per group of 32 target points: lo.xyz, hi.xyz, max b_n, min b_n
     float* colmin = nullptr;    // [Ncap] min_m d^2 per column from the previous E-step (seed of the cull bound),
                                 // followed by [Ncap/32] per-group maxima of it
-    unsigned* motion = nullptr; // [8] float bits, slot = parity of the E-step: [0,1] max_m |z_new - z_old| of the transform,
+    unsigned* motion = nullptr; // [16] float bits, slot = parity of the E-step: [0,1] max_m |z_new - z_old| of the transform,
                                 // [4,5] largest column minimum of the E-step (what the host needs to decide whether the
-                                // matrix-core column pass may run)
+                                // matrix-core column pass may run); [8..13] bounding box of the transformed
+                                // source (lo.xyz, hi.xyz) of the current E-step
     bool have_colmin = false;
     // matrix-core (dense regime) sweeps
     float4* rorig = nullptr;    // [Mcap/512] origin of each 512-row block of the last matrix-core row pass
@@ -60,6 +61,7 @@ struct prg_cpd {
     bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
     bool last_estep_mfma = false;
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
+    float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)
     // measurement hook: evaluated (wave, group) blocks per workgroup of the last culled column / row pass
     // ([0, wg_cap) column pass, [wg_cap, 2 wg_cap) row pass); wg_col / wg_row = workgroups of the last launches,
     // dense_pairs_* = pairs covered by the last NON-culled launches (0 when the culled kernels ran)

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          int64_t m_total, int64_t n_total,
                                                          const double* __restrict__ params,
                                                          float2* __restrict__ colpart, int64_t ncap,
-                                                         unsigned* __restrict__ wgcount) {
+                                                         unsigned* __restrict__ wgcount, int first) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n0wg = (int64_t)blockIdx.x * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     float thr = INFINITY;  // skip a chunk when its box is farther than thr (squared) from the patch
     if (n0wg + kWgPoints <= n_total && wg_box(tmeta, n0wg, n_total, lane, lo, hi)) {
         o = make_float4(0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), 0.f);
+      if (!first) {  // (first E-step of a registration: no minima to bound anything with)
         // as in k_colpass_cull: (sqrt(largest column minimum of the previous E-step) + source motion)^2 bounds this
         // E-step's minima from above; a chunk beyond that by 127 / |kk| adds < 2^-127 of any column's largest term
         float cmax = colmin_g[n0wg / 32 + (lane & 15)];
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
         for (int sh = 1; sh < 16; sh <<= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, sh, 64));
         const float r = sqrtf(cmax) + mo;
         thr = r * r * 1.00001f + (-127.0f) / kk;
+      }
     } else {
         o = tgt4[n0wg];
         o.w = 0.f;
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
         const float4 x = tgt4[n0 + 16 * t + j];
         const float xx = x.x - o.x, xy = x.y - o.y, xz = x.z - o.z;
         const float xsq = fmaf(xz, xz, fmaf(xy, xy, xx * xx));
-        off[t] = prg::col_seed_offset(kk, colmin_prev[n0 + 16 * t + j], mo);
+        off[t] = first ? 0.f : prg::col_seed_offset(kk, colmin_prev[n0 + 16 * t + j], mo);
         bx[t] = owned_operand(k, kk, xx, xy, xz, fmaf(kk, xsq, off[t]));
         s[t] = 0.f;
         tm[t] = -INFINITY;
@@ -392,6 +394,63 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta(const BoxMeta* __restrict
     cmeta[c] = o;
 }
 
+// the same for the transformed source, plus the bounding box of its m real points -> stat[8..13] (lo.xyz, hi.xyz as float
+// bits): one workgroup, the host reads the box back with the other per-E-step statistics (cpd.hip, estep_impl)
+__global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __restrict__ gmeta, int64_t nchunk,
+                                                            BoxMeta* __restrict__ cmeta, const float4* __restrict__ pts,
+                                                            int64_t m, unsigned* __restrict__ stat) {
+    __shared__ float sh[kBlock / 64][6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t c = threadIdx.x; c < nchunk; c += kBlock) {
+        BoxMeta o = gmeta[c * 8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const BoxMeta q = gmeta[c * 8 + g];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o.lo[k] = fminf(o.lo[k], q.lo[k]);
+                o.hi[k] = fmaxf(o.hi[k], q.hi[k]);
+            }
+            o.aux = fmaxf(o.aux, q.aux);
+            if ((c * 8 + g + 1) * 32 <= m) {  // a group of real points only
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = fminf(lo[k], q.lo[k]);
+                    hi[k] = fmaxf(hi[k], q.hi[k]);
+                }
+            }
+        }
+        cmeta[c] = o;
+    }
+    const int64_t tail = (m / 32) * 32 + threadIdx.x;  // the real points of the last, partly padded group
+    if (threadIdx.x < 32 && tail < m) {
+        const float4 p = pts[tail];
+        lo[0] = fminf(lo[0], p.x); hi[0] = fmaxf(hi[0], p.x);
+        lo[1] = fminf(lo[1], p.y); hi[1] = fmaxf(hi[1], p.y);
+        lo[2] = fminf(lo[2], p.z); hi[2] = fmaxf(hi[2], p.z);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int sft = 1; sft <= 32; sft <<= 1) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], sft, 64));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], sft, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sh[threadIdx.x >> 6][k] = lo[k];
+            sh[threadIdx.x >> 6][3 + k] = hi[k];
+        }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = sh[0][threadIdx.x];
+        for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
+        stat[8 + threadIdx.x] = __float_as_uint(v);
+    }
+}
+
 }  // namespace
 
 namespace prg {
@@ -431,14 +490,19 @@ void launch_chunk_meta(prg_cpd* h, const float* gmeta, int64_t cap, float* cmeta
                                                                              reinterpret_cast<BoxMeta*>(cmeta));
 }
 
-void launch_colpass_mfma(prg_cpd* h, int S) {
+void launch_chunk_meta_bbox(prg_cpd* h) {
+    k_chunk_meta_bbox<<<1, kBlock, 0, h->stream>>>(reinterpret_cast<const BoxMeta*>(h->zmeta), h->Mcap / kChunk,
+                                                  reinterpret_cast<BoxMeta*>(h->zchunk), h->z4, h->M, h->motion);
+}
+
+void launch_colpass_mfma(prg_cpd* h, int S, bool first) {
     const int cps = mfma_chunks_per_seg(h->N, h->M, S);
     dim3 grid((unsigned)ceil_div(h->N, kWgPoints), (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
-    launch_chunk_meta(h, h->zmeta, h->Mcap, h->zchunk);  // boxes of this E-step's transformed source
+    // (zchunk: boxes of this E-step's transformed source, written by launch_chunk_meta_bbox before the engine decision)
     k_colpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
                                                    h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
-                                                   h->colpart, h->Ncap, h->wgcount);
+                                                   h->colpart, h->Ncap, h->wgcount, first ? 1 : 0);
     h->wg_col = (int64_t)grid.x * grid.y;
     h->wg_col_pairs = (double)kWgPoints * kChunk;
     h->dense_pairs_col = 0.0;

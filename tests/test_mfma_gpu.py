@@ -73,10 +73,10 @@ def test_auto_engine_registration_matches_oracle_and_switches_engines():
         engines.append(plan.last_estep_engine())
         plan.mstep(_lib.PRG_TF_RIGID, True)
     res = reg._result_from_params(plan.get_params())
-    assert engines[0] == 0            # no column minima yet: the first E-step is the vector-pipe one
+    assert engines[0] == 1            # first E-step: no column minima yet, but sigma2 is large enough for zero offsets
     assert sum(engines) >= 4          # the dense regime's column passes ran on the matrix cores ...
     assert engines[-1] == 0           # ... and the late regime did not
-    first_off = engines[1:].index(0) + 1
+    first_off = engines.index(0)
     assert all(e == 0 for e in engines[first_off:])  # once left, never re-entered
     params = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
     sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
@@ -110,7 +110,7 @@ def test_forced_matrix_core_engine_through_a_whole_dense_phase_2d():
         plan.estep(0.05)
         used += plan.last_estep_engine()
         plan.mstep(_lib.PRG_TF_AFFINE, True)
-    assert used == 7
+    assert used == 8  # including the first E-step (zero offsets: sigma2 is large)
     res = reg._result_from_params(plan.get_params())
     p, s2, q, _ = co.registration("affine", src, tgt, w=0.05, maxiter=8, tol=-1.0, closed_form_init=True)
     assert rel_err(res.transformation.b, p["b"]) < TOL_TF

@@ -39,5 +39,8 @@ for world in (1, 2, 4, 8):
             p2.estep(0.0)
         torch.cuda.synchronize()
         out.append("it%2d %.3f ms" % (it, (time.perf_counter() - t0) / reps * 1e3))
+        if world == 8 or world == 1:  # where the time of one E-step goes (HIP events between the kernels)
+            ms = p2.estep_timed(0.0)
+            out[-1] += " [" + " ".join("%s %.0f" % (k[:5], 1e3 * v) for k, v in ms.items()) + " us; mfma col %d]" % p2.last_estep_engine()
     print("world %d: back-to-back E-step of rank 0 | %s" % (world, " | ".join(out)))
     p2.close()
