@@ -79,6 +79,9 @@ struct Lattice {
     int* nb = nullptr;                  // [2][d+1][size] blur neighbours (dense id or -1)
     int* count = nullptr;               // device counters: [0] vertices, [1] table overflow flag
     int64_t cap_used = 0;               // slots of the table in use for the current build (power of two <= cap)
+    // d <= 3: a table entry is (generation << 48) | packed key; an entry of another generation counts as empty, so a
+    // build starts by taking the next generation instead of clearing the table (gen 0 = freshly zeroed memory)
+    unsigned gen = 0, gen2 = 0;
     int prev_size[2] = {0, 0};          // last lattice size without / with blur: sizes the next hash table
     double* pinned = nullptr;           // 64 doubles of pinned host memory: small device->host read-backs (a copy
                                         // into pageable memory costs ~100 us of staging, this one a few us)
@@ -111,11 +114,14 @@ template <int D, bool FR>
 __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, const FrFeat fr, int64_t first,
                                                   int64_t n, float s0, float s1, float s2,
                                                   unsigned long long* __restrict__ tkeys, unsigned long long mask,
-                                                  int* __restrict__ pslot, float* __restrict__ bary,
-                                                  int* __restrict__ overflow) {
+                                                  unsigned gen, int* __restrict__ pslot, float* __restrict__ bary,
+                                                  int* __restrict__ count, int* __restrict__ slot_id,
+                                                  unsigned long long* __restrict__ dkeys) {
     const int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // points [first, n)
     if (i >= n) return;
     constexpr int D1 = D + 1;
+    const unsigned long long gbits = (unsigned long long)gen << 48;
+    const int lane = threadIdx.x & 63;
     const float scale[3] = {s0, s1, s2};
     float f[D];
     if (FR) {
@@ -189,6 +195,14 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
         }
     }
     bar[0] = __fadd_rn(bar[0], __fadd_rn(1.0f, bar[D1]));
+    unsigned nclaim_mask = 0;  // rounds in which this lane created a vertex, with the slot and key of each
+    int cslot[D1];
+    unsigned long long ckey[D1];
+#pragma unroll
+    for (int r = 0; r < D1; ++r) {
+        cslot[r] = 0;
+        ckey[r] = 0;
+    }
 #pragma unroll
     for (int r = 0; r < D1; ++r) {
         short key[D];
@@ -199,23 +213,66 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
             const int can = (rk <= D - r) ? r : r - D1;
             key[k] = (short)(rem0[k] + (float)can);
         }
-        const unsigned long long pk = pack_key(key, D);
+        const unsigned long long pk = pack_key(key, D), mine = pk | gbits;
         unsigned long long slot = mix64(pk) & mask;
+        bool claimed = false;
         for (int probes = 0;; ++probes) {
             if (probes > 4096) {  // table (sized from the previous lattice) is too small: the host rebuilds
-                *overflow = 1;
+                count[1] = 1;
                 slot = 0;
                 break;
             }
             // plain (L2-coherent) read first: once a vertex exists, the ~N/L points sharing it never issue an
             // atomic - a CAS storm on a few hundred hot keys costs milliseconds when sigma is large
             unsigned long long cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == kEmpty) cur = atomicCAS(&tkeys[slot], kEmpty, pk);
-            if (cur == kEmpty || cur == pk) break;
+            if ((unsigned)(cur >> 48) != gen) {  // empty, or left over from an earlier build
+                const unsigned long long old = atomicCAS(&tkeys[slot], cur, mine);
+                if (old == cur) {
+                    claimed = true;
+                    break;
+                }
+                cur = old;  // somebody of this build got there first
+            }
+            if (cur == mine) break;
             slot = (slot + 1) & mask;
+        }
+        if (claimed) {
+            nclaim_mask |= 1u << r;
+            cslot[r] = (int)slot;
+            ckey[r] = pk;
         }
         pslot[i * D1 + r] = (int)slot;
         bary[i * D1 + r] = bar[r];
+    }
+    // whoever created a vertex numbers it (no scan of the table afterwards): ONE counter update per wave - the lanes'
+    // claims of all D + 1 rounds are ranked with ballots, the first claiming lane fetches the base
+    unsigned long long bal[D1];
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < D1; ++r) {
+        bal[r] = __ballot((nclaim_mask >> r) & 1u);
+        total += __popcll(bal[r]);
+    }
+    if (total) {
+        unsigned long long any = 0;
+#pragma unroll
+        for (int r = 0; r < D1; ++r) any |= bal[r];
+        const int leader = __ffsll((long long)any) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(count, total);
+        base = __shfl(base, leader, 64);
+        if (slot_id) {
+            int before = 0;
+#pragma unroll
+            for (int r = 0; r < D1; ++r) {
+                if ((nclaim_mask >> r) & 1u) {
+                    const int id = base + before + __popcll(bal[r] & ((1ull << lane) - 1ull));
+                    slot_id[cslot[r]] = id;
+                    dkeys[id] = ckey[r];
+                }
+                before += __popcll(bal[r]);
+            }
+        }
     }
 }
 
@@ -405,24 +462,6 @@ __global__ __launch_bounds__(kBlock) void k_compact(const unsigned long long* __
     }
 }
 
-// Number of occupied slots only (the with_blur decision of filterreg.py:90-91 needs nothing else).
-__global__ __launch_bounds__(kBlock) void k_count_occupied(const unsigned long long* __restrict__ tkeys, int64_t cap,
-                                                           int* __restrict__ count) {
-    __shared__ int wave_cnt[kBlock / 64];
-    int c = 0;
-    for (int64_t s = (int64_t)blockIdx.x * kBlock + threadIdx.x; s < cap; s += (int64_t)gridDim.x * kBlock)
-        c += tkeys[s] != kEmpty;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-        for (int w = 0; w < kBlock / 64; ++w) tot += wave_cnt[w];
-        if (tot) atomicAdd(count, tot);
-    }
-}
-
 __global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int64_t total,
                                                     const int* __restrict__ slot_id) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -430,12 +469,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int
 }
 
 __device__ __forceinline__ int lookup(const unsigned long long* __restrict__ tkeys, unsigned long long mask,
-                                      const int* __restrict__ slot_id, unsigned long long pk) {
+                                      const int* __restrict__ slot_id, unsigned long long pk, unsigned gen) {
     unsigned long long slot = mix64(pk) & mask;
+    const unsigned long long want = pk | ((unsigned long long)gen << 48);
     for (;;) {
         const unsigned long long k = tkeys[slot];
-        if (k == pk) return slot_id[slot];
-        if (k == kEmpty) return -1;
+        if (k == want) return slot_id[slot];
+        if ((unsigned)(k >> 48) != gen) return -1;
         slot = (slot + 1) & mask;
     }
 }
@@ -446,7 +486,7 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void k_neighbours(const unsigned long long* __restrict__ dkeys, int size,
                                                        const unsigned long long* __restrict__ tkeys,
                                                        unsigned long long mask, const int* __restrict__ slot_id,
-                                                       int* __restrict__ nb1, int* __restrict__ nb2) {
+                                                       int* __restrict__ nb1, int* __restrict__ nb2, unsigned gen) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (int64_t)size * (D + 1)) return;
     const int j = (int)(t / size), v = (int)(t % size);
@@ -461,8 +501,8 @@ __global__ __launch_bounds__(kBlock) void k_neighbours(const unsigned long long*
 #pragma unroll
     for (int k = 0; k < D; ++k)
         if (k == j) { n1[k] = (short)(key[k] + D); n2[k] = (short)(key[k] - D); }
-    nb1[(int64_t)j * size + v] = lookup(tkeys, mask, slot_id, pack_key(n1, D));
-    nb2[(int64_t)j * size + v] = lookup(tkeys, mask, slot_id, pack_key(n2, D));
+    nb1[(int64_t)j * size + v] = lookup(tkeys, mask, slot_id, pack_key(n1, D), gen);
+    nb2[(int64_t)j * size + v] = lookup(tkeys, mask, slot_id, pack_key(n2, D), gen);
 }
 
 // ---- filtering (permutohedral.cpp:482-616) --------------------------------------------------------------
@@ -630,8 +670,9 @@ void lat_scale(int d, int with_blur, float (&sc)[3]) {
     for (int i = 0; i < 3; ++i) sc[i] = i < d ? (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std) : 0.f;
 }
 
+// count: [0] vertices created so far, [1] overflow flag; slot_id / dkeys may be null (count only)
 void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&sc)[3], unsigned long long* table,
-                  unsigned long long mask, int* overflow) {
+                  unsigned long long mask, unsigned gen, int* count, int* slot_id, unsigned long long* dkeys) {
     const unsigned nb = (unsigned)prg::ceil_div(last - first, kBlock);
     if (nb == 0) return;
     hipStream_t st = L->stream;
@@ -639,14 +680,24 @@ void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&
 #define PRG_EMBED(DD)                                                                                              \
     if (L->prod)                                                                                                    \
         k_embed<DD, true><<<nb, kBlock, 0, st>>>(nullptr, *L->prod, first, last, sc[0], sc[1], sc[2], table, mask,  \
-                                                 L->pslot, L->bary, overflow);                                      \
+                                                 gen, L->pslot, L->bary, count, slot_id, dkeys);                    \
     else                                                                                                            \
         k_embed<DD, false><<<nb, kBlock, 0, st>>>(L->feat, none, first, last, sc[0], sc[1], sc[2], table, mask,     \
-                                                  L->pslot, L->bary, overflow)
+                                                  gen, L->pslot, L->bary, count, slot_id, dkeys)
     if (d == 1) { PRG_EMBED(1); }
     else if (d == 2) { PRG_EMBED(2); }
     else { PRG_EMBED(3); }
 #undef PRG_EMBED
+}
+
+// next generation of a table (see Lattice::gen): wraps by zeroing the table once every 65535 builds
+static int next_generation(unsigned long long* table, int64_t cap, unsigned* gen, hipStream_t st) {
+    if (*gen >= 0xFFFFu) {
+        PRG_HIP(hipMemsetAsync(table, 0, cap * sizeof(unsigned long long), st));
+        *gen = 0;
+    }
+    ++*gen;
+    return PRG_OK;
 }
 
 int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above = -1) {
@@ -668,6 +719,8 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         PRG_HIP(hipMalloc((void**)&L->bary, na * d1 * sizeof(float)));
         PRG_HIP(hipMalloc((void**)&L->dkeys, na * d1 * sizeof(unsigned long long)));
         if (!L->count) PRG_HIP(hipMalloc((void**)&L->count, 2 * sizeof(int)));
+        PRG_HIP(hipMemsetAsync(L->tkeys, 0, cap * sizeof(unsigned long long), st));
+        L->gen = 0;
         L->n_alloc = na;
     }
     L->n = n;
@@ -676,8 +729,8 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
     float sc[3];
     lat_scale(d, with_blur, sc);
     // The table is sized from the previous lattice of the same kind (x8..16 head room: the lattice at most doubles
-    // per EM iteration) so that clearing and compacting it costs microseconds; an overflow falls back to the
-    // worst-case size.
+    // per EM iteration) so that the probes stay inside a few cache lines' worth of slots; an overflow falls back to the
+    // worst-case size.  Nothing is cleared: the build takes the next generation of the table.
     const int mode = with_blur ? 1 : 0;
     int64_t capu = L->cap;
     if (L->prev_size[mode] > 0) {
@@ -685,23 +738,22 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         while (capu < 8 * (int64_t)L->prev_size[mode]) capu <<= 1;
         if (capu > L->cap) capu = L->cap;
     }
-    auto embed = [&](int64_t first, int64_t last, unsigned long long mask) {
-        launch_embed(L, d, first, last, sc, L->tkeys, mask, L->count + 1);
-    };
     L->built = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         L->cap_used = capu;
-        PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, capu * sizeof(unsigned long long), st));
+        PRG_TRY(next_generation(L->tkeys, L->cap, &L->gen, st));
         PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
         const unsigned long long mask = (unsigned long long)capu - 1;
+        auto embed = [&](int64_t first, int64_t last) {
+            launch_embed(L, d, first, last, sc, L->tkeys, mask, L->gen, L->count, L->slot_id, L->dkeys);
+        };
         if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
         volatile int* host = reinterpret_cast<volatile int*>(L->pinned);
         host[0] = host[1] = 0;
         int64_t done = 0;
-        if (decide_above >= 0 && n >= 4096) {  // stage 1: a sixteenth of the points, count only
+        if (decide_above >= 0 && n >= 4096) {  // stage 1: a sixteenth of the points; the vertex counter tells
             done = n / 16;
-            embed(0, done, mask);
-            k_count_occupied<<<(unsigned)std::min<int64_t>(prg::ceil_div(capu, kBlock), 2048), kBlock, 0, st>>>(L->tkeys, capu, L->count);
+            embed(0, done);
             PRG_HIP(hipGetLastError());
             PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             PRG_HIP(hipStreamSynchronize(st));
@@ -712,19 +764,16 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                             (long long)done, (long long)n, host[0], (long long)decide_above, with_blur);
                 return PRG_OK;  // prev_size[mode] keeps the last full count
             }
-            PRG_HIP(hipMemsetAsync(L->count, 0, sizeof(int), st));  // the vertex counter restarts for the compaction
         } else if (n >= 4096) {
             // no decision to take, but the table is still filled in two launches: the first sixteenth of the points
             // creates most vertices almost uncontended, the rest then find them with plain reads - one launch over
             // all points has every wave compare-and-swap the same few hundred empty slots at once (3x slower while
             // the lattice is small)
             done = n / 16;
-            embed(0, done, mask);
+            embed(0, done);
         }
         if (host[1] == 0) {
-            embed(done, n, mask);
-            k_compact<<<(unsigned)prg::ceil_div(capu, kBlock), kBlock, 0, st>>>(L->tkeys, capu, L->slot_id, L->dkeys,
-                                                                               L->count);
+            embed(done, n);
             PRG_HIP(hipGetLastError());
             PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             if (L->side_pending)  // the speculative decision stage rides on the same synchronisation
@@ -761,17 +810,18 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         int* nb1 = L->nb;
         int* nb2 = L->nb + (int64_t)d1 * L->size;
         const unsigned g = (unsigned)prg::ceil_div((int64_t)L->size * d1, kBlock);
-        if (d == 1) k_neighbours<1><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
-        else if (d == 2) k_neighbours<2><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
-        else k_neighbours<3><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2);
+        if (d == 1) k_neighbours<1><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2, L->gen);
+        else if (d == 2) k_neighbours<2><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2, L->gen);
+        else k_neighbours<3><<<g, kBlock, 0, st>>>(L->dkeys, L->size, L->tkeys, mask, L->slot_id, nb1, nb2, L->gen);
         PRG_HIP(hipGetLastError());
     }
     return PRG_OK;
 }
 
 // Decision stage of the blurred lattice into the side table, WITHOUT synchronising: 1/16 of the points are hashed with
-// the blur scaling and counted; the count is read back by the next lat_build on this lattice (side_pending).  A subset's
-// vertices are a subset of the vertices, so side_size > threshold proves that the blurred lattice is too large.
+// the blur scaling and counted as they create vertices; the count is read back by the next lat_build on this lattice
+// (side_pending).  A subset's vertices are a subset of the vertices, so side_size > threshold proves that the blurred
+// lattice is too large.
 int lat_side_stage(Lattice* L, int64_t n, int d) {
     const int d1 = d + 1;
     hipStream_t st = L->stream;
@@ -782,17 +832,17 @@ int lat_side_stage(Lattice* L, int64_t n, int d) {
         if (L->tkeys2) (void)hipFree(L->tkeys2);
         L->tkeys2 = nullptr;
         PRG_HIP(hipMalloc((void**)&L->tkeys2, want * sizeof(unsigned long long)));
+        PRG_HIP(hipMemsetAsync(L->tkeys2, 0, want * sizeof(unsigned long long), st));
+        L->gen2 = 0;
         L->cap2 = want;
     }
     if (!L->count2) PRG_HIP(hipMalloc((void**)&L->count2, 2 * sizeof(int)));
     if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
     float sc[3];
     lat_scale(d, 1, sc);
-    PRG_HIP(hipMemsetAsync(L->tkeys2, 0xFF, want * sizeof(unsigned long long), st));
+    PRG_TRY(next_generation(L->tkeys2, L->cap2, &L->gen2, st));
     PRG_HIP(hipMemsetAsync(L->count2, 0, 2 * sizeof(int), st));
-    launch_embed(L, d, 0, n16, sc, L->tkeys2, (unsigned long long)want - 1, L->count2 + 1);
-    k_count_occupied<<<(unsigned)std::min<int64_t>(prg::ceil_div(want, kBlock), 2048), kBlock, 0, st>>>(L->tkeys2, want,
-                                                                                                       L->count2);
+    launch_embed(L, d, 0, n16, sc, L->tkeys2, (unsigned long long)L->cap2 - 1, L->gen2, L->count2, nullptr, nullptr);
     PRG_HIP(hipGetLastError());
     L->side_pending = true;
     return PRG_OK;
