@@ -28,7 +28,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU 
 done
 sum --pmc $(db $out/c4_FETCH_SIZE) $(db $out/c4_WRITE_SIZE) $(db $out/c4_SQ_INSTS_VALU) > $out/${tag}_filterreg_500k_pmc.txt
 
-c3="python bench.py --workload nonrigid_50k --steps 1 --warmup 1"
+c3="python bench.py --workload nonrigid_50k --steps 20 --warmup 2"
 rocprofv3 --kernel-trace --stats -d $out/c3_kt -o b -- $c3 > $out/c3_line.json 2> $out/c3_kt.err
 sum $(db $out/c3_kt) > $out/${tag}_nonrigid_50k_kernel_trace.txt
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
@@ -37,5 +37,6 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_
 done
 sum --pmc $(db $out/c3_FETCH_SIZE) $(db $out/c3_WRITE_SIZE) $(db $out/c3_SQ_INSTS_VALU) > $out/${tag}_nonrigid_50k_pmc.txt
 ls -la $out/*.txt
+# afterwards, locally: cp gpurun_out/prof_$tag/${tag}_*.txt profiles/ && python tools/pmc_traffic_update.py $tag
 # keep the merged output small: the databases stay on the box
 rm -rf $out/kt_default $out/c1_* $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c4_SQ_INSTS_VALU $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE $out/c3_SQ_INSTS_VALU 2>/dev/null
