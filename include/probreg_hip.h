@@ -82,7 +82,7 @@ int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
  * each): the pair sweeps take
  * their exponents from the matrix cores (bf16x3-split MFMA distance blocks) while
  * |log2(e) / (2 sigma2)| * (squared diagonal of the larger of the source's / local target's bounding box) < bound (default
- * 4000; the row pass leaves at 1/8 of it; both skip whole 512 x 256 blocks of exact zeros) - from there on the culled
+ * 16000; the row pass leaves at 1/20 of it; both skip exact zeros in blocks of 512 x 256 and, per wave, 128 x 32) - from there on the culled
  * vector-pipe sweeps, which skip 128 x 32 blocks, are faster and the registration stays on them; mode 0: vector-pipe sweeps only; mode 2: both sweeps on the matrix cores whatever the bound says
  * (tests, measurements).  bound = 0 keeps the current value.  prg_cpd_last_estep_engine reports which engine the last
  * E-step's column pass used (1 = matrix cores). */

@@ -1160,6 +1160,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // them and never synchronises again.
     bool use_mfma = false, row_mfma = false;  // column pass / row pass on the matrix cores
     bool first_mfma = false;                  // ... column pass without seeds (first E-step of a registration)
+    bool fine_cull = false;                   // ... with the per-wave group tests (some groups can be skipped by now)
     if (mfma_possible && !h->mfma_off) {
         // chunk boxes of this E-step's transformed source (the matrix-core sweeps cull with them) and its bounding box
         prg::launch_chunk_meta_bbox(h);
@@ -1181,7 +1182,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // first E-step, no minima yet - none at all when the farthest target / source pair is still above the flush
         // threshold (farthest corners of the two bounding boxes: every term of every column is >= 2^-110).
         // The culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
-        // (profiles/r2_mfma_cull_vs_valu_100k.log): it leaves at 1/8 of the bound.
+        // (profiles/r2_mfma_cull_vs_valu_100k.log): it leaves at 1/20 of the bound.
         double far2 = 0.0;
         for (int k = 0; k < 3; ++k) {
             const double a = fabs((double)h->tbox[3 + k] - (double)st[8 + k]), b = fabs((double)st[11 + k] - (double)h->tbox[k]);
@@ -1189,13 +1190,14 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         }
         first_mfma = dense && !h->have_colmin && std::isfinite(far2) && nk * far2 < 110.0;
         use_mfma = first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0);
-        row_mfma = dense && (forced || nk * ext2 < 0.125 * h->dense_bound);
+        row_mfma = dense && (forced || nk * ext2 < 0.05 * h->dense_bound);
+        fine_cull = nk * ext2 > 200.0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2) and the test is overhead
     }
     h->last_estep_mfma = use_mfma;
     h->wg_col_pairs = h->wg_row_pairs = 128.0 * prg::kGroup;  // a (wave, group) block of the culled vector-pipe sweeps
     if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
     if (use_mfma)
-        prg::launch_colpass_mfma(h, mfma_seg, first_mfma);
+        prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull);
     else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, h->have_colmin && !h->srcw);  // the seed bound assumes unweighted distances
     else if (ra < 0)
@@ -1209,7 +1211,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                       use_cull ? h->tmeta : nullptr, use_mfma ? (first_mfma ? 2 : 1) : 0, h->motion, slot);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
-        prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap));
+        prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap), fine_cull);
     else if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);
     else if (rb < 0)

@@ -57,7 +57,7 @@ struct prg_cpd {
     float* tchunk = nullptr;    // [Ncap/256][8] box + largest b_n of every 256-point chunk of the target (per E-step)
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
                                 // 2: both sweeps on the matrix cores, always (tests)
-    double dense_bound = 4000.0;  // matrix-core column pass while |kk| * (cloud bounding-box diagonal)^2 is below this (C1: sigma2 > ~1.5e-3)
+    double dense_bound = 16000.0;  // matrix-core column pass while |kk| * (cloud bounding-box diagonal)^2 is below this (C1: sigma2 > ~4e-4)
     bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
     bool last_estep_mfma = false;
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source

@@ -37,9 +37,11 @@ __device__ __forceinline__ float col_seed_offset(float kk, float cm, float mo) {
     const float g = __fmul_rn(nk, __fsub_rn(hi, lo));
     return __fadd_rn(__fmul_rn(nk, lo), fmaxf(__fsub_rn(g, 80.f), 0.f));
 }
-void launch_colpass_mfma(prg_cpd* h, int S, bool first);  // first: no seeds from a previous E-step (offsets 0, no culling)
+// first: no seeds from a previous E-step (offsets 0, no culling); fine: every wave also tests its own 128 points against
+// the groups of 32 streamed points of each chunk (pays once sigma2 is small enough for some of them to be skipped)
+void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine);
 void launch_chunk_meta_bbox(prg_cpd* h);  // zchunk + bounding box of z4 -> motion[8..13]  // S segments of the streamed cloud (0 = fill the chip once)
-void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag);  // rowflag: 64 bytes per 128-row block (touched planes)
+void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine);  // rowflag: 64 bytes per 128-row block (touched planes)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)

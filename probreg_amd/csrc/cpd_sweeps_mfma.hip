@@ -96,6 +96,32 @@ __device__ __forceinline__ bool wg_box(const BoxMeta* __restrict__ gmeta, int64_
     return hi[0] >= lo[0];
 }
 
+// Box of the 128 points a wave owns (its 4 groups), wave-uniform in SGPRs.  false: one of the groups holds pads.
+struct WaveBox { float lo[3]; float hi[3]; };
+__device__ __forceinline__ bool wave_box(const BoxMeta* __restrict__ gmeta, int64_t first_point, int64_t n_points, int lane,
+                                         WaveBox& w) {
+    const BoxMeta m = gmeta[first_point / 32 + (lane & 3)];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float l = m.lo[k], h = m.hi[k];
+        l = fminf(l, __shfl_xor(l, 1, 64));
+        l = fminf(l, __shfl_xor(l, 2, 64));
+        h = fmaxf(h, __shfl_xor(h, 1, 64));
+        h = fmaxf(h, __shfl_xor(h, 2, 64));
+        w.lo[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(l)));
+        w.hi[k] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(h)));
+    }
+    return first_point + 16 * kOwn <= n_points;
+}
+
+// 8 group bits (one per group of 32 streamed points of a chunk) -> 16 tile bits (two 16-point tiles per group)
+__device__ __forceinline__ unsigned tiles_of_groups(unsigned g) {
+    g = (g | (g << 4)) & 0x0F0Fu;
+    g = (g | (g << 2)) & 0x3333u;
+    g = (g | (g << 1)) & 0x5555u;
+    return g | (g << 1);
+}
+
 // a = h + m + l with three bf16 pieces: 24 significant bits, every piece product exact in the f32 accumulator
 struct Split3 { __bf16 h, m, l; };
 __device__ __forceinline__ Split3 split3(float a) {
@@ -155,6 +181,7 @@ __device__ __forceinline__ bf16x8 owned_operand(int k, float kk, float dx, float
 // L_n = prg::col_seed_offset - the same for every segment of a column.
 __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
                                                          const BoxMeta* __restrict__ tmeta,
+                                                         const BoxMeta* __restrict__ zmeta,
                                                          const BoxMeta* __restrict__ zchunk,
                                                          const float* __restrict__ colmin_prev,
                                                          const float* __restrict__ colmin_g,
@@ -162,31 +189,40 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          int64_t m_total, int64_t n_total,
                                                          const double* __restrict__ params,
                                                          float2* __restrict__ colpart, int64_t ncap,
-                                                         unsigned* __restrict__ wgcount, int first) {
+                                                         unsigned* __restrict__ wgcount, int first, int fine) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
+    __shared__ unsigned wave_tiles[kBlock / 64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n0wg = (int64_t)blockIdx.x * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const float mo = __uint_as_float(*motion);
-    // the workgroup's patch: box (for the cull test) and origin (its centre).  A workgroup that holds pads has no usable
+    // the workgroup's patch: box (for the chunk test) and origin (its centre).  A workgroup that holds pads has no usable
     // box: it evaluates everything and takes its first point as origin.
     float lo[3], hi[3];
     float4 o;
-    float thr = INFINITY;  // skip a chunk when its box is farther than thr (squared) from the patch
+    float thr = INFINITY;    // skip a chunk when its box is farther than thr (squared) from the patch
+    float thr_w = INFINITY;  // ... and a group of 32 streamed points when it is farther than thr_w from this wave's 128
+    WaveBox wb;
+    bool wave_cull = wave_box(tmeta, n0, n_total, lane, wb) && !first && fine;
     if (n0wg + kWgPoints <= n_total && wg_box(tmeta, n0wg, n_total, lane, lo, hi)) {
         o = make_float4(0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), 0.f);
-      if (!first) {  // (first E-step of a registration: no minima to bound anything with)
-        // as in k_colpass_cull: (sqrt(largest column minimum of the previous E-step) + source motion)^2 bounds this
-        // E-step's minima from above; a chunk beyond that by 127 / |kk| adds < 2^-127 of any column's largest term
-        float cmax = colmin_g[n0wg / 32 + (lane & 15)];
+        if (!first) {  // (first E-step of a registration: no minima to bound anything with)
+            // as in k_colpass_cull: (sqrt(largest column minimum of the previous E-step) + source motion)^2 bounds this
+            // E-step's minima from above; a chunk beyond that by 127 / |kk| adds < 2^-127 of any column's largest term
+            float cm = colmin_g[n0wg / 32 + (lane & 15)];
+            float cw = __shfl(cm, 4 * wv + (lane & 3), 64);  // the wave's own four groups
+            cw = fmaxf(cw, __shfl_xor(cw, 1, 64));
+            cw = fmaxf(cw, __shfl_xor(cw, 2, 64));
 #pragma unroll
-        for (int sh = 1; sh < 16; sh <<= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, sh, 64));
-        const float r = sqrtf(cmax) + mo;
-        thr = r * r * 1.00001f + (-127.0f) / kk;
-      }
+            for (int sh = 1; sh < 16; sh <<= 1) cm = fmaxf(cm, __shfl_xor(cm, sh, 64));
+            const float r = sqrtf(cm) + mo, rw = sqrtf(cw) + mo;
+            thr = r * r * 1.00001f + (-127.0f) / kk;
+            thr_w = rw * rw * 1.00001f + (-127.0f) / kk;
+        }
     } else {
         o = tgt4[n0wg];
         o.w = 0.f;
+        wave_cull = false;
 #pragma unroll
         for (int q = 0; q < 3; ++q) { lo[q] = -INFINITY; hi[q] = INFINITY; }
     }
@@ -209,31 +245,33 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     // which chunks of the segment are needed: one box test per lane, one ballot (identical in all four waves)
     const BoxMeta cm = zchunk[c0 + (lane < nc ? lane : nc - 1)];
     unsigned long long mask = __ballot(lane < nc && !(box_gap2(lo, hi, cm) > thr));
-    int evaluated = 0;
+    unsigned tiles_done = 0;
     if (mask) {
         int cur = __builtin_ctzll(mask);
         mask &= mask - 1;
         float4 ra = z4[(c0 + cur) * kChunk + threadIdx.x];
         ra.w = 0.f;  // (weighted sources do not take this path)
+        BoxMeta gm = zmeta[wave_cull ? (c0 + cur) * 8 + (lane & 7) : 0];  // the chunk's eight groups, for this wave's finer test
         stage_point(stage[0], threadIdx.x, ra, o, kk);
         __syncthreads();
         for (int bsel = 0;; bsel ^= 1) {
             const float* __restrict__ buf = stage[bsel];
+            // groups of this chunk the wave's own 128 points can see -> tiles to evaluate (wave-uniform)
+            unsigned tmask = 0xFFFFu;
+            if (wave_cull)
+                tmask = tiles_of_groups((unsigned)__ballot(lane < 8 && !(box_gap2(wb.lo, wb.hi, gm) > thr_w)) & 0xFFu);
             const int nxt = mask ? __builtin_ctzll(mask) : -1;
             mask &= mask - 1;
             if (nxt >= 0) {
                 ra = z4[(c0 + nxt) * kChunk + threadIdx.x];
                 ra.w = 0.f;
+                if (wave_cull) gm = zmeta[(c0 + nxt) * 8 + (lane & 7)];
             }
+            tiles_done += __popc(tmask);
             // software pipeline: the MFMA of the NEXT (tile, column tile) pair is issued before the current pair's
-            // accumulator is exponentiated
-            bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
-            f32x4 cz = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
-            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[0], cz, 0, 0, 0);
-            for (int t = 0; t < kChunkTiles; ++t) {
-                const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
-                const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
-                const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+            // accumulator is exponentiated.  tile_step works on accumulator d of tile (a1, cz) and leaves the first
+            // accumulator of tile (a1n, czn) in d.
+            auto tile_step = [&](f32x4& d, const bf16x8 a1, const f32x4 cz, const bf16x8 a1n, const f32x4 czn) {
 #pragma unroll
                 for (int u = 0; u < kOwn; ++u) {
                     const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[u + 1], cz, 0, 0, 0)
@@ -243,16 +281,48 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                     s[u] += (exp2r(d[0]) + exp2r(d[1])) + (exp2r(d[2]) + exp2r(d[3]));
                     d = dn;
                 }
-                a1 = a1n;
-                cz = czn;
+            };
+            if (tmask == 0xFFFFu) {  // every tile (the dense regime): fixed trip count
+                bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
+                f32x4 cz = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[0], cz, 0, 0, 0);
+                for (int t = 0; t < kChunkTiles; ++t) {
+                    const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
+                    const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+                    const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+                    tile_step(d, a1, cz, a1n, czn);
+                    a1 = a1n;
+                    cz = czn;
+                }
+            } else if (tmask) {  // the tiles this wave can see
+                int t = __builtin_ctz(tmask);
+                tmask &= tmask - 1;
+                bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf + t * kTileFloats)[lane];
+                f32x4 cz = *reinterpret_cast<const f32x4*>(buf + t * kTileFloats + 256 + 4 * k);
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[0], cz, 0, 0, 0);
+                for (;;) {
+                    const bool more = tmask != 0;
+                    const int t2 = more ? __builtin_ctz(tmask) : t;
+                    tmask &= tmask - 1;
+                    const float* __restrict__ tn = buf + t2 * kTileFloats;
+                    const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+                    const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+                    tile_step(d, a1, cz, a1n, czn);
+                    if (!more) break;
+                    t = t2;
+                    a1 = a1n;
+                    cz = czn;
+                }
             }
-            ++evaluated;
             if (nxt >= 0) stage_point(stage[bsel ^ 1], threadIdx.x, ra, o, kk);
             __syncthreads();
             if (nxt < 0) break;
         }
     }
-    if (threadIdx.x == 0) wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned)evaluated;
+    if (lane == 0) wave_tiles[wv] = tiles_done;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
     float2* __restrict__ out = colpart + (int64_t)blockIdx.y * ncap + n0;
 #pragma unroll
     for (int u = 0; u < kOwn; ++u) {
@@ -275,23 +345,28 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
 // the reference point.
 __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
                                                          const BoxMeta* __restrict__ zmeta,
+                                                         const BoxMeta* __restrict__ tmeta,
                                                          const BoxMeta* __restrict__ tchunk, int chunks_per_seg,
                                                          int64_t n_total, int64_t m_total,
                                                          const double* __restrict__ params, float* __restrict__ rowpart,
                                                          int64_t mcap, float4* __restrict__ rorig,
                                                          unsigned char* __restrict__ rowflag,
-                                                         unsigned* __restrict__ wgcount) {
+                                                         unsigned* __restrict__ wgcount, int fine) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
+    __shared__ unsigned wave_tiles[kBlock / 64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t m0wg = (int64_t)blockIdx.x * kWgPoints, m0 = m0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     float lo[3], hi[3];
     float4 o;
+    WaveBox wb;
+    bool wave_cull = wave_box(zmeta, m0, m_total, lane, wb) && fine;
     if (m0wg + kWgPoints <= m_total && wg_box(zmeta, m0wg, m_total, lane, lo, hi)) {
         o = make_float4(0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]), 0.f);
     } else {  // a workgroup that holds pads: no usable box, nothing is skipped
         o = z4[m0wg];
         o.w = 0.f;
+        wave_cull = false;
 #pragma unroll
         for (int q = 0; q < 3; ++q) { lo[q] = -INFINITY; hi[q] = INFINITY; }
     }
@@ -311,27 +386,31 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     // a chunk is skipped when every P of the (patch, chunk) block is an exact zero: kk dist^2(boxes) + max b_n < -127
     const BoxMeta cm = tchunk[c0 + (lane < nc ? lane : nc - 1)];
     unsigned long long mask = __ballot(lane < nc && !(fmaf(box_gap2(lo, hi, cm), kk, cm.aux) < -127.0f));
-    const bool touched = mask != 0;
-    int evaluated = 0;
+    unsigned tiles_done = 0;
     if (mask) {
         int cur = __builtin_ctzll(mask);
         mask &= mask - 1;
         float4 ra = tgt4[(c0 + cur) * kChunk + threadIdx.x];
+        BoxMeta gm = tmeta[wave_cull ? (c0 + cur) * 8 + (lane & 7) : 0];  // the chunk's eight groups (box, largest b_n)
         stage_point(stage[0], threadIdx.x, ra, o, kk);
         __syncthreads();
         for (int bsel = 0;; bsel ^= 1) {
             const float* __restrict__ buf = stage[bsel];
+            // the same test for this wave's own 128 rows against each group of 32 targets -> tiles to evaluate
+            unsigned tmask = 0xFFFFu;
+            if (wave_cull)
+                tmask = tiles_of_groups(
+                    (unsigned)__ballot(lane < 8 && !(fmaf(box_gap2(wb.lo, wb.hi, gm), kk, gm.aux) < -127.0f)) & 0xFFu);
             const int nxt = mask ? __builtin_ctzll(mask) : -1;
             mask &= mask - 1;
-            if (nxt >= 0) ra = tgt4[(c0 + nxt) * kChunk + threadIdx.x];
-            bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
-            f32x4 cx = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
-            f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[0], cx, 0, 0, 0);
-            for (int t = 0; t < kChunkTiles; ++t) {
-                const float* __restrict__ tb = buf + t * kTileFloats;
-                const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
-                const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
-                const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+            if (nxt >= 0) {
+                ra = tgt4[(c0 + nxt) * kChunk + threadIdx.x];
+                if (wave_cull) gm = tmeta[(c0 + nxt) * 8 + (lane & 7)];
+            }
+            tiles_done += __popc(tmask);
+            // tile_step: accumulator d of tile tb (operands a1, cx) -> sums; leaves the first accumulator of the next tile
+            auto tile_step = [&](f32x4& d, const float* __restrict__ tb, const bf16x8 a1, const f32x4 cx, const bf16x8 a1n,
+                                 const f32x4 cxn) {
                 const f32x4 xx = *reinterpret_cast<const f32x4*>(tb + 272 + 4 * k), xy = *reinterpret_cast<const f32x4*>(tb + 288 + 4 * k),
                             xz = *reinterpret_cast<const f32x4*>(tb + 304 + 4 * k), xs = *reinterpret_cast<const f32x4*>(tb + 320 + 4 * k);
 #pragma unroll
@@ -346,18 +425,51 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
                     e[u] = fmaf(q3, xs[3], fmaf(q2, xs[2], fmaf(q1, xs[1], fmaf(q0, xs[0], e[u]))));
                     d = dn;
                 }
-                a1 = a1n;
-                cx = cxn;
+            };
+            if (tmask == 0xFFFFu) {  // every tile (the dense regime): fixed trip count
+                bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf)[lane];
+                f32x4 cx = *reinterpret_cast<const f32x4*>(buf + 256 + 4 * k);
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[0], cx, 0, 0, 0);
+                for (int t = 0; t < kChunkTiles; ++t) {
+                    const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
+                    const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+                    const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+                    tile_step(d, buf + t * kTileFloats, a1, cx, a1n, cxn);
+                    a1 = a1n;
+                    cx = cxn;
+                }
+            } else if (tmask) {  // the tiles this wave can see
+                int t = __builtin_ctz(tmask);
+                tmask &= tmask - 1;
+                bf16x8 a1 = reinterpret_cast<const bf16x8*>(buf + t * kTileFloats)[lane];
+                f32x4 cx = *reinterpret_cast<const f32x4*>(buf + t * kTileFloats + 256 + 4 * k);
+                f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[0], cx, 0, 0, 0);
+                for (;;) {
+                    const bool more = tmask != 0;
+                    const int t2 = more ? __builtin_ctz(tmask) : t;
+                    tmask &= tmask - 1;
+                    const float* __restrict__ tn = buf + t2 * kTileFloats;
+                    const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
+                    const f32x4 cxn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
+                    tile_step(d, buf + t * kTileFloats, a1, cx, a1n, cxn);
+                    if (!more) break;
+                    t = t2;
+                    a1 = a1n;
+                    cx = cxn;
+                }
             }
-            ++evaluated;
             if (nxt >= 0) stage_point(stage[bsel ^ 1], threadIdx.x, ra, o, kk);
             __syncthreads();
             if (nxt < 0) break;
         }
     }
-    if (threadIdx.x == 0) wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned)evaluated;
+    if (lane == 0) wave_tiles[wv] = tiles_done;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
     // k_row_moments skips (128-row block, plane) partials that were never touched: neither written nor read
-    if (threadIdx.x < 4) rowflag[((int64_t)blockIdx.x * 4 + threadIdx.x) * 64 + blockIdx.y] = touched ? 1 : 0;
+    const bool touched = tiles_done != 0;  // (wave-uniform: this wave's 128 rows)
+    if (lane == 0) rowflag[((int64_t)blockIdx.x * 4 + wv) * 64 + blockIdx.y] = touched ? 1 : 0;
     if (touched) {
         float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
 #pragma unroll
@@ -495,28 +607,30 @@ void launch_chunk_meta_bbox(prg_cpd* h) {
                                                   reinterpret_cast<BoxMeta*>(h->zchunk), h->z4, h->M, h->motion);
 }
 
-void launch_colpass_mfma(prg_cpd* h, int S, bool first) {
+void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine) {
     const int cps = mfma_chunks_per_seg(h->N, h->M, S);
     dim3 grid((unsigned)ceil_div(h->N, kWgPoints), (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
     // (zchunk: boxes of this E-step's transformed source, written by launch_chunk_meta_bbox before the engine decision)
     k_colpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
+                                                   reinterpret_cast<const BoxMeta*>(h->zmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
                                                    h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
-                                                   h->colpart, h->Ncap, h->wgcount, first ? 1 : 0);
+                                                   h->colpart, h->Ncap, h->wgcount, first ? 1 : 0, fine ? 1 : 0);
     h->wg_col = (int64_t)grid.x * grid.y;
-    h->wg_col_pairs = (double)kWgPoints * kChunk;
+    h->wg_col_pairs = 128.0 * 16.0;  // counted unit: one wave's 128 points x one 16-point tile
     h->dense_pairs_col = 0.0;
 }
 
-void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag) {
+void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine) {
     const int cps = mfma_chunks_per_seg(h->M, h->N, S);
     dim3 grid((unsigned)ceil_div(h->M, kWgPoints), (unsigned)ceil_div(ceil_div(h->N, kChunk), cps));
     launch_chunk_meta(h, h->tmeta, h->Ncap, h->tchunk);  // target boxes with this E-step's b_n ranges (after k_colfinal)
     k_rowpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const BoxMeta*>(h->zmeta),
+                                                   reinterpret_cast<const BoxMeta*>(h->tmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->tchunk), cps, h->N, h->M, h->params,
-                                                   h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap);
+                                                   h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap, fine ? 1 : 0);
     h->wg_row = (int64_t)grid.x * grid.y;
-    h->wg_row_pairs = (double)kWgPoints * kChunk;
+    h->wg_row_pairs = 128.0 * 16.0;
     h->dense_pairs_row = 0.0;
 }
 

@@ -61,7 +61,7 @@ def test_auto_engine_registration_matches_oracle_and_switches_engines():
     from oracle import cpd_c, cpd_numpy as co
     from probreg_amd import _lib, cpd, synthetic
 
-    n, k = 20000, 18
+    n, k = 20000, 22
     src, tgt, _ = synthetic.rigid_pair(n, seed=4)
     reg = cpd.RigidCPD(src)
     reg._initialize(tgt)
