@@ -78,7 +78,8 @@ class NonRigidTransformation(Transformation):
     """y_m -> y_m + (G W)_m on the control points it was built with (reference transformation.py:81-102).
 
     ``g`` is the float32 Gaussian kernel matrix of the control points.  When the object comes out
-    of ``NonRigidCPD`` the matrix lives on the GPU; ``.g`` downloads it on first access (M*M*4 bytes).
+    of ``NonRigidCPD`` the GPU plan holds the kernel as its factor ``G = F F^T`` (or, when the kernel is too narrow to
+    factor, as the matrix itself); ``.g`` evaluates / downloads the M x M float32 matrix on first access (M*M*4 bytes).
     """
 
     def __init__(self, w, points, beta=2.0, xp=np, _plan=None, _plan_points=None):
@@ -105,7 +106,7 @@ class NonRigidTransformation(Transformation):
     def _transform(self, points):
         # same contract as the reference: ``points`` must be the control points the kernel was built on
         if self._plan is not None:
-            # G W on the GPU (fp64 accumulation over the float32 G), never through a host copy of G
+            # G W on the GPU (fp64; through the kernel factor, or the float32 G of the dense fallback), never through a host copy of G
             self._plan.set_w(np.asarray(self.w, dtype=np.float64))
             disp = self._plan.nonrigid_apply() - self._plan_points.astype(np.float32).astype(np.float64)
             return np.asarray(points) + disp
