@@ -516,7 +516,7 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(n)
         if world == 1 and args.workload == "rigid_100k" and not args.no_other_workloads:
             others = {}
-            for name, fn, k, w in (("affine_200k", bench_cpd, 5, 1), ("nonrigid_50k", bench_nonrigid, 20, 2),
+            for name, fn, k, w in (("affine_200k", bench_cpd, 20, 1), ("nonrigid_50k", bench_nonrigid, 20, 2),
                                    ("filterreg_500k", bench_filterreg, 20, 3)):
                 try:
                     others[name] = _slim(fn(name, k, w))

@@ -1176,7 +1176,14 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // size of the problem: the (replicated) source's bounding box or the local target's, whichever is larger - a
         // target shard is a small patch, and every rank should leave the dense regime at the same sigma2
         const double ext2 = std::max(h->sext2, h->text2);
-        const bool dense = ok && (forced || nk * ext2 < h->dense_bound);
+        // where the culled vector sweeps overtake the matrix-core ones depends on how small the 128 x 32-point blocks of
+        // the cull tests are next to sigma, i.e. on the point density: measured crossovers at 30k / 100k / 200k points
+        // (tools/mfma_vs_valu.py) move like n^1.8 (column pass) and n^2 above 100k (row pass); dense_bound is the
+        // value at n = 1e5
+        const double dens = sqrt((double)h->M * (double)h->Nglobal) / 1.0e5;
+        const double col_bound = h->dense_bound * pow(dens, 1.8);
+        const double row_bound = 0.05 * h->dense_bound * std::max(1.0, dens * dens);
+        const bool dense = ok && (forced || nk * ext2 < col_bound);
         if (!dense) h->mfma_off = true;
         // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or -
         // first E-step, no minima yet - none at all when the farthest target / source pair is still above the flush
@@ -1190,7 +1197,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         }
         first_mfma = dense && !h->have_colmin && std::isfinite(far2) && nk * far2 < 110.0;
         use_mfma = first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0);
-        row_mfma = dense && (forced || nk * ext2 < 0.05 * h->dense_bound);
+        row_mfma = dense && (forced || nk * ext2 < row_bound);
         fine_cull = nk * ext2 > 200.0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2) and the test is overhead
     }
     h->last_estep_mfma = use_mfma;
