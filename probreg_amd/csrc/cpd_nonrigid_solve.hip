@@ -116,6 +116,7 @@ __device__ __forceinline__ void load_diag8(const double* a, int jb, double (&l)[
 __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, int64_t ld, int64_t k0,
                                                       double* __restrict__ linv, int* __restrict__ info,
                                                       int64_t nreal) {
+    // linv == nullptr: factor only (the small-system path solves with the factor itself, k_trsm_rows / k_tri_solve3)
     extern __shared__ double a[];  // [NB][LDP]
     __shared__ double rdiag[NB];   // 1 / L_jj
     const int tid = threadIdx.x;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_potrf_inv(double* __restrict__ s, in
         const int i = idx >> 7, j = idx & 127;
         if (j <= i && i < nb) sblk[(int64_t)i * ld + j] = a[i * LDP + j];
     }
+    if (!linv) return;
     // ---------------- in-place inverse of the lower triangle, block columns from last to first ----------------
     // with A11 the 8 x 8 diagonal block, A21 the rows below it and X22 = inv(A22) already in place:
     //   new A21 = -X22 * A21 * inv(A11),  new A11 = inv(A11)
@@ -380,6 +382,124 @@ __global__ __launch_bounds__(kBlock, 2) void k_gemm_nt_f64(const double* abase, 
                 for (int r = 0; r < 4; ++r) cp[(int64_t)(16 * i + 4 * r) * ldc + 16 * j] = acc[i][j][r];
         }
     }
+}
+
+// ---- small systems: solves with the factor itself (no block inverses) ------------------------------------------------
+// The reduced system of the low-rank M-step has a few hundred rows: the triangular inverse that feeds the MFMA panel
+// solve of the big factorisation costs more than it saves there (it is 60 % of k_potrf_inv).
+//
+// Panel solve X L11^T = A21 for the rows below a factored diagonal block, in place.  8 lanes share a row (lane s owns the
+// columns j = s mod 8); right-looking: x_j is finished by its owner, broadcast inside the 8-lane group, and every lane
+// retires it from its later columns.  L11 sits in LDS (k * LDP + j: conflict free across the 8 x 8 lanes of a wave).
+__global__ __launch_bounds__(kBlock) void k_trsm_rows(double* __restrict__ s, int64_t ld, int64_t k0, int64_t row_begin,
+                                                      int64_t row_end) {
+    extern __shared__ double a[];  // [NB][LDP] lower triangle of L11
+    __shared__ double rdiag[NB];
+    const int tid = threadIdx.x;
+    const double* lblk = s + k0 * ld + k0;
+    for (int base = 0; base < NB * NB; base += 16 * kBlock) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * kBlock + tid, i = idx >> 7, j = idx & 127;
+            v[u] = j <= i ? lblk[(int64_t)i * ld + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * kBlock + tid, i = idx >> 7, j = idx & 127;
+            a[i * LDP + j] = v[u];
+        }
+    }
+    __syncthreads();
+    if (tid < NB) rdiag[tid] = 1.0 / a[tid * LDP + tid];
+    __syncthreads();
+    const int sub = tid & 7;
+    const int64_t row = row_begin + (int64_t)blockIdx.x * (kBlock / 8) + (tid >> 3);
+    const bool live = row < row_end;
+    double* __restrict__ arow = s + (live ? row : row_begin) * ld + k0;
+    double x[16];  // columns sub + 8 q
+#pragma unroll
+    for (int q = 0; q < 16; ++q) x[q] = live ? arow[sub + 8 * q] : 0.0;
+    const int lane = tid & 63;
+#pragma unroll
+    for (int jq = 0; jq < 16; ++jq) {
+#pragma unroll
+        for (int js = 0; js < 8; ++js) {
+            const int j = 8 * jq + js;
+            const double mine = x[jq] * rdiag[j];  // only lane js of the group holds column j
+            const double xj = __shfl(mine, (lane & ~7) | js, 64);
+            if (sub == js) x[jq] = xj;
+#pragma unroll
+            for (int q = jq; q < 16; ++q) {
+                const int k = sub + 8 * q;
+                if (k > j) x[q] = fma(-xj, a[k * LDP + j], x[q]);
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) arow[sub + 8 * q] = x[q];
+    }
+}
+
+// L11 u = v (TRANS 0) or L11^T u = v (TRANS 1) for one diagonal block and 3 right-hand sides, in place: one wave, two rows
+// per lane, column oriented - u_j is finished by its owner, broadcast, and retired from the rows that still wait.
+template <int TRANS>
+__global__ __launch_bounds__(kBlock) void k_tri_solve3(const double* __restrict__ s, int64_t ld, int64_t k0,
+                                                       double* __restrict__ v) {
+    extern __shared__ double a[];  // [NB][LDP]
+    const int tid = threadIdx.x;
+    const double* lblk = s + k0 * ld + k0;
+    for (int base = 0; base < NB * NB; base += 16 * kBlock) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * kBlock + tid, i = idx >> 7, j = idx & 127;
+            t[u] = j <= i ? lblk[(int64_t)i * ld + j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = base + u * kBlock + tid, i = idx >> 7, j = idx & 127;
+            a[i * LDP + j] = t[u];
+        }
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    const int lane = tid;
+    double r[2][3], dinv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = lane + 64 * h;
+        dinv[h] = 1.0 / a[k * LDP + k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[h][c] = v[(k0 + k) * 3 + c];
+    }
+#pragma unroll
+    for (int h0 = 0; h0 < 2; ++h0) {
+        const int hj = TRANS ? 1 - h0 : h0;  // the half the pivots of this sweep live in
+        for (int step = 0; step < 64; ++step) {
+            const int jl = TRANS ? 63 - step : step, j = jl + 64 * hj;
+            double u[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u[c] = __shfl(r[hj][c] * dinv[hj], jl, 64);
+            if (lane == jl) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) r[hj][c] = u[c];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = lane + 64 * h;
+                const bool pending = TRANS ? k < j : k > j;
+                const double l = pending ? (TRANS ? a[j * LDP + k] : a[k * LDP + j]) : 0.0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) r[h][c] = fma(-l, u[c], r[h][c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[(k0 + lane + 64 * h) * 3 + c] = r[h][c];
 }
 
 // ---- block triangular solves with 3 right-hand sides ----------------------------------------------
@@ -799,7 +919,51 @@ int cholesky_solve3(prg_cpd* h, const double* S, int64_t mp, const double* linv,
     return PRG_OK;
 }
 
+// Small SPD systems (the r x r system of the low-rank M-step): plain right-looking blocked Cholesky on one stream, the
+// factor is used as it is.  nreal: rows that are not identity padding.
+int cholesky_small(prg_cpd* h, double* S, int64_t mp, int* info, int64_t nreal) {
+    hipStream_t st = h->stream;
+    const size_t lds = (size_t)NB * LDP * sizeof(double);
+    for (int64_t k0 = 0; k0 < mp && k0 < nreal; k0 += NB) {
+        k_potrf_inv<<<1, kBlock, lds, st>>>(S, mp, k0, nullptr, info, nreal);
+        const int64_t row_end = std::min<int64_t>(mp, prg::round_up(nreal, NB));  // identity rows need nothing
+        const int64_t rows = row_end - (k0 + NB);
+        if (rows <= 0) break;
+        k_trsm_rows<<<(unsigned)prg::ceil_div(rows, kBlock / 8), kBlock, lds, st>>>(S, mp, k0, k0 + NB, row_end);
+        const int64_t below = rows / NB;
+        double* a21 = S + (k0 + NB) * mp + k0;
+        k_gemm_nt_f64<2><<<dim3((unsigned)below, (unsigned)below), kBlock, 0, st>>>(a21, a21, mp, mp,
+                                                                                  S + (k0 + NB) * mp + (k0 + NB), mp, NB);
+    }
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+// L L^T u = v in place, 3 right-hand sides, with the factor of cholesky_small
+int cholesky_small_solve3(prg_cpd* h, const double* S, int64_t mp, double* v, int64_t nreal) {
+    hipStream_t st = h->stream;
+    const size_t lds = (size_t)NB * LDP * sizeof(double);
+    const int64_t nblk = prg::ceil_div(std::min<int64_t>(mp, nreal), NB);  // identity blocks: u = v
+    for (int64_t kb = 0; kb < nblk; ++kb) {
+        const int64_t k0 = kb * NB;
+        k_tri_solve3<0><<<1, kBlock, lds, st>>>(S, mp, k0, v);
+        const int64_t rows = nblk * NB - k0 - NB;
+        if (rows > 0) k_fwd_update<<<(unsigned)prg::ceil_div(rows, 64), kBlock, 0, st>>>(S, mp, k0, nblk * NB, v);
+    }
+    for (int64_t kb = nblk - 1; kb >= 0; --kb) {
+        const int64_t k0 = kb * NB;
+        k_tri_solve3<1><<<1, kBlock, lds, st>>>(S, mp, k0, v);
+        if (k0 > 0) k_bwd_update<<<grid1(k0), kBlock, 0, st>>>(S, mp, k0, v);
+    }
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
 int ensure_solve_workspace(prg_cpd* h, size_t need) {
+    // kernels that keep a 128 x 129 fp64 block in LDS need the opt-in above 64 KB (once per process and device context)
+    for (const void* fn : {reinterpret_cast<const void*>(k_potrf_inv), reinterpret_cast<const void*>(k_trsm_rows),
+                           reinterpret_cast<const void*>(k_tri_solve3<0>), reinterpret_cast<const void*>(k_tri_solve3<1>)})
+        PRG_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NB * LDP * (int)sizeof(double)));
     if (h->nr_solve_bytes >= need) return PRG_OK;
     if (h->nr_solve) {
         PRG_HIP(hipStreamSynchronize(h->stream));
@@ -809,8 +973,6 @@ int ensure_solve_workspace(prg_cpd* h, size_t need) {
     h->nr_solve_bytes = 0;
     PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
     h->nr_solve_bytes = need;
-    PRG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                NB * LDP * (int)sizeof(double)));
     return PRG_OK;
 }
 
@@ -850,8 +1012,14 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
     // S = c I + F^T D F and z = F^T B in one pass over the factor
     k_lr_gram<<<ggrid, kBlock, 0, st>>>(h->F, ld, m, rank, sp, b3, chunk, part, upart);
     k_lr_gram_reduce<<<rgrid, kBlock, 0, st>>>(part, upart, ntile, nsplit, rank, rp, h->params, lmd, S, z);
-    PRG_TRY(cholesky_lookahead(h, S, rp, linv, info, rank));
-    PRG_TRY(cholesky_solve3(h, S, rp, linv, z));  // z = (c I + F^T D F)^-1 F^T B
+    const bool small = rp <= 1024;  // (beyond, the MFMA panel solves of the big factorisation pay for their inverses)
+    if (small) {
+        PRG_TRY(cholesky_small(h, S, rp, info, rank));
+        PRG_TRY(cholesky_small_solve3(h, S, rp, z, rank));  // z = (c I + F^T D F)^-1 F^T B
+    } else {
+        PRG_TRY(cholesky_lookahead(h, S, rp, linv, info, rank));
+        PRG_TRY(cholesky_solve3(h, S, rp, linv, z));
+    }
     double* gw = h->nr_work;                      // [M][3]: G W, kept for the next E-step's transform
     // W = (B - D F z) / c ... and G W = F (F^T W) = F z exactly: F^T W = (F^T B - F^T D F z) / c = (S z - (S - c I) z) / c
     PRG_TRY(prg::lowrank_apply(h, z, gw));
@@ -864,7 +1032,10 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
         k_residual<<<grid1(ld), kBlock, 0, st>>>(b3, sp, gb, h->W, m, ld, h->params, lmd, r3);
         if (rp > rank) PRG_HIP(hipMemsetAsync(z + (size_t)rank * 3, 0, (size_t)(rp - rank) * 3 * sizeof(double), st));
         PRG_TRY(prg::lowrank_ft3(h, r3, z));
-        PRG_TRY(cholesky_solve3(h, S, rp, linv, z));
+        if (small)
+            PRG_TRY(cholesky_small_solve3(h, S, rp, z, rank));
+        else
+            PRG_TRY(cholesky_solve3(h, S, rp, linv, z));
         PRG_TRY(prg::lowrank_apply(h, z, fz));
         k_lr_form_w<<<grid1(m), kBlock, 0, st>>>(r3, sp, fz, m, h->params, lmd, dw);
         k_axpy3<<<grid1(m * 3), kBlock, 0, st>>>(dw, m, h->W);
