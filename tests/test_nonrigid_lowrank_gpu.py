@@ -81,6 +81,26 @@ def test_lowrank_mstep_equals_fp64_solve_on_the_exact_matrix(seed, beta, lmd):
     assert abs(plan.get_params()[13] - s2) < 1e-9 * s2 + 1e-7 * sigma2  # (the trace difference cancels ~1e2)
 
 
+def test_wide_factor_takes_the_lookahead_factorisation():
+    """A narrow kernel (beta = 0.06) on 6000 points needs > 1024 columns: the reduced system then goes through the
+    look-ahead factorisation with block inverses instead of the small-system path - same answer as numpy's solve."""
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(6100, m=6000, seed=14)
+    reg = cpd.NonRigidCPD(src, beta=0.06, lmd=3.0)
+    reg._initialize(tgt)
+    plan = reg._plan
+    assert 1024 < plan.nonrigid_rank() <= 2048
+    sigma2 = plan.get_params()[13]
+    plan.estep(0.0)
+    pt1, p1, px = plan.get_estep()
+    plan.mstep_nonrigid(3.0)
+    w = plan.get_w()
+    y = src.astype(np.float32).astype(np.float64) - reg._origin
+    want = np.linalg.solve(p1[:, None] * _exact_g(src, 0.06) + 3.0 * sigma2 * np.identity(len(src)), px - p1[:, None] * y)
+    assert np.max(np.abs(w - want)) < 1e-7 * np.max(np.abs(want))
+
+
 def test_lowrank_and_dense_registrations_agree():
     """Same registration through both solvers: they differ only by the float32 rounding of the dense G."""
     from probreg_amd import cpd, synthetic
