@@ -7,7 +7,8 @@ north-star tolerances (transform 1e-4 relative, sigma2 1e-5 relative).
                                    the (wave, group) blocks culled) - oracle/cpd_estep_c.c, ~6 s per iteration
   C2  AffineCPD  N = M = 200 000   1 iteration from the identity and 1 continued from iteration 22 (~29 s each)
   C3  NonRigid   N = M = 12 000    3 iterations (largest M whose three M x M fp64 temporaries the numpy oracle holds
-                                   comfortably; the blocked Cholesky walks 94 diagonal blocks / 24 outer panels)
+                                   comfortably), through the kernel factor (rank ~175) AND through the dense fallback
+                                   (blocked Cholesky: 94 diagonal blocks / 24 outer panels)
   C4  FilterReg  N = M = 500 000   5 iterations, 5 % outliers, sigma2 updated - oracle/filterreg_numpy.py on the C lattice
 
 Reference lines: probreg/cpd.py:106-120 (driver), :71-88 (E-step), :160-192 / :219-244 / :284-303 (M-steps);
@@ -94,17 +95,31 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
     _check(kind, res, p, s2, q)
 
 
-def test_nonrigid_c3_style_12k_vs_oracle():
-    """C3's kernels at the largest size the numpy oracle's LAPACK solve holds: M = N = 12 000 is 94 diagonal blocks of the
-    blocked fp64 Cholesky and 24 outer 512-column panels (C3 itself: 391 / 98), beta = lmd = 2 as in the config."""
+@pytest.fixture(scope="module")
+def c3_style_oracle():
     from oracle import cpd_numpy as co
-    from probreg_amd import cpd, synthetic
+    from probreg_amd import synthetic
 
     src, tgt = synthetic.nonrigid_pair(12000, seed=0)
     p, s2, q, _ = co.registration("nonrigid", src, tgt, maxiter=3, tol=-1.0, closed_form_init=True)
-    g = co.rbf_kernel(src, src, 2.0)
-    want = co.transform("nonrigid", p, src, g)
-    res = cpd.registration_cpd(src, tgt, "nonrigid", maxiter=3, tol=-1.0)
+    return src, tgt, s2, co.transform("nonrigid", p, src, co.rbf_kernel(src, src, 2.0))
+
+
+@pytest.mark.parametrize("solver", ["factor", "dense"])
+def test_nonrigid_c3_style_12k_vs_oracle(c3_style_oracle, solver):
+    """C3's kernels at the largest size the numpy oracle's LAPACK solve holds, beta = lmd = 2 as in the config.  "factor":
+    the default path (G = F F^T, r x r reduced system); "dense": the fallback - M = N = 12 000 is 94 diagonal blocks of the
+    blocked fp64 Cholesky and 24 outer 512-column panels (C3 itself: 391 / 98)."""
+    from probreg_amd import cpd
+
+    src, tgt, s2, want = c3_style_oracle
+
+    class Dense(cpd.NonRigidCPD):
+        _solver_mode = 0
+
+    reg = (cpd.NonRigidCPD if solver == "factor" else Dense)(src)
+    res = reg.registration(tgt, maxiter=3, tol=-1.0)
+    assert (reg._plan.nonrigid_rank() > 0) == (solver == "factor")
     assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
     got = res.transformation.transform(src)
     assert np.max(np.abs(got - want)) < TOL_TF * np.max(np.abs(want - want.mean(0)))
