@@ -1198,6 +1198,13 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         first_mfma = dense && !h->have_colmin && std::isfinite(far2) && nk * far2 < 110.0;
         use_mfma = first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0);
         row_mfma = dense && (forced || nk * ext2 < row_bound);
+        static const bool debug_engine = getenv("PRG_DEBUG_ENGINE") != nullptr;
+        if (debug_engine)
+            fprintf(stderr, "[engine] sigma2 %.4e nk*ext2 %.1f (col bound %.0f, row bound %.0f) motion %.3e cmax %.3e nk*width %.1f "
+                            "nk*far2 %.1f have_colmin %d -> col %d (first %d) row %d fine %d\n",
+                    sigma2, nk * ext2, col_bound, row_bound, mo, cmax, nk * width, nk * far2, (int)h->have_colmin,
+                    (int)(first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0)), (int)first_mfma,
+                    (int)row_mfma, (int)(nk * ext2 > 200.0));
         fine_cull = nk * ext2 > 200.0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2) and the test is overhead
     }
     h->last_estep_mfma = use_mfma;
