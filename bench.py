@@ -285,7 +285,7 @@ def bench_cpd(workload, steps, warmup, tuning=""):
 # ----------------------------------------------------------------------------------------------------------------
 # C3: non-rigid CPD
 # ----------------------------------------------------------------------------------------------------------------
-def bench_nonrigid(workload, steps, warmup):
+def bench_nonrigid(workload, steps, warmup, dense_compare=True):
     """One step = E-step (fp32 sweeps over all M x N pairs) + M-step (cpd.py:284-303) on the low-rank factor of G
     (G = F F^T, pivoted Cholesky at set_source).  The timed window is EM iterations 0..steps-1 of the
     registration (state reset after the warm-up).  `dense_solver` times the same M-step through the M x M fp64
@@ -346,7 +346,7 @@ def bench_nonrigid(workload, steps, warmup):
     out["kernel_factor"] = {"rank": rank, "build_ms_incl_upload": 1e3 * t_build,
                             "what": "pivoted Cholesky of G, columns evaluated on the fly in fp64, stops at 1e-14 per entry"}
     out["result"] = {"sigma2": sigma2_end}
-    if rank > 0:  # the dense fallback on the same E-step, for the record
+    if rank > 0 and dense_compare:  # the dense fallback on the same E-step, for the record
         try:
             class _Dense(cpd.NonRigidCPD):
                 _solver_mode = 0
@@ -477,6 +477,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the parity block")
     ap.add_argument("--no-other-workloads", action="store_true", help="C1 only (skip the C2 / C3 / C4 entries)")
     ap.add_argument("--tuning", default="", help="r_col,seg_col,r_row,seg_row (0 = auto)")
+    ap.add_argument("--no-dense-compare", action="store_true",
+                    help="non-rigid: skip the M-step through the dense fallback (profiles of the product path alone)")
     args = ap.parse_args()
 
     import torch
@@ -506,8 +508,10 @@ def main():
     if kind in ("nonrigid", "filterreg", "bcpd"):
         if world > 1:
             raise SystemExit("%s runs as single-GPU replicas (DESIGN.md section 6)" % args.workload)
-        out = {"nonrigid": bench_nonrigid, "filterreg": bench_filterreg, "bcpd": bench_bcpd}[kind](
-            args.workload, args.steps, args.warmup)
+        if kind == "nonrigid":
+            out = bench_nonrigid(args.workload, args.steps, args.warmup, dense_compare=not args.no_dense_compare)
+        else:
+            out = {"filterreg": bench_filterreg, "bcpd": bench_bcpd}[kind](args.workload, args.steps, args.warmup)
         print(json.dumps(out))
         return
     out = bench_cpd(args.workload, args.steps, args.warmup, args.tuning)

@@ -28,7 +28,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU 
 done
 sum --pmc $(db $out/c4_FETCH_SIZE) $(db $out/c4_WRITE_SIZE) $(db $out/c4_SQ_INSTS_VALU) > $out/${tag}_filterreg_500k_pmc.txt
 
-c3="python bench.py --workload nonrigid_50k --steps 20 --warmup 2"
+c3="python bench.py --workload nonrigid_50k --steps 20 --warmup 2 --no-dense-compare"
 rocprofv3 --kernel-trace --stats -d $out/c3_kt -o b -- $c3 > $out/c3_line.json 2> $out/c3_kt.err
 sum $(db $out/c3_kt) > $out/${tag}_nonrigid_50k_kernel_trace.txt
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
