@@ -82,7 +82,7 @@ int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
  * each): the pair sweeps take
  * their exponents from the matrix cores (bf16x3-split MFMA distance blocks) while
  * |log2(e) / (2 sigma2)| * (squared diagonal of the larger of the source's / local target's bounding box) < bound * (n / 1e5)^1.8,
- * n = sqrt(M N_global) (bound: default 16000, the measured crossover at 1e5 points; the row pass leaves at 1/20 of it, times
+ * n = sqrt(M N_local) (bound: default 16000, the measured crossover at 1e5 points; the row pass leaves at 1/20 of it, times
  * (n / 1e5)^2 above 1e5 points; both skip exact zeros in blocks of 512 x 256 and, per wave, 128 x 32) - from there on the culled
  * vector-pipe sweeps, which skip 128 x 32 blocks, are faster and the registration stays on them; mode 0: vector-pipe sweeps only; mode 2: both sweeps on the matrix cores whatever the bound says
  * (tests, measurements).  bound = 0 keeps the current value.  prg_cpd_last_estep_engine reports which engine the last

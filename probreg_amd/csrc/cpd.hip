@@ -1180,7 +1180,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // the cull tests are next to sigma, i.e. on the point density: measured crossovers at 30k / 100k / 200k points
         // (tools/mfma_vs_valu.py) move like n^1.8 (column pass) and n^2 above 100k (row pass); dense_bound is the
         // value at n = 1e5
-        const double dens = sqrt((double)h->M * (double)h->Nglobal) / 1.0e5;
+        // (n = sqrt(M N_local): a rank that holds a shard of the target has fewer, equally dense columns - its matrix-core
+        // sweeps run out of workgroups earlier; tools/shard_steady.py)
+        const double dens = sqrt((double)h->M * (double)h->N) / 1.0e5;
         const double col_bound = h->dense_bound * pow(dens, 1.8);
         const double row_bound = 0.05 * h->dense_bound * std::max(1.0, dens * dens);
         const bool dense = ok && (forced || nk * ext2 < col_bound);
