@@ -9,6 +9,7 @@ north-star tolerances (transform 1e-4 relative, sigma2 1e-5 relative).
   C3  NonRigid   N = M = 12 000    3 iterations (largest M whose three M x M fp64 temporaries the numpy oracle holds
                                    comfortably), through the kernel factor (rank ~175) AND through the dense fallback
                                    (blocked Cholesky: 94 diagonal blocks / 24 outer panels)
+  C3  NonRigid   N = M = 50 000    4 iterations, kernel factor against the dense fallback (no oracle at this size)
   C4  FilterReg  N = M = 500 000   5 iterations, 5 % outliers, sigma2 updated - oracle/filterreg_numpy.py on the C lattice
 
 Reference lines: probreg/cpd.py:106-120 (driver), :71-88 (E-step), :160-192 / :219-244 / :284-303 (M-steps);
@@ -123,6 +124,29 @@ def test_nonrigid_c3_style_12k_vs_oracle(c3_style_oracle, solver):
     assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
     got = res.transformation.transform(src)
     assert np.max(np.abs(got - want)) < TOL_TF * np.max(np.abs(want - want.mean(0)))
+
+
+def test_nonrigid_c3_full_size_factor_vs_dense_fallback():
+    """C3 itself (N = M = 50 000) is beyond the numpy oracle (three 20 GB temporaries per M-step).  The chain of evidence at
+    this size: both solvers match the oracle at 12k (above); here they must match EACH OTHER at 50k over 4 iterations - the
+    dense fallback being the path that evaluates the reference's own float32 M x M matrix (391 Cholesky blocks)."""
+    from probreg_amd import cpd, synthetic
+
+    src, tgt = synthetic.nonrigid_pair(50000, seed=0)
+
+    class Dense(cpd.NonRigidCPD):
+        _solver_mode = 0
+
+    out = []
+    for cls in (cpd.NonRigidCPD, Dense):
+        reg = cls(src)
+        res = reg.registration(tgt, maxiter=4, tol=-1.0)
+        out.append((res.sigma2, res.transformation.transform(src), reg._plan.nonrigid_rank()))
+        del reg, res
+    assert out[0][2] > 0 and out[1][2] == 0
+    ext = np.max(np.abs(out[1][1] - out[1][1].mean(0)))
+    assert np.max(np.abs(out[0][1] - out[1][1])) < TOL_TF * ext
+    assert abs(out[0][0] - out[1][0]) <= TOL_SIGMA2 * out[1][0]
 
 
 def test_filterreg_c4_500k_vs_oracle():
