@@ -774,48 +774,43 @@ __global__ __launch_bounds__(kBlock) void k_lr_gram(const double* __restrict__ f
 }
 
 // S[a][b] = c [a == b] + sum over the splits of T's tile entry (a, b) for a, b < rank; identity in the pad (rp x rp).
-// The splits are summed in four interleaved chains (fixed order: reproducible) so that the loads overlap.
+// Four lanes share an output element: each sums every fourth split, the four partial sums are combined in a fixed order
+// (reproducible; the loads of the four chains run in parallel - one thread walking all splits is a chain of dependent adds
+// behind ~80 loads).
 __global__ __launch_bounds__(kBlock) void k_lr_gram_reduce(const double* __restrict__ part, const double* __restrict__ upart,
                                                            int ntile, int nsplit, int rank, int64_t rp,
                                                            const double* __restrict__ params, double lmd,
                                                            double* __restrict__ s, double* __restrict__ u) {
-    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (e < (int64_t)rp * 3) {  // u = F^T B (zero rows in the pad)
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        if (e < (int64_t)rank * 3) {
-            const double* __restrict__ src = upart + e;
-            const int64_t st = (int64_t)rank * 3;
-            int q = 0;
-            for (; q + 4 <= nsplit; q += 4) {
-                v0 += src[q * st];
-                v1 += src[(q + 1) * st];
-                v2 += src[(q + 2) * st];
-                v3 += src[(q + 3) * st];
-            }
-            for (; q < nsplit; ++q) v0 += src[q * st];
-        }
-        u[e] = (v0 + v1) + (v2 + v3);
-    }
-    if (e >= rp * rp) return;
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t e = t >> 2;
+    const int sub = (int)(t & 3);
+    double v = 0.0, uv = 0.0;
+    const bool in_u = e < (int64_t)rank * 3;
     const int a = (int)(e / rp), b = (int)(e % rp);
-    double v;
-    if (a < rank && b < rank) {
+    const bool in_s = e < rp * rp, real = in_s && a < rank && b < rank;
+    if (in_u) {  // u = F^T B
+        const double* __restrict__ src = upart + e;
+        const int64_t st = (int64_t)rank * 3;
+        for (int q = sub; q < nsplit; q += 4) uv += src[q * st];
+    }
+    if (real) {
         const int hi = a > b ? a : b, lo = a > b ? b : a;  // lower triangle holds (hi, lo)
         const int ta = hi / GT, tb = lo / GT;
         const int tile = ta * (ta + 1) / 2 + tb;
         const int r = hi - ta * GT, c = lo - tb * GT;
         const double* __restrict__ src = part + (int64_t)tile * (GT * GT) + r * GT + c;
         const int64_t st = (int64_t)ntile * (GT * GT);
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        int q = 0;
-        for (; q + 4 <= nsplit; q += 4) {
-            v0 += src[q * st];
-            v1 += src[(q + 1) * st];
-            v2 += src[(q + 2) * st];
-            v3 += src[(q + 3) * st];
-        }
-        for (; q < nsplit; ++q) v0 += src[q * st];
-        v = (v0 + v1) + (v2 + v3);
+        for (int q = sub; q < nsplit; q += 4) v += src[q * st];
+    }
+    // (lanes 4k .. 4k+3 hold the four chains of one element)
+    v = (v + __shfl_xor(v, 1, 64));
+    v = (v + __shfl_xor(v, 2, 64));
+    uv = (uv + __shfl_xor(uv, 1, 64));
+    uv = (uv + __shfl_xor(uv, 2, 64));
+    if (sub != 0) return;
+    if (e < rp * 3) u[e] = in_u ? uv : 0.0;  // zero rows in the pad
+    if (!in_s) return;
+    if (real) {
         if (a == b) v += lmd * params[13];
     } else {
         v = a == b ? 1.0 : 0.0;
@@ -1004,7 +999,7 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
     int* info = reinterpret_cast<int*>(trpart + 2 * (size_t)tr_blk);
     hipStream_t st = h->stream;
     const dim3 ggrid((unsigned)ntile, (unsigned)nsplit);
-    const dim3 rgrid = grid1(std::max<int64_t>((int64_t)rp * rp, rp * 3));
+    const dim3 rgrid = grid1(4 * std::max<int64_t>((int64_t)rp * rp, rp * 3));  // four lanes per element
 
     PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
     k_rhs<<<grid1(ld), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, ld, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
