@@ -98,6 +98,7 @@ struct Lattice {
     int64_t cap2 = 0;
     int* count2 = nullptr;
     bool side_pending = false;
+    bool side_fuse = false;            // the side stage is prepared and rides in the next build's first embedding launch
     int side_size = 0, side_overflow = 0;
     // feature lattices (d > 3): keys are d shorts, the table holds a 64-bit hash of them (checked by a second hash)
     short* rem0s = nullptr;             // [n][d+1] rounded remainders of every point (keys are rebuilt from these)
@@ -110,43 +111,30 @@ struct Lattice {
 };
 
 // ---- embedding (permutohedral.cpp:186-276, SSE build) -------------------------------------------------
-template <int D, bool FR>
-__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, const FrFeat fr, int64_t first,
-                                                  int64_t n, float s0, float s1, float s2,
-                                                  unsigned long long* __restrict__ tkeys, unsigned long long mask,
-                                                  unsigned gen, int* __restrict__ pslot, float* __restrict__ bary,
-                                                  int* __restrict__ count, int* __restrict__ slot_id,
-                                                  unsigned long long* __restrict__ dkeys) {
-    const int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // points [first, n)
-    if (i >= n) return;
+// One hash table of a lattice build: entries are (generation << 48) | packed key (see Lattice::gen).
+struct EmbedTable {
+    unsigned long long* tkeys;
+    unsigned long long mask;
+    unsigned gen;
+    int* count;               // [0] vertices created so far, [1] overflow flag
+    int* slot_id;             // may be null (count only)
+    unsigned long long* dkeys;
+};
+
+// Embed one point (features f, scale factors s) and insert its D + 1 vertices into table T.  pslot_i / bary_i: where the
+// point's slots and barycentric weights go, or null (the side table of the speculative with_blur decision only counts).
+template <int D>
+__device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, float s1, float s2, const EmbedTable& T,
+                                             int lane, int* __restrict__ pslot_i, float* __restrict__ bary_i) {
     constexpr int D1 = D + 1;
+    unsigned long long* __restrict__ tkeys = T.tkeys;
+    const unsigned long long mask = T.mask;
+    const unsigned gen = T.gen;
+    int* __restrict__ count = T.count;
+    int* __restrict__ slot_id = T.slot_id;
+    unsigned long long* __restrict__ dkeys = T.dkeys;
     const unsigned long long gbits = (unsigned long long)gen << 48;
-    const int lane = threadIdx.x & 63;
     const float scale[3] = {s0, s1, s2};
-    float f[D];
-    if (FR) {
-        const double sigma = sqrt(fr.state[12]);
-        if (i < fr.m) {
-            double y[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < D; ++k) y[k] = fr.src[i * D + k];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc += y[k] * fr.state[3 * r + k];  // dot(points, rot.T), transformation.py:49-50
-                const double z = r < D ? acc + fr.state[9 + r] : 0.0;
-                fr.ts[i * 3 + r] = z;
-                if (r < D) f[r < D ? r : 0] = (float)(z / sigma);
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < D; ++k) f[k] = (float)(fr.tgt[(i - fr.m) * D + k] / sigma);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < D; ++k) f[k] = feat[i * D + k];
-    }
     float elevated[D1], rem0[D1], rank[D1], bar[D1 + 1];
     float sm = 0.f;
 #pragma unroll
@@ -241,8 +229,10 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
             cslot[r] = (int)slot;
             ckey[r] = pk;
         }
-        pslot[i * D1 + r] = (int)slot;
-        bary[i * D1 + r] = bar[r];
+        if (pslot_i) {
+            pslot_i[r] = (int)slot;
+            bary_i[r] = bar[r];
+        }
     }
     // whoever created a vertex numbers it (no scan of the table afterwards): ONE counter update per wave - the lanes'
     // claims of all D + 1 rounds are ranked with ballots, the first claiming lane fetches the base
@@ -274,6 +264,45 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
             }
         }
     }
+}
+
+// side.tkeys != null: the same points are ALSO embedded with the scale factors (t0, t1, t2) into the side table (count
+// only) - the speculative with_blur decision of prg_fr_estep rides in the first launch of the build instead of its own.
+template <int D, bool FR>
+__global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, const FrFeat fr, int64_t first,
+                                                  int64_t n, float s0, float s1, float s2, const EmbedTable table,
+                                                  int* __restrict__ pslot, float* __restrict__ bary,
+                                                  const EmbedTable side, float t0, float t1, float t2) {
+    const int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // points [first, n)
+    if (i >= n) return;
+    constexpr int D1 = D + 1;
+    const int lane = threadIdx.x & 63;
+    float f[D];
+    if (FR) {
+        const double sigma = sqrt(fr.state[12]);
+        if (i < fr.m) {
+            double y[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < D; ++k) y[k] = fr.src[i * D + k];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += y[k] * fr.state[3 * r + k];  // dot(points, rot.T), transformation.py:49-50
+                const double z = r < D ? acc + fr.state[9 + r] : 0.0;
+                fr.ts[i * 3 + r] = z;
+                if (r < D) f[r < D ? r : 0] = (float)(z / sigma);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) f[k] = (float)(fr.tgt[(i - fr.m) * D + k] / sigma);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) f[k] = feat[i * D + k];
+    }
+    embed_insert<D>(f, s0, s1, s2, table, lane, pslot + i * D1, bary + i * D1);
+    if (side.tkeys) embed_insert<D>(f, t0, t1, t2, side, lane, nullptr, nullptr);
 }
 
 // ---- feature-space lattices, d > 3 (filterreg.py:121, 125-133 with feature_fn = FPFH: d = 33) ---------------------
@@ -670,20 +699,21 @@ void lat_scale(int d, int with_blur, float (&sc)[3]) {
     for (int i = 0; i < 3; ++i) sc[i] = i < d ? (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std) : 0.f;
 }
 
-// count: [0] vertices created so far, [1] overflow flag; slot_id / dkeys may be null (count only)
-void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&sc)[3], unsigned long long* table,
-                  unsigned long long mask, unsigned gen, int* count, int* slot_id, unsigned long long* dkeys) {
+// Embedding launch over points [first, last) into `table`; side (tkeys may be null): the same points also go, with the
+// scale factors ssc, into the side table of the speculative with_blur decision.
+void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&sc)[3], const EmbedTable& table,
+                  const EmbedTable& side, const float (&ssc)[3]) {
     const unsigned nb = (unsigned)prg::ceil_div(last - first, kBlock);
     if (nb == 0) return;
     hipStream_t st = L->stream;
     const FrFeat none = {nullptr, nullptr, nullptr, nullptr, 0, 0};
 #define PRG_EMBED(DD)                                                                                              \
     if (L->prod)                                                                                                    \
-        k_embed<DD, true><<<nb, kBlock, 0, st>>>(nullptr, *L->prod, first, last, sc[0], sc[1], sc[2], table, mask,  \
-                                                 gen, L->pslot, L->bary, count, slot_id, dkeys);                    \
+        k_embed<DD, true><<<nb, kBlock, 0, st>>>(nullptr, *L->prod, first, last, sc[0], sc[1], sc[2], table,        \
+                                                 L->pslot, L->bary, side, ssc[0], ssc[1], ssc[2]);                  \
     else                                                                                                            \
-        k_embed<DD, false><<<nb, kBlock, 0, st>>>(L->feat, none, first, last, sc[0], sc[1], sc[2], table, mask,     \
-                                                  gen, L->pslot, L->bary, count, slot_id, dkeys)
+        k_embed<DD, false><<<nb, kBlock, 0, st>>>(L->feat, none, first, last, sc[0], sc[1], sc[2], table,           \
+                                                  L->pslot, L->bary, side, ssc[0], ssc[1], ssc[2])
     if (d == 1) { PRG_EMBED(1); }
     else if (d == 2) { PRG_EMBED(2); }
     else { PRG_EMBED(3); }
@@ -744,9 +774,10 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         PRG_TRY(next_generation(L->tkeys, L->cap, &L->gen, st));
         PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
         const unsigned long long mask = (unsigned long long)capu - 1;
-        auto embed = [&](int64_t first, int64_t last) {
-            launch_embed(L, d, first, last, sc, L->tkeys, mask, L->gen, L->count, L->slot_id, L->dkeys);
-        };
+        const EmbedTable main_table = {L->tkeys, mask, L->gen, L->count, L->slot_id, L->dkeys};
+        const EmbedTable no_side = {nullptr, 0, 0, nullptr, nullptr, nullptr};
+        const float no_sc[3] = {0.f, 0.f, 0.f};
+        auto embed = [&](int64_t first, int64_t last) { launch_embed(L, d, first, last, sc, main_table, no_side, no_sc); };
         if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
         volatile int* host = reinterpret_cast<volatile int*>(L->pinned);
         host[0] = host[1] = 0;
@@ -770,7 +801,16 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
             // all points has every wave compare-and-swap the same few hundred empty slots at once (3x slower while
             // the lattice is small)
             done = n / 16;
-            embed(0, done);
+            if (L->side_fuse) {  // the prepared side stage (lat_side_stage) covers exactly these points: one launch for both
+                float bsc[3];
+                lat_scale(d, 1, bsc);
+                const EmbedTable side = {L->tkeys2, (unsigned long long)L->cap2 - 1, L->gen2, L->count2, nullptr, nullptr};
+                launch_embed(L, d, 0, done, sc, main_table, side, bsc);
+                L->side_fuse = false;
+                L->side_pending = true;
+            } else {
+                embed(0, done);
+            }
         }
         if (host[1] == 0) {
             embed(done, n);
@@ -818,9 +858,9 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
     return PRG_OK;
 }
 
-// Decision stage of the blurred lattice into the side table, WITHOUT synchronising: 1/16 of the points are hashed with
-// the blur scaling and counted as they create vertices; the count is read back by the next lat_build on this lattice
-// (side_pending).  A subset's vertices are a subset of the vertices, so side_size > threshold proves that the blurred
+// Decision stage of the blurred lattice into the side table, WITHOUT synchronising and without a launch of its own: 1/16
+// of the points are hashed with the blur scaling (by the next lat_build's first embedding launch, side_fuse) and counted
+// as they create vertices; the count is read back by that lat_build (side_pending).  A subset's vertices are a subset of the vertices, so side_size > threshold proves that the blurred
 // lattice is too large.
 int lat_side_stage(Lattice* L, int64_t n, int d) {
     const int d1 = d + 1;
@@ -842,9 +882,8 @@ int lat_side_stage(Lattice* L, int64_t n, int d) {
     lat_scale(d, 1, sc);
     PRG_TRY(next_generation(L->tkeys2, L->cap2, &L->gen2, st));
     PRG_HIP(hipMemsetAsync(L->count2, 0, 2 * sizeof(int), st));
-    launch_embed(L, d, 0, n16, sc, L->tkeys2, (unsigned long long)L->cap2 - 1, L->gen2, L->count2, nullptr, nullptr);
-    PRG_HIP(hipGetLastError());
-    L->side_pending = true;
+    (void)sc;
+    L->side_fuse = true;  // launched by the next lat_build on this lattice, together with its first sixteenth
     return PRG_OK;
 }
 
