@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.  With the defaults (1 GPU, C1) it also carries
   parity          GPU vs the CPU oracle on the cpu_baseline sample (same inputs, same iterations)
   cpu_baseline    oracle/cpd_estep_c.c timed on the host cores at three sizes, fitted t = a M N
   other_workloads C2 (affine 200k), C3 (non-rigid 50k), C4 (FilterReg 500k) measured the same way, each with its roofline
+                  and its own GPU-vs-oracle parity block (reduced samples of the same generators)
 """
 import argparse
 import json
@@ -120,6 +121,59 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
     parity["ok"] = bool(parity["rot_max_abs_err"] < 1e-4 and parity["t_max_abs_err"] < 1e-4
                         and parity["scale_rel_err"] < 1e-4 and parity["sigma2_rel_err"] < 1e-5)
     return baseline, parity
+
+
+def parity_other_workloads():
+    """GPU vs CPU oracle for C2 / C3 / C4 on reduced samples of the same generators (the C1 block rides on the
+    cpu_baseline sample); the full-size comparisons live in tests/test_fullsize_gpu.py.  Tolerances: BASELINE.json."""
+    from oracle import cpd_c, cpd_numpy as co, filterreg_numpy as fo
+    from probreg_amd import cpd, filterreg, synthetic
+
+    out = {}
+    tol = {"transform": 1e-4, "sigma2": 1e-5}
+    # C2: affine, 40k x 40k, 2 iterations (C E-step + numpy M-step)
+    n, iters = 40000, 2
+    src, tgt, _ = synthetic.affine_pair(n, seed=0)
+    s2 = co.squared_kernel_sum_closed_form(src, tgt)
+    p = dict(b=np.identity(3), t=np.zeros(3))
+    for _ in range(iters):
+        es = co.EstepResult(*cpd_c.expectation_step(co.transform("affine", p, src), tgt, s2, 0.0))
+        p, s2, _q = co.mstep_affine(src, tgt, es)
+    res = cpd.registration_cpd(src, tgt, "affine", maxiter=iters, tol=-1.0)
+    e = {"against": "oracle (C E-step + numpy M-step, fp64) on synthetic.affine_pair(%d, seed=0), %d EM iterations" % (n, iters),
+         "b_rel_err": float(np.max(np.abs(res.transformation.b - p["b"])) / np.max(np.abs(p["b"]))),
+         "t_max_abs_err": float(np.max(np.abs(res.transformation.t - p["t"]))),
+         "sigma2_rel_err": float(abs(res.sigma2 - s2) / s2), "tolerance": tol}
+    e["ok"] = bool(e["b_rel_err"] < 1e-4 and e["t_max_abs_err"] < 1e-4 and e["sigma2_rel_err"] < 1e-5)
+    out["affine_200k"] = e
+    # C3: non-rigid, 4k x 4k (numpy LAPACK solve on the float32 G), 3 iterations
+    n, iters = 4000, 3
+    src, tgt = synthetic.nonrigid_pair(n, seed=0)
+    p, s2, _q, _ = co.registration("nonrigid", src, tgt, maxiter=iters, tol=-1.0, closed_form_init=True)
+    want = co.transform("nonrigid", p, src, co.rbf_kernel(src, src, 2.0))
+    res = cpd.registration_cpd(src, tgt, "nonrigid", maxiter=iters, tol=-1.0)
+    got = res.transformation.transform(src)
+    e = {"against": "oracle (numpy fp64, reference formulation cpd.py:284-303 on the float32 G) on "
+                    "synthetic.nonrigid_pair(%d, seed=0), %d EM iterations" % (n, iters),
+         "transformed_source_max_err_over_extent": float(np.max(np.abs(got - want)) / np.max(np.abs(want - want.mean(0)))),
+         "sigma2_rel_err": float(abs(res.sigma2 - s2) / s2), "tolerance": tol,
+         "full_size": "tests/test_fullsize_gpu.py::test_nonrigid_c3_full_size_vs_lapack (N = M = 50 000, LAPACK dgesv on the host)"}
+    e["ok"] = bool(e["transformed_source_max_err_over_extent"] < 1e-4 and e["sigma2_rel_err"] < 1e-5)
+    out["nonrigid_50k"] = e
+    # C4: FilterReg, 50k x 50k with 5 % outliers, 4 iterations (C lattice, bit-identical to the reference's vendored one)
+    n, iters = 50000, 4
+    src, tgt, _ = synthetic.filterreg_pair(n, seed=0)
+    s2_0 = float(np.float32(co.squared_kernel_sum_closed_form(src, tgt)))
+    rot, t, s2, q, _k = fo.registration(src, tgt, sigma2=s2_0, update_sigma2=True, w=0.05, maxiter=iters, tol=-1.0)
+    res = filterreg.registration_filterreg(src, tgt, sigma2=s2_0, update_sigma2=True, w=0.05, maxiter=iters, tol=-1.0)
+    e = {"against": "oracle (filterreg_numpy on the C permutohedral lattice) on synthetic.filterreg_pair(%d, seed=0), "
+                    "%d EM iterations, w = 0.05, sigma2 updated" % (n, iters),
+         "rot_max_abs_err": float(np.max(np.abs(res.transformation.rot - rot))),
+         "t_max_abs_err": float(np.max(np.abs(res.transformation.t - t))),
+         "sigma2_rel_err": float(abs(res.sigma2 - s2) / s2), "q_rel_err": float(abs(res.q - q) / abs(q)), "tolerance": tol}
+    e["ok"] = bool(e["rot_max_abs_err"] < 1e-4 and e["t_max_abs_err"] < 1e-4 and e["sigma2_rel_err"] < 1e-5)
+    out["filterreg_500k"] = e
+    return out
 
 
 def _pmc_traffic(workload, key):
@@ -527,6 +581,13 @@ def main():
                 except Exception as e:  # a failing side workload must not take the headline line with it
                     others[name] = {"error": "%s: %s" % (type(e).__name__, e)}
                 torch.cuda.empty_cache()
+            if not args.no_cpu_baseline:
+                try:
+                    for name, blk in parity_other_workloads().items():
+                        if name in others and "error" not in others[name]:
+                            others[name]["parity"] = blk
+                except Exception as e:
+                    others["parity_error"] = "%s: %s" % (type(e).__name__, e)
             out["other_workloads"] = others
         print(json.dumps(out))
     if torch.distributed.is_available() and torch.distributed.is_initialized():

@@ -114,3 +114,45 @@ double cpd_oracle_estep(const double* ts, int64_t m, const double* x, int64_t n,
     free(den);
     return n_p;
 }
+
+/* ---- non-rigid M-step pieces at sizes numpy cannot hold (tests/test_fullsize_gpu.py, C3 at N = M = 50 000) ----------
+ * The reference's G (transformation.py:91-99 -> cc/math_utils.cc:17-19) is a float32 matrix: squared distance and exp in
+ * float32 (un-fused: this file is built for x86-64-v2, which has no FMA) as in oracle/cpd_numpy.py:rbf_kernel; the squared
+ * distances are bit-identical to that function's, the exponential is glibc's expf (correctly rounded in > 99.9 % of the cases)
+ * where numpy and Eigen use their own vectorised float32 exp (each within 1 ulp): entries agree to 1 float32 ulp.  The two
+ * functions below evaluate the entries on the fly instead of storing M x M floats. */
+static inline float rbf32(const float* a, const float* b, int d, float den) {
+    float s = 0.f;
+    for (int k = 0; k < d; ++k) {
+        const float t = a[k] - b[k];
+        s += t * t;
+    }
+    return expf(-s / den);
+}
+
+/* a (column-major M x M float64, LAPACK layout) = (p1 * g).T + c I of cpd.py:297, i.e. a[i][j] = p1[i] g[i][j] + c delta_ij */
+void cpd_oracle_nonrigid_lhs(const float* y32, int64_t m, int d, double beta, const double* p1, double c, double* a) {
+    const float den = (float)(2.0 * beta);
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < m; ++j) {
+        double* col = a + j * m;
+        const float* yj = y32 + j * d;
+        for (int64_t i = 0; i < m; ++i) col[i] = p1[i] * (double)rbf32(y32 + i * d, yj, d, den);
+        col[j] += c;
+    }
+}
+
+/* out (M x d float64) = g @ w with float64 accumulation (numpy upcasts the float32 g for the product, cpd.py:298) */
+void cpd_oracle_nonrigid_gw(const float* y32, int64_t m, int d, double beta, const double* w, double* out) {
+    const float den = (float)(2.0 * beta);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < m; ++i) {
+        double acc[3] = {0.0, 0.0, 0.0};
+        const float* yi = y32 + i * d;
+        for (int64_t j = 0; j < m; ++j) {
+            const double g = (double)rbf32(yi, y32 + j * d, d, den);
+            for (int k = 0; k < d; ++k) acc[k] += g * w[j * d + k];
+        }
+        for (int k = 0; k < d; ++k) out[i * d + k] = acc[k];
+    }
+}

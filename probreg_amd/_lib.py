@@ -36,7 +36,7 @@ def _load():
     # whatever the import order of the caller.  torch stays optional.
     try:
         import torch  # noqa: F401
-    except ImportError:  # pragma: no cover
+    except Exception:  # pragma: no cover - torch absent, or present with broken shared libraries (OSError): stay usable
         pass
     if not os.path.isfile(LIB_PATH):
         raise ImportError(

@@ -107,8 +107,10 @@ class CoherentPointDrift(abc.ABC):
     def maximization_step(self, target, estep_res, sigma2_p=None):
         return self._maximization_step(self._source, target, estep_res, sigma2_p)
 
+    @staticmethod
     @abc.abstractmethod
-    def _maximization_step(self, source, target, estep_res, sigma2_p=None):
+    def _maximization_step(source, target, estep_res, sigma2_p=None, xp=np):
+        """A static method in every subclass, with the reference's signature (cpd.py:95-104)."""
         return None
 
     # -- plan handling ------------------------------------------------------------------------
@@ -124,11 +126,13 @@ class CoherentPointDrift(abc.ABC):
         if source.shape[1] != target.shape[1] or source.shape[1] not in (2, 3):
             raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
         rank, world = pdist.world()
-        cy, cx = self._centres(source, target)
-        rows = pdist.spatial_shard(target, rank, world)
-        if len(rows) == 0:
+        # the GLOBAL condition, so every rank raises together (a per-rank "my slice is empty" test would leave the
+        # other ranks waiting in the first all-reduce)
+        if target.shape[0] < world:
             raise ValueError("the target has %d points, fewer than the %d ranks it is sharded over."
                              % (target.shape[0], world))
+        cy, cx = self._centres(source, target)
+        rows = pdist.spatial_shard(target, rank, world)
         plan = self._plan if self._plan is not None else CpdPlan(self._device)
         self._plan = plan
         self._cy, self._cx = cy, cx
@@ -231,18 +235,17 @@ class RigidCPD(CoherentPointDrift):
         plan.mstep(_lib.PRG_TF_RIGID, self._update_scale)
 
     def _result_from_params(self, params):
-        dim = self._source.shape[1]
-        rot = params[:9].reshape(3, 3)[:dim, :dim].copy()
-        scale = float(params[12])
-        t = params[9:9 + dim] + self._cx - scale * rot @ self._cy
-        return MstepResult(tf.RigidTransformation(rot, t, scale), float(params[13]), float(params[14]))
+        return _rigid_result(params, self._source.shape[1], self._cy, self._cx)
 
     def maximization_step(self, target, estep_res, sigma2_p=None):
-        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._update_scale)
+        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._update_scale,
+                                       _device=self._device)
 
-    def _maximization_step(self, source, target, estep_res, sigma2_p=None, update_scale=True):
-        """Rigid M-step from explicit EstepResult arrays (reference cpd.py:160-192), on the GPU."""
-        return _mstep_from_arrays(self, source, target, estep_res, _lib.PRG_TF_RIGID, update_scale)
+    @staticmethod
+    def _maximization_step(source, target, estep_res, sigma2_p=None, update_scale=True, xp=np, _device=None):
+        """Rigid M-step from explicit EstepResult arrays, on the GPU - a static method with the reference's signature
+        (cpd.py:160-192); ``xp`` is accepted and ignored, ``_device`` picks the GPU (default: the current one)."""
+        return _mstep_from_arrays(source, target, estep_res, _lib.PRG_TF_RIGID, update_scale, _device)
 
 
 class AffineCPD(CoherentPointDrift):
@@ -272,26 +275,42 @@ class AffineCPD(CoherentPointDrift):
         plan.mstep(_lib.PRG_TF_AFFINE, True)
 
     def _result_from_params(self, params):
-        dim = self._source.shape[1]
-        b = params[:9].reshape(3, 3)[:dim, :dim].copy()
-        if not np.all(np.isfinite(b)):
-            # Y^T diag(P1) Y is singular (fewer than D + 1 supported source points, or coplanar ones): the
-            # reference's np.linalg.solve (cpd.py:237) raises here, the device solve leaves non-finite numbers
-            raise np.linalg.LinAlgError("Singular matrix")
-        t = params[9:9 + dim] + self._cx - b @ self._cy
-        return MstepResult(tf.AffineTransformation(b, t), float(params[13]), float(params[14]))
+        return _affine_result(params, self._source.shape[1], self._cy, self._cx)
 
-    def _maximization_step(self, source, target, estep_res, sigma2_p=None):
-        """Affine M-step from explicit EstepResult arrays (reference cpd.py:219-244), on the GPU."""
-        return _mstep_from_arrays(self, source, target, estep_res, _lib.PRG_TF_AFFINE, True)
+    def maximization_step(self, target, estep_res, sigma2_p=None):
+        return self._maximization_step(self._source, target, estep_res, sigma2_p, _device=self._device)
+
+    @staticmethod
+    def _maximization_step(source, target, estep_res, sigma2_p=None, xp=np, _device=None):
+        """Affine M-step from explicit EstepResult arrays, on the GPU - static, the reference's signature
+        (cpd.py:219-244)."""
+        return _mstep_from_arrays(source, target, estep_res, _lib.PRG_TF_AFFINE, True, _device)
 
 
-def _mstep_from_arrays(obj, source, target, estep_res, kind, update_scale):
+def _rigid_result(params, dim, cy, cx):
+    """Parameter block of the centred frame -> MstepResult in the caller's frame (z - cx = s R (y - cy) + t')."""
+    rot = params[:9].reshape(3, 3)[:dim, :dim].copy()
+    scale = float(params[12])
+    t = params[9:9 + dim] + cx - scale * rot @ cy
+    return MstepResult(tf.RigidTransformation(rot, t, scale), float(params[13]), float(params[14]))
+
+
+def _affine_result(params, dim, cy, cx):
+    b = params[:9].reshape(3, 3)[:dim, :dim].copy()
+    if not np.all(np.isfinite(b)):
+        # Y^T diag(P1) Y is singular (fewer than D + 1 supported source points, or coplanar ones): the
+        # reference's np.linalg.solve (cpd.py:237) raises here, the device solve leaves non-finite numbers
+        raise np.linalg.LinAlgError("Singular matrix")
+    t = params[9:9 + dim] + cx - b @ cy
+    return MstepResult(tf.AffineTransformation(b, t), float(params[13]), float(params[14]))
+
+
+def _mstep_from_arrays(source, target, estep_res, kind, update_scale, device=None):
     source = _as_points(source)
     target = _as_points(target)
     pt1, p1, px, n_p = estep_res
     cy, cx = source.mean(axis=0), target.mean(axis=0)
-    plan = CpdPlan(obj._device)
+    plan = CpdPlan(device)
     try:
         plan.set_source(source - cy)
         plan.set_target(target - cx)
@@ -305,12 +324,8 @@ def _mstep_from_arrays(obj, source, target, estep_res, kind, update_scale):
         params = plan.get_params()
     finally:
         plan.close()
-    obj_cy, obj_cx = getattr(obj, "_cy", None), getattr(obj, "_cx", None)
-    obj._cy, obj._cx = cy, cx
-    try:
-        return obj._result_from_params(params)
-    finally:
-        obj._cy, obj._cx = obj_cy, obj_cx
+    conv = _rigid_result if kind == _lib.PRG_TF_RIGID else _affine_result
+    return conv(params, source.shape[1], cy, cx)
 
 
 class NonRigidCPD(CoherentPointDrift):
@@ -340,23 +355,8 @@ class NonRigidCPD(CoherentPointDrift):
         return self._origin, self._origin
 
     def _build(self):
-        self._plan = CpdPlan(self._device)
-        # both clouds are Morton-sorted inside the plan (culled / matrix-core sweeps); W, the priors and the transformed
-        # points cross the C-ABI in the caller's order, and every rank sorts the replicated source the same way, so the
-        # per-point all-reduce block lines up across ranks
-        self._plan.set_options(sort_source=True, sort_target=True, cull=True)
-        # G is built from the float32 source exactly as the reference's pybind cast sees it (cc/math_utils.cc:17-19),
-        # so clouds near the origin are uploaded as they are.  A cloud FAR from the origin (coordinates many times its
-        # own extent, e.g. examples/face-x.txt with z ~ 1277) would lose its fine structure in that cast - in the
-        # E-step's float32 differences as well as in G - so it is shifted by its fp64 mean first: differences, G and the
-        # displacement field are translation invariant, and the reference's own float32 G is no yardstick there.
-        c = self._source.mean(axis=0)
-        ext = float(np.max(self._source.max(axis=0) - self._source.min(axis=0)))
-        self._origin = c if float(np.max(np.abs(c))) > 8.0 * max(ext, 1e-300) else np.zeros(self._source.shape[1])
-        self._plan.set_source(self._source - self._origin)
+        self._plan, self._origin = _nonrigid_plan(self._source, self._beta, self._device, self._solver_mode)
         self._source_uploaded = True
-        self._plan.set_nonrigid_solver(self._solver_mode)
-        self._plan.build_g(self._beta)
         self._tf_obj = tf.NonRigidTransformation(None, self._source, self._beta, _plan=self._plan,
                                                  _plan_points=self._source - self._origin)
 
@@ -397,30 +397,40 @@ class NonRigidCPD(CoherentPointDrift):
         return MstepResult(self._tf_obj, float(params[13]), float(params[14]))
 
     def maximization_step(self, target, estep_res, sigma2_p=None):
-        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._tf_obj, self._lmd)
+        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._tf_obj, self._lmd,
+                                       _device=self._device, _solver_mode=self._solver_mode)
 
-    def _maximization_step(self, source, target, estep_res, sigma2_p, tf_obj=None, lmd=None, xp=np):
-        """Non-rigid M-step from explicit EstepResult arrays (reference cpd.py:272-303), on the GPU.
+    @staticmethod
+    def _maximization_step(source, target, estep_res, sigma2_p, tf_obj, lmd, xp=np, _priors=None, _device=None,
+                           _solver_mode=1):
+        """Non-rigid M-step from explicit EstepResult arrays, on the GPU - a static method with the reference's
+        signature (cpd.py:284-303): any ``source`` with a ``NonRigidTransformation`` built on it will do.
 
-        ``(diag(p1) G + lmd sigma2_p I) W = px - diag(p1) Y`` is solved by the plan that holds ``G`` for this
-        object's source; like the reference the transformation object is updated in place (``tf_obj.w``) and returned,
-        and ``q`` is the new sigma2.  ``sigma2_p`` is the variance of the E-step that produced ``estep_res``.
+        ``(diag(p1) G + lmd sigma2_p I) W = px - diag(p1) Y`` is solved on a plan that belongs to ``tf_obj`` (created
+        on the first call, kept for the next ones: the kernel factor of ``tf_obj``'s control points) - never on the
+        plan of a running registration, whose EM state a call from a callback must not disturb.  Like the reference,
+        ``tf_obj.w`` is updated in place, the object is returned and ``q`` is the new sigma2.  ``sigma2_p`` is the
+        variance of the E-step that produced ``estep_res``.
         """
         if sigma2_p is None:
             raise ValueError("NonRigidCPD.maximization_step needs sigma2_p (the regulariser is lmd * sigma2_p).")
-        tf_obj = self._tf_obj if tf_obj is None else tf_obj
-        lmd = self._lmd if lmd is None else lmd
         source = _as_points(source)
-        if tf_obj is not self._tf_obj or source.shape != self._source.shape or not np.array_equal(source, self._source):
-            raise ValueError("NonRigidCPD._maximization_step: source / tf_obj must be this object's own (G lives "
-                             "on the GPU plan built for them).")
         target = _as_points(target)
+        ctrl = np.asarray(tf_obj._points, dtype=np.float64)
+        if source.shape != ctrl.shape or not np.array_equal(source, ctrl):
+            raise ValueError("NonRigidCPD._maximization_step: source must be the control points tf_obj was built on "
+                             "(the reference reads G from tf_obj and Y from source; both are the same cloud).")
+        cache = getattr(tf_obj, "_mstep_plan", None)
+        if cache is None:
+            cache = _nonrigid_plan(ctrl, tf_obj._beta, _device, _solver_mode)
+            tf_obj._mstep_plan = cache
+        plan, origin = cache
         pt1, p1, px, _n_p = estep_res
-        plan = self._plan
-        plan.set_target(target - self._origin, n_global=target.shape[0])
-        px = np.asarray(px, dtype=np.float64) - np.outer(p1, self._origin)  # P X in the plan's frame
-        self._upload_priors(target)
-        plan.moments_from_estep(pt1, p1, px)
+        plan.set_target(target - origin, n_global=target.shape[0])
+        if _priors is not None:
+            alpha, p1_tilde, px_tilde = _priors
+            plan.set_priors(p1_tilde, np.asarray(px_tilde, dtype=np.float64) - np.outer(p1_tilde, origin), alpha)
+        plan.moments_from_estep(pt1, p1, np.asarray(px, dtype=np.float64) - np.outer(p1, origin))  # P X in the plan's frame
         p = plan.get_params()
         p[13] = float(sigma2_p)
         plan.set_params(p)
@@ -429,8 +439,27 @@ class NonRigidCPD(CoherentPointDrift):
         tf_obj.w = plan.get_w()
         return MstepResult(tf_obj, float(out[13]), float(out[14]))
 
-    def _upload_priors(self, target):
-        """Hook of ConstrainedNonRigidCPD; plain non-rigid CPD has no correspondence priors."""
+
+def _nonrigid_plan(points, beta, device=None, solver_mode=1):
+    """A GPU plan holding the kernel ``G = exp(-|y_i - y_j|^2 / (2 beta))`` of ``points`` (as its factor when the rank
+    allows).  Returns ``(plan, origin)``; the plan works in the frame ``points - origin``."""
+    plan = CpdPlan(device)
+    # both clouds are Morton-sorted inside the plan (culled / matrix-core sweeps); W, the priors and the transformed
+    # points cross the C-ABI in the caller's order, and every rank sorts the replicated source the same way, so the
+    # per-point all-reduce block lines up across ranks
+    plan.set_options(sort_source=True, sort_target=True, cull=True)
+    # G is built from the float32 source exactly as the reference's pybind cast sees it (cc/math_utils.cc:17-19),
+    # so clouds near the origin are uploaded as they are.  A cloud FAR from the origin (coordinates many times its
+    # own extent, e.g. examples/face-x.txt with z ~ 1277) would lose its fine structure in that cast - in the
+    # E-step's float32 differences as well as in G - so it is shifted by its fp64 mean first: differences, G and the
+    # displacement field are translation invariant, and the reference's own float32 G is no yardstick there.
+    c = points.mean(axis=0)
+    ext = float(np.max(points.max(axis=0) - points.min(axis=0)))
+    origin = c if float(np.max(np.abs(c))) > 8.0 * max(ext, 1e-300) else np.zeros(points.shape[1])
+    plan.set_source(points - origin)
+    plan.set_nonrigid_solver(solver_mode)
+    plan.build_g(beta)
+    return plan, origin
 
 
 class ConstrainedNonRigidCPD(NonRigidCPD):
@@ -456,7 +485,8 @@ class ConstrainedNonRigidCPD(NonRigidCPD):
         self.idx_source, self.idx_target = idx_source, idx_target
         super(ConstrainedNonRigidCPD, self).__init__(source, beta, lmd, use_cuda, device)
 
-    def _upload_priors(self, target):
+    def _priors_for(self, target):
+        """``p1_tilde`` (M) and ``px_tilde`` (M x D) of the reference's 0-1 matrix ``p_tilde`` (cpd.py:370-374)."""
         target = _as_points(target)
         m, dim = self._source.shape
         self.p1_tilde = np.zeros(m)
@@ -466,13 +496,29 @@ class ConstrainedNonRigidCPD(NonRigidCPD):
             pairs = np.unique(np.stack([np.asarray(self.idx_source), np.asarray(self.idx_target)], axis=1), axis=0)
             np.add.at(self.p1_tilde, pairs[:, 0], 1.0)
             np.add.at(self.px_tilde, pairs[:, 0], target[pairs[:, 1]])
-        # (the plan works in the shifted frame of NonRigidCPD._build)
-        self._plan.set_priors(self.p1_tilde, self.px_tilde - np.outer(self.p1_tilde, self._origin), self.alpha)
+        return self.p1_tilde, self.px_tilde
 
     def _initialize(self, target):
         res = super(ConstrainedNonRigidCPD, self)._initialize(target)
-        self._upload_priors(target)
+        p1_tilde, px_tilde = self._priors_for(target)
+        # (the plan works in the shifted frame of _nonrigid_plan)
+        self._plan.set_priors(p1_tilde, px_tilde - np.outer(p1_tilde, self._origin), self.alpha)
         return res
+
+    def maximization_step(self, target, estep_res, sigma2_p=None):
+        # the reference reads self.p1_tilde / self.px_tilde left by _initialize (cpd.py:349-364); here they are (re)built
+        # from ``target``, so the call also works on an object that has not run a registration yet
+        p1_tilde, px_tilde = self._priors_for(target)
+        return self._maximization_step(self._source, target, estep_res, sigma2_p, self._tf_obj, self._lmd, self.alpha,
+                                       p1_tilde, px_tilde, _device=self._device, _solver_mode=self._solver_mode)
+
+    @staticmethod
+    def _maximization_step(source, target, estep_res, sigma2_p, tf_obj, lmd, alpha, p1_tilde, px_tilde, xp=np,
+                           _device=None, _solver_mode=1):
+        """Constrained non-rigid M-step on explicit arrays - static, the reference's signature (cpd.py:377-404)."""
+        return NonRigidCPD._maximization_step(source, target, estep_res, sigma2_p, tf_obj, lmd, xp,
+                                              _priors=(alpha, p1_tilde, px_tilde), _device=_device,
+                                              _solver_mode=_solver_mode)
 
 
 def registration_cpd(source, target, tf_type_name="rigid", w=0.0, maxiter=50, tol=0.001, callbacks=[],

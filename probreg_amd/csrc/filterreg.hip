@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset
 // lattice is small (sigma large: a few hundred vertices shared by 2M point-vertex incidences) this removes
 // the same-address global atomic storm; when a chunk touches more distinct vertices than the table holds,
 // the overflow goes straight to global memory, where contention is low by then.
-// (512 points / 512 slots per workgroup: 18 KB of LDS, 8 workgroups per CU.  The first version used 2048 / 2048 = 72 KB:
+// (256 points / 256 slots per workgroup: 9 KB of LDS, 8 workgroups per CU.  The first version used 2048 / 2048 = 72 KB:
 // 245 workgroups of one wave per SIMD each, every lane walking 32 incidences through dependent loads and returning LDS
 // atomics with nobody to hide the latency - 52 % of the wave cycles were waits, profiles/r2_filterreg_500k_pmc.txt)
 constexpr int kSplatBits = 8;

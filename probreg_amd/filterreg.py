@@ -217,12 +217,12 @@ class FilterReg(abc.ABC):
         if objective_type == "pt2pl" and self._target_normals is None:
             raise ValueError("objective_type 'pt2pl' needs target_normals.")
         target = _as_points(target)
-        if feature_fn is not _identity:
-            probe = np.asarray(feature_fn(self._source[:2]))
-            if probe.shape != self._source[:2].shape or not np.array_equal(probe, self._source[:2]):
-                return self._registration_features(target, w, objective_type, maxiter, tol, min_sigma2, feature_fn)
         if self._source.shape[1] != target.shape[1] or target.shape[1] not in (2, 3):
             raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
+        if feature_fn is not _identity:
+            # any callable other than the module's own identity takes the reference's loop (features on the host every
+            # iteration); it is not probed on a sample - an extractor that needs neighbourhoods would misbehave on one
+            return self._registration_features(target, w, objective_type, maxiter, tol, min_sigma2, feature_fn)
         q = None
         if self._sigma2 is None:
             self._sigma2 = max(mu.squared_kernel_sum(self._source, target), min_sigma2)

@@ -2,14 +2,18 @@
 oracle run on the exact inputs ``bench.py`` uses, for a handful of EM iterations, and must agree within the
 north-star tolerances (transform 1e-4 relative, sigma2 1e-5 relative).
 
-  C1  RigidCPD   N = M = 100 000   3 iterations from the identity (dense sweeps) and 2 iterations continued from the
-                                   GPU's own state after 25 (late regime: 196 segments / 49 partial planes, ~97 % of
+  C1  RigidCPD   N = M = 100 000   3 iterations from the identity (dense sweeps), 1 iteration continued from the GPU's
+                                   own state in the MID regime (sigma2 < 3e-3: the matrix-core column pass with its
+                                   per-wave tile masks next to the culled vector row pass) and 2 iterations continued
+                                   from the state after 25 (late regime: 196 segments / 49 partial planes, ~97 % of
                                    the (wave, group) blocks culled) - oracle/cpd_estep_c.c, ~6 s per iteration
-  C2  AffineCPD  N = M = 200 000   1 iteration from the identity and 1 continued from iteration 22 (~29 s each)
+  C2  AffineCPD  N = M = 200 000   1 iteration from the identity, 1 in the mid regime, 1 from iteration 22 (~29 s each)
   C3  NonRigid   N = M = 12 000    3 iterations (largest M whose three M x M fp64 temporaries the numpy oracle holds
                                    comfortably), through the kernel factor (rank ~175) AND through the dense fallback
                                    (blocked Cholesky: 94 diagonal blocks / 24 outer panels)
-  C3  NonRigid   N = M = 50 000    4 iterations, kernel factor against the dense fallback (no oracle at this size)
+  C3  NonRigid   N = M = 50 000    4 iterations, kernel factor against the dense fallback; and iteration 4 of BOTH solvers
+                                   against the reference's own formulation solved by LAPACK on the host (dgesv on the
+                                   20 GB float64 system built from the float32 G; self-skips below 48 GB of free RAM)
   C4  FilterReg  N = M = 500 000   5 iterations, 5 % outliers, sigma2 updated - oracle/filterreg_numpy.py on the C lattice
 
 Reference lines: probreg/cpd.py:106-120 (driver), :71-88 (E-step), :160-192 / :219-244 / :284-303 (M-steps);
@@ -81,9 +85,29 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
     p, s2, q = _oracle_iterations(kind, src, tgt, ident, s2_0, k_dense)
     _check(kind, res, p, s2, q)
 
-    # ---- late regime: continue on the GPU from its own iteration-k_warm state, hand that state to the oracle ----
+    # ---- mid regime: the matrix-core column pass with chunk / tile masks hands over to the culled vector row pass ----
     plan = reg._plan
-    for _ in range(k_warm - k_dense):
+    done = k_dense
+    while True:
+        mid = reg._result_from_params(plan.get_params())
+        if (mid.sigma2 < 3e-3 and done >= 8) or done >= k_warm - 2:
+            break
+        plan.estep(0.0)
+        reg._device_mstep(plan)
+        done += 1
+    assert 1e-4 < mid.sigma2 < 3e-3 and done < k_warm - 2, (done, mid.sigma2)
+    plan.estep(0.0)
+    assert plan.last_estep_engine() == 1  # this iteration's column pass ran on the matrix cores (tile-mask regime)
+    col_pairs, _row_pairs = plan.pair_counts()
+    assert col_pairs < 0.9 * float(n) * n  # ... and its chunk / tile masks did skip blocks
+    reg._device_mstep(plan)
+    done += 1
+    res = reg._result_from_params(plan.get_params())
+    p, s2, q = _oracle_iterations(kind, src, tgt, _state_as_oracle_params(kind, mid), mid.sigma2, 1)
+    _check(kind, res, p, s2, q)
+
+    # ---- late regime: continue on the GPU from its own iteration-k_warm state, hand that state to the oracle ----
+    for _ in range(k_warm - done):
         plan.estep(0.0)
         reg._device_mstep(plan)
     warm = reg._result_from_params(plan.get_params())
@@ -147,6 +171,66 @@ def test_nonrigid_c3_full_size_factor_vs_dense_fallback():
     ext = np.max(np.abs(out[1][1] - out[1][1].mean(0)))
     assert np.max(np.abs(out[0][1] - out[1][1])) < TOL_TF * ext
     assert abs(out[0][0] - out[1][0]) <= TOL_SIGMA2 * out[1][0]
+
+
+def test_nonrigid_c3_full_size_vs_lapack():
+    """C3 at its own size against the reference's formulation (cpd.py:284-303) solved on the HOST: EM iteration 4, continued
+    from the GPU's state after 3, through oracle/cpd_estep_c.c (E-step) and LAPACK dgesv on the M x M float64 system built
+    from the float32 kernel matrix - 20 GB, ~1 min on the GPU box's cores.  Both GPU solvers (kernel factor, dense
+    Cholesky) run the same iteration from the same state."""
+    psutil = pytest.importorskip("psutil")
+    if psutil.virtual_memory().available < 48 * 2 ** 30:
+        pytest.skip("needs ~30 GB of free host memory for the 50 000 x 50 000 float64 system")
+    from scipy.linalg import lapack
+
+    from oracle import cpd_c
+    from probreg_amd import cpd, synthetic
+
+    m, beta, lmd = 50000, 2.0, 2.0
+    src, tgt = synthetic.nonrigid_pair(m, seed=0)
+    reg = cpd.NonRigidCPD(src, beta=beta, lmd=lmd)
+    assert not np.any(reg._origin)  # the plan holds the float32 cast of the caller's coordinates, like the reference's G
+    res3 = reg.registration(tgt, maxiter=3, tol=-1.0)
+    plan = reg._plan
+    assert plan.nonrigid_rank() > 0
+    state3, w3, s2_3 = plan.get_params(), plan.get_w(), res3.sigma2
+
+    # ---- the oracle's iteration 4 from that state ----
+    ts = src + cpd_c.nonrigid_gw(src, beta, w3)                      # transformation.py:101-102
+    pt1, p1, px, n_p = cpd_c.expectation_step(ts, tgt, s2_3, 0.0)    # cpd.py:71-88
+    a = cpd_c.nonrigid_lhs(src, beta, p1, lmd * s2_3)                # (p1 * g).T + lmd sigma2 I, cpd.py:297
+    rhs = np.asfortranarray(px - src * p1[:, None])
+    _lu, _piv, w4, info = lapack.dgesv(a, rhs, overwrite_a=1, overwrite_b=1)
+    assert info == 0
+    del a, _lu
+    t4 = src + cpd_c.nonrigid_gw(src, beta, w4)
+    tr_xp1x = float(np.sum(pt1 * np.sum(tgt * tgt, axis=1)))
+    tr_pxt = float(np.sum(px * t4))
+    tr_tpt = float(np.sum(p1 * np.sum(t4 * t4, axis=1)))
+    s2_4 = (tr_xp1x - 2.0 * tr_pxt + tr_tpt) / (n_p * 3)             # cpd.py:299-302
+    ext = np.max(np.abs(t4 - t4.mean(0)))
+
+    # ---- the same iteration on the GPU: kernel factor (the plan is at state 3), then the dense fallback ----
+    def gpu_iteration(pl):
+        pl.estep(0.0)
+        pl.mstep_nonrigid(lmd)
+        return float(pl.get_params()[13]), pl.nonrigid_apply()
+
+    got = {"factor": gpu_iteration(plan)}
+    del reg, plan
+
+    class Dense(cpd.NonRigidCPD):
+        _solver_mode = 0
+
+    regd = Dense(src, beta=beta, lmd=lmd)
+    regd._initialize(tgt)
+    assert regd._plan.nonrigid_rank() == 0
+    regd._plan.set_params(state3)
+    regd._plan.set_w(w3)
+    got["dense"] = gpu_iteration(regd._plan)
+    for solver, (s2, t_gpu) in got.items():
+        assert abs(s2 - s2_4) <= TOL_SIGMA2 * s2_4, solver
+        assert np.max(np.abs(t_gpu - t4)) < TOL_TF * ext, solver
 
 
 def test_filterreg_c4_500k_vs_oracle():

@@ -57,6 +57,20 @@ def test_api_surface_matches_reference_names():
     assert list(inspect.signature(cpd.NonRigidCPD.__init__).parameters)[1:5] == ["source", "beta", "lmd", "use_cuda"]
 
 
+def test_maximization_steps_are_static_with_the_reference_signatures():
+    """cpd.py:160-162, 219-221, 284-292, 377-388: every ``_maximization_step`` is a @staticmethod."""
+    want = {
+        cpd.RigidCPD: ["source", "target", "estep_res", "sigma2_p", "update_scale", "xp"],
+        cpd.AffineCPD: ["source", "target", "estep_res", "sigma2_p", "xp"],
+        cpd.NonRigidCPD: ["source", "target", "estep_res", "sigma2_p", "tf_obj", "lmd", "xp"],
+        cpd.ConstrainedNonRigidCPD: ["source", "target", "estep_res", "sigma2_p", "tf_obj", "lmd", "alpha", "p1_tilde",
+                                     "px_tilde", "xp"],
+    }
+    for cls, names in want.items():
+        assert isinstance(inspect.getattr_static(cls, "_maximization_step"), staticmethod), cls
+        assert list(inspect.signature(cls._maximization_step).parameters)[:len(names)] == names, cls
+
+
 def test_unknown_type_raises_value_error():
     x = np.zeros((4, 3))
     with pytest.raises(ValueError):
