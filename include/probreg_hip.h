@@ -253,6 +253,11 @@ int prg_nn_mean_distance(int device, void* hip_stream, const float* a_hd, int64_
  * (cc/permutohedral_lattice_py.cc:13-21 over third_party/permutohedral/permutohedral.cpp) behind
  * probreg.gaussian_filtering.Permutohedral (gaussian_filtering.py:8-17). */
 typedef struct prg_ph prg_ph;
+/* How the splat (permutohedral.cpp:491-500 / :548-556, `values[o] += w * in[i]` over the points in order) accumulates,
+ * process-wide, for prg_ph_filter and prg_fr_estep:  1 (default) - every vertex' float32 sum is evaluated as ONE chain in
+ * the reference's point order (stable sort of the point-vertex incidences by vertex, then sequential chains): the
+ * reference's bits, identical from run to run;  0 - float atomics in arrival order (round-off level noise). */
+int prg_lattice_set_splat_mode(int ordered);
 int prg_ph_create(prg_ph** out, int device, void* hip_stream);
 int prg_ph_destroy(prg_ph* h);
 /* init(features, with_blur): points is n x d row-major float32 (the reference passes the transpose). */

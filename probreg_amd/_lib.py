@@ -101,6 +101,7 @@ SIGNATURES = {
     "prg_rbf_kernel": [_i, _vp, _vp, _i64, _vp, _i64, _i, _d, _vp],
     "prg_inverse_multiquadric_kernel": [_i, _vp, _vp, _i64, _vp, _i64, _i, _d, _vp],
     "prg_nn_mean_distance": [_i, _vp, _vp, _i64, _vp, _i64, _i, _c.POINTER(_d)],
+    "prg_lattice_set_splat_mode": [_i],
     "prg_ph_create": [_pp, _i, _vp],
     "prg_ph_destroy": [_vp],
     "prg_ph_init": [_vp, _vp, _i64, _i, _i],

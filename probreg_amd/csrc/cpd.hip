@@ -24,6 +24,8 @@
 #include "morton.h"
 #include "small_linalg.h"
 
+#include <atomic>
+#include <cstring>
 #include <numeric>
 #include <vector>
 
@@ -843,6 +845,8 @@ int prg_cpd_destroy(prg_cpd* h) {
     prg::nonrigid_free(h);
     if (h->state) (void)hipFree(h->state);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->eng_host) (void)hipHostFree(h->eng_host);
+    if (h->eng_dev) (void)hipFree(h->eng_dev);
     delete h;
     return PRG_OK;
 }
@@ -1023,6 +1027,7 @@ int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound) {
     h->dense_engine = mode;
     if (bound > 0.0) h->dense_bound = bound;
     h->mfma_off = false;
+    h->pred_col = 1;
     return PRG_OK;
 }
 
@@ -1073,6 +1078,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     if (init_params_host) PRG_HIP(hipStreamSynchronize(h->stream));  // host buffer may be reused by the caller
     h->have_colmin = false;  // a new registration starts: its first column pass takes no seed from the previous one
     h->mfma_off = false;     // ... and it starts in the dense regime
+    h->pred_col = 1;
     return PRG_OK;
 }
 
@@ -1153,29 +1159,33 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (h->nonrigid) PRG_TRY(prg::nonrigid_displacement(h, &disp));
     k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
         h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw, disp);  // pad-only blocks are static
-    // Dense regime on the matrix cores?  The host decides per E-step from three numbers the device already has:
-    // sigma2, the source motion of this transform and the largest column minimum of the previous E-step (DESIGN.md
-    // 3.1c).  One small read-back per E-step while the registration is in the dense regime; once sigma2 has fallen to
-    // where the culled VALU sweeps skip most of the pairs (|kk| * extent^2 above the bound) the registration stays on
-    // them and never synchronises again.
+    // Dense regime on the matrix cores?  Decided per E-step from numbers only the device has at this point - sigma2, the
+    // source motion of this transform, the largest column minimum of the previous E-step - so the device
+    // decides (last thread of k_chunk_meta_bbox) and the host neither reads back nor synchronises: it launches the column
+    // pass of the engine the PREVIOUS E-step used right behind the decision kernel (guarded: the launch returns at once if
+    // the decision names the other engine), then polls the mapped mailbox while that launch runs and enqueues the rest of
+    // the E-step behind it - the queue never drains.  Once sigma2 has fallen to where the culled vector sweeps skip most
+    // of the pairs the registration stays on them and nothing is asked any more.
     bool use_mfma = false, row_mfma = false;  // column pass / row pass on the matrix cores
     bool first_mfma = false;                  // ... column pass without seeds (first E-step of a registration)
     bool fine_cull = false;                   // ... with the per-wave group tests (some groups can be skipped by now)
-    if (mfma_possible && !h->mfma_off) {
-        // chunk boxes of this E-step's transformed source (the matrix-core sweeps cull with them) and its bounding box
-        prg::launch_chunk_meta_bbox(h);
-        if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
-        float* st = reinterpret_cast<float*>(h->pinned + 40);
-        PRG_HIP(hipMemcpyAsync(st, h->motion, 14 * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
-        PRG_HIP(hipMemcpyAsync(h->pinned + 39, h->params + 13, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        PRG_HIP(hipStreamSynchronize(h->stream));
-        const double sigma2 = h->pinned[39], nk = kLog2e / (2.0 * sigma2);
-        const double mo = st[slot], cmax = st[4 + (slot ^ 1)], r = sqrt(cmax);
-        const double width = r >= mo ? 4.0 * r * mo : (r + mo) * (r + mo);  // of the bracket of a column minimum
-        const bool forced = h->dense_engine >= 2, ok = sigma2 > 0.0 && std::isfinite(sigma2);
+    bool col_launched = false;
+    const bool cull_seed = h->have_colmin && !h->srcw;  // the seed bound assumes unweighted distances
+    const bool ask = mfma_possible && !h->mfma_off;
+    if (ev && !ask) PRG_HIP(hipEventRecord(ev[1], h->stream));
+    h->wg_col_pairs = h->wg_row_pairs = 128.0 * prg::kGroup;  // a (wave, group) block of the culled vector-pipe sweeps
+    if (ask) {
+        if (!h->eng_host) {
+            PRG_HIP(hipHostMalloc((void**)&h->eng_host, sizeof(EngineDecision), hipHostMallocMapped | hipHostMallocCoherent));
+            memset(h->eng_host, 0, sizeof(EngineDecision));
+            PRG_HIP(hipHostGetDevicePointer((void**)&h->eng_host_dev, h->eng_host, 0));
+            PRG_HIP(hipMalloc((void**)&h->eng_dev, sizeof(EngineDecision)));
+            PRG_HIP(hipMemsetAsync(h->eng_dev, 0, sizeof(EngineDecision), h->stream));
+        }
+        EngineArgs ea;
         // size of the problem: the (replicated) source's bounding box or the local target's, whichever is larger - a
         // target shard is a small patch, and every rank should leave the dense regime at the same sigma2
-        const double ext2 = std::max(h->sext2, h->text2);
+        ea.ext2 = std::max(h->sext2, h->text2);
         // where the culled vector sweeps overtake the matrix-core ones depends on how small the 128 x 32-point blocks of
         // the cull tests are next to sigma, i.e. on the point density: measured crossovers at 30k / 100k / 200k points
         // (tools/mfma_vs_valu.py) move like n^1.8 (column pass) and n^2 above 100k (row pass); dense_bound is the
@@ -1183,39 +1193,63 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // (n = sqrt(M N_local): a rank that holds a shard of the target has fewer, equally dense columns - its matrix-core
         // sweeps run out of workgroups earlier; tools/shard_steady.py)
         const double dens = sqrt((double)h->M * (double)h->N) / 1.0e5;
-        const double col_bound = h->dense_bound * pow(dens, 1.8);
-        const double row_bound = 0.05 * h->dense_bound * std::max(1.0, dens * dens);
-        const bool dense = ok && (forced || nk * ext2 < col_bound);
-        if (!dense) h->mfma_off = true;
-        // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or -
-        // first E-step, no minima yet - none at all when the farthest target / source pair is still above the flush
-        // threshold (farthest corners of the two bounding boxes: every term of every column is >= 2^-110).
-        // The culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
-        // (profiles/r2_mfma_cull_vs_valu_100k.log): it leaves at 1/20 of the bound.
-        double far2 = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            const double a = fabs((double)h->tbox[3 + k] - (double)st[8 + k]), b = fabs((double)st[11 + k] - (double)h->tbox[k]);
-            far2 += std::max(a, b) * std::max(a, b);
+        ea.col_bound = h->dense_bound * pow(dens, 1.8);
+        ea.row_bound = 0.05 * h->dense_bound * std::max(1.0, dens * dens);
+        for (int k = 0; k < 6; ++k) ea.tbox[k] = h->tbox[k];
+        ea.slot = slot;
+        ea.have_colmin = h->have_colmin ? 1 : 0;
+        ea.forced = h->dense_engine >= 2 ? 1 : 0;
+        ea.seq = (unsigned)h->estep_count;  // (already incremented: never 0, the mailbox's initial value)
+        ea.dev = h->eng_dev;
+        ea.host = h->eng_host_dev;
+        // chunk boxes of this E-step's transformed source (the matrix-core sweeps cull with them), its bounding box, and
+        // the decision
+        prg::launch_chunk_meta_bbox(h, &ea);
+        if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
+        const bool pred = h->pred_col != 0;
+        if (pred)
+            prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev);
+        else
+            prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev);
+        PRG_HIP(hipGetLastError());
+        // the answer: a few microseconds after the transform has finished, long before the column pass has
+        volatile EngineDecision* mb = h->eng_host;
+        for (uint64_t spins = 0; mb->seq != ea.seq; ++spins) {
+            if ((spins & 0xFFFull) == 0xFFFull && hipStreamQuery(h->stream) != hipErrorNotReady) {
+                // the stream has drained (or failed): the decision kernel is done, its store must be here by now
+                if (mb->seq == ea.seq) break;
+                PRG_HIP(hipStreamSynchronize(h->stream));
+                PRG_REQUIRE(mb->seq == ea.seq, PRG_ERR_HIP, "prg_cpd_estep: the engine decision never reached the host");
+            }
+            __builtin_ia32_pause();
         }
-        first_mfma = dense && !h->have_colmin && std::isfinite(far2) && nk * far2 < 110.0;
-        use_mfma = first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0);
-        row_mfma = dense && (forced || nk * ext2 < row_bound);
+        std::atomic_thread_fence(std::memory_order_acquire);
+        use_mfma = mb->col != 0;
+        first_mfma = mb->first != 0;
+        row_mfma = mb->row != 0;
+        fine_cull = mb->fine != 0;
+        if (!mb->dense) h->mfma_off = true;
         static const bool debug_engine = getenv("PRG_DEBUG_ENGINE") != nullptr;
         if (debug_engine)
             fprintf(stderr, "[engine] sigma2 %.4e nk*ext2 %.1f (col bound %.0f, row bound %.0f) motion %.3e cmax %.3e nk*width %.1f "
-                            "nk*far2 %.1f have_colmin %d -> col %d (first %d) row %d fine %d\n",
-                    sigma2, nk * ext2, col_bound, row_bound, mo, cmax, nk * width, nk * far2, (int)h->have_colmin,
-                    (int)(first_mfma || (dense && h->have_colmin && std::isfinite(cmax) && nk * width < 150.0)), (int)first_mfma,
-                    (int)row_mfma, (int)(nk * ext2 > 200.0));
-        fine_cull = nk * ext2 > 200.0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2) and the test is overhead
+                            "nk*far2 %.1f have_colmin %d -> col %d (first %d, launched ahead: %s) row %d fine %d\n",
+                    (double)mb->sigma2, (double)mb->nk_ext2, ea.col_bound, ea.row_bound, (double)mb->motion, (double)mb->cmax,
+                    (double)mb->nk_width, (double)mb->nk_far2, (int)h->have_colmin, (int)use_mfma, (int)first_mfma,
+                    pred == use_mfma ? "yes" : "NO", (int)row_mfma, (int)fine_cull);
+        col_launched = pred == use_mfma;
+        h->pred_col = use_mfma ? 1 : 0;
+        if (!col_launched) {  // (the guarded launch has returned at once; rare: the engine changes once or twice per registration)
+            if (use_mfma)
+                prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev);
+            else
+                prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);
+            col_launched = true;
+        }
     }
     h->last_estep_mfma = use_mfma;
-    h->wg_col_pairs = h->wg_row_pairs = 128.0 * prg::kGroup;  // a (wave, group) block of the culled vector-pipe sweeps
-    if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
-    if (use_mfma)
-        prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull);
-    else if (use_cull)
-        prg::launch_colpass_cull(h, SA, segA, h->have_colmin && !h->srcw);  // the seed bound assumes unweighted distances
+    if (col_launched) {
+    } else if (use_cull)
+        prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);
     else if (ra < 0)
         prg::launch_colpass_scalar(h, RA, SA, segA);
     else
@@ -1241,6 +1275,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                   use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)(row_mfma ? PBm : PB) * 5 * h->Mcap)
                                                            : nullptr,
                                                   row_mfma ? h->rorig : nullptr);
+    // (folding this single-block reduction into the last-finishing workgroup of k_row_moments was measured in round 3:
+    // +25 us - that workgroup's 256 threads read the ~400 partial rows through L2 in a few dependent rounds, the 1024
+    // threads of this launch do it in 5 us including the launch)
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());

@@ -4,6 +4,30 @@
 
 #include "prg_common.h"
 
+// Which engine an E-step's sweeps run on while a registration is in the dense regime.  The decision needs
+// sigma2, the source motion of this E-step's transform and the previous E-step's largest column minimum - all of them on
+// the device - so the device takes it (last thread of k_chunk_meta_bbox) and publishes it twice: in device memory, where
+// the column-pass launch the host issued AHEAD of the answer checks that it is the wanted one, and in a mapped host
+// mailbox the host polls while that launch runs - no stream synchronisation, the queue never drains.
+struct EngineDecision {
+    unsigned seq;  // E-step counter the decision belongs to (host mailbox: written last)
+    int col;       // 1: matrix-core column pass, 0: culled vector-pipe column pass
+    int first;     // ... without seeds (first E-step of a registration)
+    int row;       // 1: matrix-core row pass
+    int fine;      // per-wave tile masks on (some groups of a chunk can be skipped by now)
+    int dense;     // 0: the registration has left the dense regime for good (the host stops asking)
+    float sigma2, motion, cmax, nk_ext2, nk_width, nk_far2;  // what it was decided from (PRG_DEBUG_ENGINE)
+    unsigned pad[4];
+};
+struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
+    double ext2, col_bound, row_bound;
+    float tbox[6];
+    int slot, have_colmin, forced;
+    unsigned seq;
+    EngineDecision* dev;
+    EngineDecision* host;
+};
+
 // Row accumulator block: 4 fp64 planes of Mcap (p1, px0, px1, px2), written by the moment kernel.
 struct prg_cpd {
     int device = 0;
@@ -58,7 +82,11 @@ struct prg_cpd {
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
                                 // 2: both sweeps on the matrix cores, always (tests)
     double dense_bound = 16000.0;  // matrix-core column pass while |kk| * (cloud bounding-box diagonal)^2 is below this (C1: sigma2 > ~4e-4)
-    bool mfma_off = false;      // this registration has left the dense regime: no more host decisions
+    bool mfma_off = false;      // this registration has left the dense regime: no more engine decisions
+    EngineDecision* eng_dev = nullptr;   // device copy of the current E-step's decision (guard of the column-pass launches)
+    EngineDecision* eng_host = nullptr;  // mapped, coherent host memory: the mailbox the host polls
+    EngineDecision* eng_host_dev = nullptr;  // ... as the device addresses it
+    int pred_col = 1;           // the column-pass engine the host launches ahead of the decision (= the previous decision)
     bool last_estep_mfma = false;
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)

@@ -39,15 +39,18 @@ __device__ __forceinline__ float col_seed_offset(float kk, float cm, float mo) {
 }
 // first: no seeds from a previous E-step (offsets 0, no culling); fine: every wave also tests its own 128 points against
 // the groups of 32 streamed points of each chunk (pays once sigma2 is small enough for some of them to be skipped)
-void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine);
-void launch_chunk_meta_bbox(prg_cpd* h);  // zchunk + bounding box of z4 -> motion[8..13]  // S segments of the streamed cloud (0 = fill the chip once)
+// guard (may be null): device copy of the E-step's engine decision - the launch was issued ahead of it and returns at
+// once unless `col` names its engine; the matrix-core kernel also takes `fine` from there
+void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard);  // S segments of the streamed cloud (0 = fill the chip once)
+// zchunk + bounding box of z4 -> motion[8..13]; eng != null: the last thread also takes the engine decision (EngineArgs)
+void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng);
 void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine);  // rowflag: 64 bytes per 128-row block (touched planes)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
 constexpr int kSuper = 256;    // quantum of a culled segment's length (8 groups)
 // culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup
-void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed);
+void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const EngineDecision* guard = nullptr);
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len);
 void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len);
 void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len);

@@ -189,9 +189,14 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          int64_t m_total, int64_t n_total,
                                                          const double* __restrict__ params,
                                                          float2* __restrict__ colpart, int64_t ncap,
-                                                         unsigned* __restrict__ wgcount, int first, int fine) {
+                                                         unsigned* __restrict__ wgcount, int first, int fine,
+                                                         const EngineDecision* __restrict__ guard) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
+    if (guard) {  // launched ahead of the engine decision (cpd.hip, estep_impl): run only if it came out this way
+        if (guard->col != 1) return;
+        fine = guard->fine;
+    }
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t n0wg = (int64_t)blockIdx.x * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
@@ -507,10 +512,14 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta(const BoxMeta* __restrict
 }
 
 // the same for the transformed source, plus the bounding box of its m real points -> stat[8..13] (lo.xyz, hi.xyz as float
-// bits): one workgroup, the host reads the box back with the other per-E-step statistics (cpd.hip, estep_impl)
+// bits): one workgroup.  With `eng.dev` set, thread 0 then takes the E-step's engine decision from what
+// the device holds at this point - sigma2, the motion of this E-step's transform (stat[slot]), the previous E-step's largest
+// column minimum (stat[4 + (slot ^ 1)]), the box just computed - and publishes it in device memory (guard of the column
+// pass launched ahead) and in the host's mailbox.
 __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __restrict__ gmeta, int64_t nchunk,
                                                             BoxMeta* __restrict__ cmeta, const float4* __restrict__ pts,
-                                                            int64_t m, unsigned* __restrict__ stat) {
+                                                            int64_t m, unsigned* __restrict__ stat,
+                                                            const double* __restrict__ params, const EngineArgs eng) {
     __shared__ float sh[kBlock / 64][6];
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t c = threadIdx.x; c < nchunk; c += kBlock) {
@@ -556,11 +565,55 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
             sh[threadIdx.x >> 6][3 + k] = hi[k];
         }
     __syncthreads();
-    if (threadIdx.x < 6) {
-        float v = sh[0][threadIdx.x];
-        for (int w = 1; w < kBlock / 64; ++w) v = threadIdx.x < 3 ? fminf(v, sh[w][threadIdx.x]) : fmaxf(v, sh[w][threadIdx.x]);
-        stat[8 + threadIdx.x] = __float_as_uint(v);
+    if (threadIdx.x != 0) return;
+    float box[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float v = sh[0][q];
+        for (int w = 1; w < kBlock / 64; ++w) v = q < 3 ? fminf(v, sh[w][q]) : fmaxf(v, sh[w][q]);
+        box[q] = v;
+        stat[8 + q] = __float_as_uint(v);
     }
+    if (!eng.dev) return;
+    // ---- the engine decision (the host's former read-back-and-decide, verbatim) ----
+    const double sigma2 = params[13], nk = kLog2e / (2.0 * sigma2);
+    const double mo = __uint_as_float(stat[eng.slot]), cmax = __uint_as_float(stat[4 + (eng.slot ^ 1)]), r = sqrt(cmax);
+    const double width = r >= mo ? 4.0 * r * mo : (r + mo) * (r + mo);  // of the bracket of a column minimum
+    const bool ok = sigma2 > 0.0 && isfinite(sigma2);
+    // where the culled vector sweeps overtake the matrix-core ones depends on how small the 128 x 32-point blocks of the
+    // cull tests are next to sigma, i.e. on the point density (the bounds come from the host: cpd.hip)
+    const bool dense = ok && (eng.forced || nk * eng.ext2 < eng.col_bound);
+    // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
+    // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold
+    // (farthest corners of the two bounding boxes: every term of every column is >= 2^-110)
+    double far2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = fabs((double)eng.tbox[3 + k] - (double)box[k]), b = fabs((double)box[3 + k] - (double)eng.tbox[k]);
+        far2 += fmax(a, b) * fmax(a, b);
+    }
+    const bool first = dense && !eng.have_colmin && isfinite(far2) && nk * far2 < 110.0;
+    const bool col = first || (dense && eng.have_colmin && isfinite(cmax) && nk * width < 150.0);
+    // the culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
+    const bool row = dense && (eng.forced || nk * eng.ext2 < eng.row_bound);
+    EngineDecision d;
+    d.seq = eng.seq;
+    d.col = col ? 1 : 0;
+    d.first = first ? 1 : 0;
+    d.row = row ? 1 : 0;
+    d.fine = nk * eng.ext2 > 200.0 ? 1 : 0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2): the test is overhead
+    d.dense = dense ? 1 : 0;
+    d.sigma2 = (float)sigma2; d.motion = (float)mo; d.cmax = (float)cmax;
+    d.nk_ext2 = (float)(nk * eng.ext2); d.nk_width = (float)(nk * width); d.nk_far2 = (float)(nk * far2);
+    d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0u;
+    *eng.dev = d;
+    // mailbox: payload first, sequence number last, both at system scope
+    EngineDecision* hm = eng.host;
+    hm->col = d.col; hm->first = d.first; hm->row = d.row; hm->fine = d.fine; hm->dense = d.dense;
+    hm->sigma2 = d.sigma2; hm->motion = d.motion; hm->cmax = d.cmax;
+    hm->nk_ext2 = d.nk_ext2; hm->nk_width = d.nk_width; hm->nk_far2 = d.nk_far2;
+    __threadfence_system();
+    __hip_atomic_store(&hm->seq, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace
@@ -602,12 +655,16 @@ void launch_chunk_meta(prg_cpd* h, const float* gmeta, int64_t cap, float* cmeta
                                                                              reinterpret_cast<BoxMeta*>(cmeta));
 }
 
-void launch_chunk_meta_bbox(prg_cpd* h) {
+void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng) {
+    EngineArgs none;
+    none.dev = nullptr;
+    none.host = nullptr;
     k_chunk_meta_bbox<<<1, kBlock, 0, h->stream>>>(reinterpret_cast<const BoxMeta*>(h->zmeta), h->Mcap / kChunk,
-                                                  reinterpret_cast<BoxMeta*>(h->zchunk), h->z4, h->M, h->motion);
+                                                  reinterpret_cast<BoxMeta*>(h->zchunk), h->z4, h->M, h->motion, h->params,
+                                                  eng ? *eng : none);
 }
 
-void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine) {
+void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard) {
     const int cps = mfma_chunks_per_seg(h->N, h->M, S);
     dim3 grid((unsigned)ceil_div(h->N, kWgPoints), (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
     // (zchunk: boxes of this E-step's transformed source, written by launch_chunk_meta_bbox before the engine decision)
@@ -615,7 +672,7 @@ void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine) {
                                                    reinterpret_cast<const BoxMeta*>(h->zmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
                                                    h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
-                                                   h->colpart, h->Ncap, h->wgcount, first ? 1 : 0, fine ? 1 : 0);
+                                                   h->colpart, h->Ncap, h->wgcount, first ? 1 : 0, fine ? 1 : 0, guard);
     h->wg_col = (int64_t)grid.x * grid.y;
     h->wg_col_pairs = 128.0 * 16.0;  // counted unit: one wave's 128 points x one 16-point tile
     h->dense_pairs_col = 0.0;

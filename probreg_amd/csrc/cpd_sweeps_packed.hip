@@ -273,8 +273,12 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
                                                          const float* __restrict__ colmin_g,
                                                          const unsigned* __restrict__ motion,
                                                          float2* __restrict__ colpart, int64_t ncap,
-                                                         unsigned* __restrict__ wgcount) {
+                                                         unsigned* __restrict__ wgcount,
+                                                         const EngineDecision* __restrict__ guard) {
     PRG_TRACE_BEGIN();
+    // launched ahead of the E-step's engine decision (cpd.hip, estep_impl; dense regime only - null afterwards): run
+    // only if the decision names this engine
+    if (guard && guard->col != 0) return;
     __shared__ float4 part[4][64];
     __shared__ int arrived, wave_groups[4];
     int ngrp = 0;  // (wave, group) blocks this wave evaluates: 128 x 32 pairs each (measurement hook, wave-uniform)
@@ -527,13 +531,13 @@ extern "C" int prg_debug_set_wave_trace(unsigned long long* dev_buffer, unsigned
 #endif
 
 // S segments of seg_len streamed points, four per workgroup: S/4 (rounded up) partial planes
-void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed) {
+void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const EngineDecision* guard) {
     dim3 grid((unsigned)ceil_div(h->N, 128), (unsigned)ceil_div(S, 4));
     k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
                                                    reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len, S, h->params,
                                                    use_seed ? h->colmin + h->Ncap : nullptr,
                                                    h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap,
-                                                   h->wgcount);
+                                                   h->wgcount, guard);
     h->wg_col = (int64_t)grid.x * grid.y;
     h->dense_pairs_col = 0.0;
 }

@@ -23,6 +23,11 @@
 #include "prg_common.h"
 #include "small_linalg.h"
 
+namespace prg {
+int sort_pairs_u32(void* tmp, size_t* tmp_bytes, const unsigned* keys_in, unsigned* keys_out, const int* vals_in,
+                   int* vals_out, unsigned n, unsigned bits, hipStream_t stream);  // lattice_sort.hip
+}
+
 namespace {
 
 constexpr int kBlock = 256;
@@ -103,6 +108,18 @@ struct Lattice {
     // feature lattices (d > 3): keys are d shorts, the table holds a 64-bit hash of them (checked by a second hash)
     short* rem0s = nullptr;             // [n][d+1] rounded remainders of every point (keys are rebuilt from these)
     unsigned char* rank8 = nullptr;     // [n][d+1]
+    // order-preserving splat (lat_segments): the (point, remainder) incidences of the splatted points sorted by vertex,
+    // within a vertex in the REFERENCE's point order (permutohedral.cpp:491-500 walks the points in order)
+    unsigned* skeys = nullptr;          // [2][cap_inc] vertex id of every incidence, before / after the sort
+    int* svals = nullptr;               // [2][cap_inc] incidence index (point * (d+1) + remainder), before / after
+    int* seg = nullptr;                 // [2][size] first / one-past-last sorted position of every vertex
+    int64_t seg_inc_cap = 0, seg_size_cap = 0;
+    void* sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    bool seg_valid = false;             // the arrays describe the current lattice for points >= seg_first
+    int64_t seg_first = -1;
+    const int* ref_pos = nullptr;       // device, may be null (identity): j-th splatted point of the reference's order ->
+                                        // its position among the splatted points as the kernels store them
     short* kfull = nullptr;             // [size][d] full key of every lattice vertex
     unsigned long long* gcheck = nullptr;  // [size] second hash of the vertex key | 1 (0 = not yet written)
     float* scale_dev = nullptr;         // [kMaxDG] scale factors of the embedding
@@ -617,6 +634,113 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
     }
 }
 
+// ---- order-preserving splat ------------------------------------------------------------------------------------------
+// The reference splats sequentially (permutohedral.cpp:491-500 / :548-556): points in order, per point its d + 1
+// vertices, `values[o] += w * in[i]` in float32 - a vertex' value is ONE chain of float additions in point order, and a
+// different order gives different float32 bits.  The atomic splats above accumulate in arrival order: run-to-run
+// noise of ~1e-7 relative that the lattice amplifies from EM iteration to EM iteration (cell assignment is discontinuous
+// in sigma).  Here every vertex' chain is evaluated in the reference's order: the incidences of the splatted points are
+// sorted by vertex id with a STABLE sort from an input written in the reference's point order (lat_segments), then one
+// thread (short chains), 8 lanes or a whole wave (long chains: while the lattice has a few hundred vertices each one
+// collects ~10^4 points) loads the chain's terms in parallel and adds them up one by one - bit for bit the reference's
+// float32 values, the same in every run.
+__global__ __launch_bounds__(kBlock) void k_seg_keys(const int* __restrict__ offset, const int* __restrict__ ref_pos,
+                                                     int64_t first, int64_t n_inc, int d1, unsigned* __restrict__ keys,
+                                                     int* __restrict__ vals, int* __restrict__ seg, int64_t seg_elems) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (int64_t z = t; z < seg_elems; z += (int64_t)gridDim.x * kBlock) seg[z] = 0;  // vertices nobody splats into: empty
+    if (t >= n_inc) return;
+    const int64_t j = t / d1;
+    const int r = (int)(t % d1);
+    const int64_t p = first + (ref_pos ? (int64_t)ref_pos[j] : j);
+    const int64_t inc = p * d1 + r;
+    keys[t] = (unsigned)offset[inc];
+    vals[t] = (int)inc;
+}
+
+__global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned* __restrict__ keys, int64_t n_inc, int size,
+                                                       int* __restrict__ seg) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n_inc) return;
+    const unsigned k = keys[t];
+    if (t == 0 || keys[t - 1] != k) seg[k] = (int)t;
+    if (t + 1 == n_inc || keys[t + 1] != k) seg[size + k] = (int)(t + 1);
+}
+
+// G lanes per vertex (1, 8 or 64).  vals_a / vals_b: the two value planes [(size + 1)][ch]; row 0 (the "no neighbour" row
+// of the blur) is zeroed in both, every other row of plane a is WRITTEN - nothing is cleared beforehand.
+template <int G>
+__global__ __launch_bounds__(kBlock) void k_segsum(const int* __restrict__ seg, const int* __restrict__ sinc,
+                                                   const float* __restrict__ bary, const float* __restrict__ in, int d1,
+                                                   int ch, int size, float* __restrict__ vals_a,
+                                                   float* __restrict__ vals_b) {
+    constexpr int kGroups = kBlock / G;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int64_t v = (int64_t)blockIdx.x * kGroups + grp;
+    if (blockIdx.x == 0 && threadIdx.x < ch) {
+        vals_a[threadIdx.x] = 0.f;
+        vals_b[threadIdx.x] = 0.f;
+    }
+    const bool live = v < size;
+    const int start = live ? seg[v] : 0, end = live ? seg[size + v] : 0;
+    if (G == 1) {
+        if (!live) return;
+        float acc[kSplatMaxCh];
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k) acc[k] = 0.f;
+        for (int t = start; t < end; ++t) {
+            const int inc = sinc[t];
+            const float w = bary[inc];
+            const float* __restrict__ row = in + (int64_t)(inc / d1) * ch;
+#pragma unroll
+            for (int k = 0; k < kSplatMaxCh; ++k)
+                if (k < ch) acc[k] = __fadd_rn(acc[k], __fmul_rn(w, row[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k)
+            if (k < ch) vals_a[(v + 1) * ch + k] = acc[k];
+        return;
+    }
+    // G > 1: lane gl fetches the term of position base + gl (all channels), the products go through LDS, lane k < ch adds
+    // channel k's products up in order.  The next round's loads are issued before this round's chain starts.
+    __shared__ float prod[kGroups][G][kSplatMaxCh];
+    float acc = 0.f;
+    float pr[kSplatMaxCh];
+    auto fetch = [&](int base) {
+        const int t = base + gl;
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k) pr[k] = 0.f;
+        if (t < end) {
+            const int inc = sinc[t];
+            const float w = bary[inc];
+            const float* __restrict__ row = in + (int64_t)(inc / d1) * ch;
+#pragma unroll
+            for (int k = 0; k < kSplatMaxCh; ++k)
+                if (k < ch) pr[k] = __fmul_rn(w, row[k]);
+        }
+    };
+    int base = start;
+    fetch(base);
+    while (__any(base < end)) {  // wave-uniform trip count: the groups of a wave wait for the longest chain among them
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k) prod[grp][gl][k] = pr[k];
+        const int cnt = base < end ? (end - base < G ? end - base : G) : 0;
+        fetch(base + G);
+        __threadfence_block();  // (LDS is in order within a wave; the fence keeps the compiler from reordering across it)
+        if (gl < ch) {
+            if (cnt == G) {
+#pragma unroll 8
+                for (int j = 0; j < G; ++j) acc = __fadd_rn(acc, prod[grp][j][gl]);
+            } else {
+                for (int j = 0; j < cnt; ++j) acc = __fadd_rn(acc, prod[grp][j][gl]);
+            }
+        }
+        __threadfence_block();
+        base += G;
+    }
+    if (live && gl < ch) vals_a[(v + 1) * ch + gl] = acc;
+}
+
 // seq_mask bit k set: channel k follows seqCompute (0.5*(n1+n2) evaluated in double, :510), else sseCompute.
 __global__ __launch_bounds__(kBlock) void k_blur(const float* __restrict__ old, float* __restrict__ nw,
                                                  const int* __restrict__ nb1, const int* __restrict__ nb2, int size,
@@ -657,7 +781,12 @@ __global__ __launch_bounds__(kBlock) void k_slice(const int* __restrict__ offset
 
 int lat_free(Lattice* L) {
     void* ptrs[] = {L->feat, L->tkeys, L->slot_id, L->pslot, L->bary, L->dkeys, L->nb, L->count, L->vals, L->io,
-                    L->rem0s, L->rank8, L->kfull, L->gcheck, L->scale_dev, L->tkeys2, L->count2};
+                    L->rem0s, L->rank8, L->kfull, L->gcheck, L->scale_dev, L->tkeys2, L->count2,
+                    L->skeys, L->svals, L->seg, L->sort_tmp};
+    L->skeys = nullptr; L->svals = nullptr; L->seg = nullptr; L->sort_tmp = nullptr;
+    L->seg_inc_cap = L->seg_size_cap = 0;
+    L->sort_tmp_bytes = 0;
+    L->seg_valid = false;
     L->tkeys2 = nullptr; L->count2 = nullptr; L->cap2 = 0;
     L->rem0s = nullptr; L->rank8 = nullptr; L->kfull = nullptr; L->gcheck = nullptr; L->scale_dev = nullptr;
     L->g_alloc_n = L->g_alloc_size = 0;
@@ -769,6 +898,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         if (capu > L->cap) capu = L->cap;
     }
     L->built = false;
+    L->seg_valid = false;
     for (int attempt = 0; attempt < 2; ++attempt) {
         L->cap_used = capu;
         PRG_TRY(next_generation(L->tkeys, L->cap, &L->gen, st));
@@ -929,6 +1059,7 @@ int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
     PRG_HIP(hipStreamSynchronize(st));  // (sc lives on this stack frame)
     volatile int* host = reinterpret_cast<volatile int*>(L->pinned);
     L->built = false;
+    L->seg_valid = false;
     for (int attempt = 0; attempt < 4; ++attempt) {
         const unsigned long long seed = 0x9e3779b97f4a7c15ull * (2 * attempt + 1), seed2 = 0xc2b2ae3d27d4eb4full * (2 * attempt + 3);
         const int64_t capu = L->cap;
@@ -983,6 +1114,61 @@ int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
     return PRG_ERR_STATE;
 }
 
+// 1: order-preserving splat (the reference's float32 bits, reproducible), 0: atomic splats.  Process-wide; tools / tests
+// switch it through prg_lattice_set_splat_mode.
+static int g_splat_ordered = []() {
+    const char* e = getenv("PRG_SPLAT_ORDERED");
+    return e ? atoi(e) : 1;
+}();
+
+// Sorted incidence lists of the current lattice for the points >= first (once per lattice build; every filter call on the
+// lattice reuses them).  No synchronisation.
+int lat_segments(Lattice* L, int64_t first) {
+    if (L->seg_valid && L->seg_first == first) return PRG_OK;
+    const int d1 = L->d + 1;
+    hipStream_t st = L->stream;
+    const int64_t n_inc = (L->n - first) * d1;
+    PRG_REQUIRE(n_inc > 0 && n_inc < (int64_t)1 << 31 && L->n * d1 < (int64_t)1 << 31, PRG_ERR_INVALID,
+                "permutohedral lattice: too many point-vertex incidences for the ordered splat");
+    if (n_inc > L->seg_inc_cap) {
+        if (L->skeys) (void)hipFree(L->skeys);
+        if (L->svals) (void)hipFree(L->svals);
+        L->skeys = nullptr; L->svals = nullptr;
+        PRG_HIP(hipMalloc((void**)&L->skeys, 2 * n_inc * sizeof(unsigned)));
+        PRG_HIP(hipMalloc((void**)&L->svals, 2 * n_inc * sizeof(int)));
+        L->seg_inc_cap = n_inc;
+    }
+    if ((int64_t)L->size > L->seg_size_cap) {
+        if (L->seg) (void)hipFree(L->seg);
+        L->seg = nullptr;
+        const int64_t want = (int64_t)L->size + L->size / 4 + 1024;
+        PRG_HIP(hipMalloc((void**)&L->seg, 2 * want * sizeof(int)));
+        L->seg_size_cap = want;
+    }
+    unsigned bits = 1;
+    while (((int64_t)1 << bits) < (int64_t)L->size) ++bits;
+    size_t need = 0;
+    PRG_TRY(prg::sort_pairs_u32(nullptr, &need, L->skeys, L->skeys + L->seg_inc_cap, L->svals, L->svals + L->seg_inc_cap,
+                                (unsigned)n_inc, bits, st));
+    if (need > L->sort_tmp_bytes) {
+        if (L->sort_tmp) (void)hipFree(L->sort_tmp);
+        L->sort_tmp = nullptr;
+        L->sort_tmp_bytes = 0;
+        PRG_HIP(hipMalloc(&L->sort_tmp, need + (need >> 2) + 256));
+        L->sort_tmp_bytes = need + (need >> 2) + 256;
+    }
+    const unsigned g = (unsigned)prg::ceil_div(n_inc, kBlock);
+    k_seg_keys<<<g, kBlock, 0, st>>>(L->pslot, L->ref_pos, first, n_inc, d1, L->skeys, L->svals, L->seg, 2 * (int64_t)L->size);
+    size_t bytes = L->sort_tmp_bytes;
+    PRG_TRY(prg::sort_pairs_u32(L->sort_tmp, &bytes, L->skeys, L->skeys + L->seg_inc_cap, L->svals,
+                                L->svals + L->seg_inc_cap, (unsigned)n_inc, bits, st));
+    k_seg_bounds<<<g, kBlock, 0, st>>>(L->skeys + L->seg_inc_cap, n_inc, L->size, L->seg);
+    PRG_HIP(hipGetLastError());
+    L->seg_valid = true;
+    L->seg_first = first;
+    return PRG_OK;
+}
+
 // Filter `ch` channels: in [n][ch] (device) -> out [n_out][ch] (device); only points >= first are splatted
 // (callers pass first > 0 only when the skipped rows are known to be zero).
 int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out, unsigned seq_mask, float* out) {
@@ -997,13 +1183,25 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
     }
     float* a = L->vals;
     float* b = L->vals + plane;
-    PRG_HIP(hipMemsetAsync(a, 0, 2 * plane * sizeof(float), st));
-    if (ch <= kSplatMaxCh)
-        k_splat_lds<<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(L->pslot, L->bary, in, first,
-                                                                                        L->n, d1, ch, a);
-    else
-        k_splat<<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, in,
-                                                                                        first, L->n, d1, ch, a);
+    if (g_splat_ordered && ch <= kSplatMaxCh) {
+        PRG_TRY(lat_segments(L, first));
+        const int* sinc = L->svals + L->seg_inc_cap;
+        const double avg = (double)((L->n - first) * d1) / (double)(L->size > 0 ? L->size : 1);
+        if (avg <= 12.0)
+            k_segsum<1><<<(unsigned)prg::ceil_div(L->size, kBlock), kBlock, 0, st>>>(L->seg, sinc, L->bary, in, d1, ch, L->size, a, b);
+        else if (avg <= 768.0)
+            k_segsum<8><<<(unsigned)prg::ceil_div(L->size, kBlock / 8), kBlock, 0, st>>>(L->seg, sinc, L->bary, in, d1, ch, L->size, a, b);
+        else
+            k_segsum<64><<<(unsigned)prg::ceil_div(L->size, kBlock / 64), kBlock, 0, st>>>(L->seg, sinc, L->bary, in, d1, ch, L->size, a, b);
+    } else {
+        PRG_HIP(hipMemsetAsync(a, 0, 2 * plane * sizeof(float), st));
+        if (ch <= kSplatMaxCh)
+            k_splat_lds<<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(L->pslot, L->bary, in, first,
+                                                                                            L->n, d1, ch, a);
+        else
+            k_splat<<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, in,
+                                                                                            first, L->n, d1, ch, a);
+    }
     if (L->with_blur) {
         const int* nb1 = L->nb;
         const int* nb2 = L->nb + (int64_t)d1 * L->size;
@@ -1044,6 +1242,7 @@ struct prg_filterreg {
     double* part = nullptr;  // block partials
     int64_t part_blocks = 0;
     std::vector<int> tgt_order;  // Morton order of the target (kernel position -> caller's index); see prg_fr_set_target
+    int* ref_pos = nullptr;      // [N] device: caller's index -> kernel position (the ordered splat walks the caller's order)
     bool have_src = false, have_tgt = false, have_estep = false;
     FrFeat prod;             // feature producer handed to the embedding kernels
     int last_blur = 1;       // with_blur of the previous E-step: which lattice the next one tries first
@@ -1505,6 +1704,12 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_finish(const double* __restri
 
 extern "C" {
 
+int prg_lattice_set_splat_mode(int ordered) {
+    PRG_REQUIRE(ordered == 0 || ordered == 1, PRG_ERR_INVALID, "prg_lattice_set_splat_mode: mode must be 0 (atomic) or 1 (ordered)");
+    g_splat_ordered = ordered;
+    return PRG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // stand-alone lattice (gaussian_filtering.Permutohedral)
 // ---------------------------------------------------------------------------------------------
@@ -1599,7 +1804,7 @@ int prg_fr_destroy(prg_filterreg* h) {
     (void)hipStreamSynchronize(h->L.stream);
     lat_free(&h->L);
     for (void* p : {(void*)h->src, (void*)h->tgt, (void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->state,
-                    (void*)h->part, (void*)h->nrm})
+                    (void*)h->part, (void*)h->nrm, (void*)h->ref_pos})
         if (p) (void)hipFree(p);
     delete h;
     return PRG_OK;
@@ -1658,6 +1863,13 @@ int prg_fr_set_target(prg_filterreg* h, const double* target_hd, int64_t n, int 
     for (int64_t i = 0; i < n; ++i)
         for (int k = 0; k < dim; ++k) sorted[(size_t)i * dim + k] = host[(size_t)h->tgt_order[i] * dim + k];
     PRG_HIP(hipMemcpyAsync(h->tgt, sorted.data(), (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
+    // ... and the splat still adds every vertex' terms up in the CALLER's point order (the reference's): caller index -> kernel position
+    std::vector<int> inv((size_t)n);
+    for (int64_t i = 0; i < n; ++i) inv[(size_t)h->tgt_order[i]] = (int)i;
+    if (h->ref_pos) (void)hipFree(h->ref_pos);
+    h->ref_pos = nullptr;
+    PRG_HIP(hipMalloc((void**)&h->ref_pos, (size_t)n * sizeof(int)));
+    PRG_HIP(hipMemcpyAsync(h->ref_pos, inv.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, h->L.stream));
     PRG_HIP(hipStreamSynchronize(h->L.stream));
     h->N = n;
     h->D = dim;
@@ -1690,6 +1902,7 @@ int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_bl
     // features are produced inside the embedding kernels (transform, division by sigma, float32 cast)
     h->prod = FrFeat{h->src, h->tgt, h->state, h->ts, h->M, h->D};
     h->L.prod = &h->prod;
+    h->L.ref_pos = h->ref_pos;
     int blur = 1;
     // filterreg.py:90-91: the blurred lattice is used only if it has at most N * alpha vertices.  The answer is exact
     // every time; what changes with the previous E-step's answer is which lattice is built FIRST:

@@ -19,8 +19,9 @@ def fr_golden():
 
 
 def test_lattice_vs_reference_vectors(fr_golden):
-    """Same simplices and weights as the vendored lattice: vertex count identical, filter outputs equal up to
-    the float32 summation order of the splat (atomics)."""
+    """Same simplices and weights as the vendored lattice and - with the order-preserving splat, the default - the same
+    float32 sums in the same order: vertex count identical, filter outputs BIT-IDENTICAL to the reference's
+    (permutohedral.cpp:482-616)."""
     from probreg_amd import gaussian_filtering as gf
 
     for name in fr_golden.group("lattice"):
@@ -31,7 +32,45 @@ def test_lattice_vs_reference_vectors(fr_golden):
             got = lat.filter(c["values_ch%d" % ch])
             want = c["out_ch%d" % ch]
             assert got.shape == want.shape
-            assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)), (name, ch)
+            assert np.array_equal(got, want), (name, ch, float(np.max(np.abs(got - want))))
+
+
+def test_atomic_splat_mode_stays_within_round_off(fr_golden):
+    """prg_lattice_set_splat_mode(0): float atomics in arrival order - the reference's values up to the summation order."""
+    from probreg_amd import _lib, gaussian_filtering as gf
+
+    _lib.check(_lib.lib.prg_lattice_set_splat_mode(0))
+    try:
+        for name in fr_golden.group("lattice"):
+            c = fr_golden.case("lattice/" + name)
+            lat = gf.Permutohedral(c["points"], "blur1" in name)
+            for ch in (1, 3, 5):
+                got, want = lat.filter(c["values_ch%d" % ch]), c["out_ch%d" % ch]
+                assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)), (name, ch)
+    finally:
+        _lib.check(_lib.lib.prg_lattice_set_splat_mode(1))
+
+
+@pytest.mark.parametrize("n,d,scale,blur", [(200000, 3, 0.3, True), (200000, 3, 12.0, True), (150000, 3, 150.0, False),
+                                            (100000, 2, 40.0, True), (100000, 2, 1500.0, True), (60000, 1, 0.5, True),
+                                            (60000, 1, 3000.0, False), (20000, 5, 1.0, True), (20000, 5, 30.0, True)])
+def test_ordered_splat_bit_exact_over_chain_lengths(n, d, scale, blur):
+    """Chains of every length class (whole wave / 8 lanes / one thread per vertex: ~10^4 ... ~1 points per vertex), d <= 3
+    and the generic d > 3 path, against the C lattice (bit-identical to the vendored one): equal bits, twice."""
+    from oracle import permutohedral as po
+    from probreg_amd import gaussian_filtering as gf
+
+    rng = np.random.default_rng(n + d)
+    pts = (rng.uniform(0.0, 1.0, (n, d)) * scale).astype(np.float32)
+    vals = rng.normal(size=(n, 5)).astype(np.float32)
+    want_lat = po.Lattice(pts, blur)
+    lat = gf.Permutohedral(pts, blur)
+    assert lat.get_lattice_size() == want_lat.lattice_size
+    for ch in (1, 3, 5):
+        want = want_lat.filter(vals[:, :ch])
+        got = lat.filter(vals[:, :ch])
+        assert np.array_equal(got, want), (ch, float(np.max(np.abs(got - want))))
+        assert np.array_equal(lat.filter(vals[:, :ch]), got)
 
 
 def test_reference_unit_test_gaussian_filtering():
@@ -59,7 +98,7 @@ def test_estep_vs_oracle():
         got = filterreg.RigidFilterReg(src).expectation_step(src, tgt, tgt, sigma2, True)
         for a, b in ((got.m0, want.m0), (got.m1, want.m1), (got.m2, want.m2)):
             assert a.dtype == np.float32
-            assert np.max(np.abs(a - b)) <= 3e-5 * np.max(np.abs(b)), sigma2
+            assert np.array_equal(a, b), (sigma2, float(np.max(np.abs(a - b))))  # ordered splat: the reference's bits
 
 
 def _kwargs(c):
