@@ -479,9 +479,8 @@ def bench_filterreg(workload, steps, warmup):
     sizes = []
 
     def step():
-        size, _blur = plan.estep()
-        out = plan.mstep(0.05, True, "pt2pt", 1e-4)  # the M-step kernel advances the device state
-        state["rot"], state["sigma2"] = out[:9].reshape(3, 3).copy(), out[15]
+        size, _blur = plan.estep()                               # one hand-over: the lattice size (device mailbox)
+        plan.mstep(0.05, True, "pt2pt", 1e-4, read=False)        # enqueued only; the kernel advances the device state
         sizes.append(size)
 
     plan.set_state(np.identity(3), np.zeros(3), s2_0)
@@ -495,6 +494,8 @@ def bench_filterreg(workload, steps, warmup):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    out = plan.get_state()
+    state["rot"], state["sigma2"] = out[:9].reshape(3, 3).copy(), out[15]
     d, c = 3, 5
     lat = float(np.mean(sizes))
     alg = (2 * n) * (4 * d + 8 * (d + 1)) + n * (4 * c + 8 * (d + 1) + 8 * c * (d + 1)) \

@@ -89,6 +89,8 @@ int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
  * E-step's column pass used (1 = matrix cores). */
 int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound);
 int prg_cpd_last_estep_engine(prg_cpd* h, int* engine);
+/* ... and for both sweeps of the last E-step: 1 = matrix cores, 0 = vector pipe (column pass, row pass). */
+int prg_cpd_last_estep_engines(prg_cpd* h, int* col_engine, int* row_engine);
 
 /* Upload the (already centred) source cloud, replicated on every device.
  * Replaces: CoherentPointDrift.set_source, cpd.py:61-62. */
@@ -254,10 +256,14 @@ int prg_nn_mean_distance(int device, void* hip_stream, const float* a_hd, int64_
  * probreg.gaussian_filtering.Permutohedral (gaussian_filtering.py:8-17). */
 typedef struct prg_ph prg_ph;
 /* How the splat (permutohedral.cpp:491-500 / :548-556, `values[o] += w * in[i]` over the points in order) accumulates,
- * process-wide, for prg_ph_filter and prg_fr_estep:  1 (default) - every vertex' float32 sum is evaluated as ONE chain in
- * the reference's point order (stable sort of the point-vertex incidences by vertex, then sequential chains): the
- * reference's bits, identical from run to run;  0 - float atomics in arrival order (round-off level noise). */
-int prg_lattice_set_splat_mode(int ordered);
+ * process-wide, for prg_ph_filter and prg_fr_estep:
+ *   1 (default)  64-bit fixed-point atomics: order independent - identical bits from run to run, every vertex the correctly
+ *                rounded exact sum of its terms (the reference's float32 chain carries its own round-off; the two agree to it);
+ *   2            the reference's own order: one sequential float32 chain per vertex in point order (stable sort of the
+ *                point-vertex incidences by vertex, then the chains) - the reference's BITS, at the price of the sort and of
+ *                chains as long as the busiest vertex has points;
+ *   0            float atomics in arrival order (round-off level run-to-run noise; the measurement baseline). */
+int prg_lattice_set_splat_mode(int mode);
 int prg_ph_create(prg_ph** out, int device, void* hip_stream);
 int prg_ph_destroy(prg_ph* h);
 /* init(features, with_blur): points is n x d row-major float32 (the reference passes the transpose). */
@@ -289,9 +295,14 @@ int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd)
  * [16] 1 if a transform was estimated (0 = every m0 was zero: the reference returns q = None,
  * filterreg.py:167-168), [17] sigma2 this step used.  min_sigma2 >= 0 advances the device state like the driver
  * (`self._sigma2 = max(res.sigma2, min_sigma2)`, filterreg.py:140) so the loop needs no upload per iteration;
- * a negative min_sigma2 leaves the device sigma2 untouched (M-step only).
+ * a negative min_sigma2 leaves the device sigma2 untouched (M-step only).  out_host may be NULL: the M-step is only
+ * enqueued, nothing is read back and the host does not wait (a driver with a fixed iteration count and no callbacks
+ * reads the state once at the end, prg_fr_get_state).
  * Replaces: RigidFilterReg._maximization_step filterreg.py:158-196 + cc/kabsch.cc:6-109. */
 int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host);
+/* The device state (synchronises): out_host[20] = the 18 entries of prg_fr_mstep, then [18] q of the last M-step that had
+ * anything to fit (an all-zero one sets [13] to NaN and [16] to 0), [19] the number of such M-steps since prg_fr_set_state. */
+int prg_fr_get_state(prg_filterreg* h, double* out_host);
 
 /* Point-to-plane objective (filterreg.py:101-105, 183-186): target normals (n x 3 float64, NULL clears) add a
  * 3-channel filter `nx` to the E-step; prg_fr_mstep_pt2pl solves the 6 x 6 twist system

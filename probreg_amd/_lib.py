@@ -65,6 +65,7 @@ SIGNATURES = {
     "prg_cpd_set_options": [_vp, _i, _i, _i],
     "prg_cpd_set_dense_engine": [_vp, _i, _d],
     "prg_cpd_last_estep_engine": [_vp, _c.POINTER(_i)],
+    "prg_cpd_last_estep_engines": [_vp, _c.POINTER(_i), _c.POINTER(_i)],
     "prg_cpd_set_source": [_vp, _vp, _i64, _i],
     "prg_cpd_set_target": [_vp, _vp, _i64, _i, _i64],
     "prg_cpd_bind_moments": [_vp, _vp],
@@ -115,6 +116,7 @@ SIGNATURES = {
     "prg_fr_estep": [_vp, _d, _c.POINTER(_i), _c.POINTER(_i)],
     "prg_fr_get_estep": [_vp, _vp, _vp, _vp],
     "prg_fr_mstep": [_vp, _d, _i, _d, _vp],
+    "prg_fr_get_state": [_vp, _vp],
     "prg_fr_set_target_normals": [_vp, _vp],
     "prg_fr_get_nx": [_vp, _vp],
     "prg_fr_mstep_pt2pl": [_vp, _d, _i, _d, _vp],

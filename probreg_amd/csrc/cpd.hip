@@ -1037,6 +1037,13 @@ int prg_cpd_last_estep_engine(prg_cpd* h, int* engine) {
     return PRG_OK;
 }
 
+int prg_cpd_last_estep_engines(prg_cpd* h, int* col_engine, int* row_engine) {
+    PRG_REQUIRE(h && col_engine && row_engine, PRG_ERR_INVALID, "prg_cpd_last_estep_engines: NULL argument");
+    *col_engine = h->last_estep_mfma ? 1 : 0;
+    *row_engine = h->last_estep_row_mfma ? 1 : 0;
+    return PRG_OK;
+}
+
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull) {
     PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_options: NULL handle");
     PRG_REQUIRE(!h->have_source && !h->have_target, PRG_ERR_STATE,
@@ -1247,6 +1254,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         }
     }
     h->last_estep_mfma = use_mfma;
+    h->last_estep_row_mfma = row_mfma;
     if (col_launched) {
     } else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);

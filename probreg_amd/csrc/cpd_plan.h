@@ -87,7 +87,7 @@ struct prg_cpd {
     EngineDecision* eng_host = nullptr;  // mapped, coherent host memory: the mailbox the host polls
     EngineDecision* eng_host_dev = nullptr;  // ... as the device addresses it
     int pred_col = 1;           // the column-pass engine the host launches ahead of the decision (= the previous decision)
-    bool last_estep_mfma = false;
+    bool last_estep_mfma = false, last_estep_row_mfma = false;  // engines of the last E-step's column / row pass
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)
     // measurement hook: evaluated (wave, group) blocks per workgroup of the last culled column / row pass

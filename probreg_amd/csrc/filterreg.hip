@@ -15,6 +15,9 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <type_traits>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -66,6 +69,9 @@ struct FrFeat {
     int dim;
 };
 
+// what the resolve kernel publishes to the host (see k_resolve)
+struct LatticeMail { int size, overflow, side_size, side_overflow; unsigned seq; unsigned pad[3]; };
+
 struct Lattice {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -116,6 +122,21 @@ struct Lattice {
     int64_t seg_inc_cap = 0, seg_size_cap = 0;
     void* sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
+    float* terms = nullptr;             // [ch][n_inc] the splat's terms w * in[i] in sorted order (per filter call)
+    int64_t terms_elems = 0;
+    int* long_list = nullptr;           // vertices whose chains are longer than kLongSeg, then their count
+    int64_t long_cap = 0;
+    LatticeMail* mail = nullptr;        // mapped, coherent host memory the resolve kernel publishes the counters in
+    LatticeMail* mail_dev = nullptr;    // ... as the device addresses it
+    unsigned mail_seq = 0;
+    bool count_clean = false, count2_clean = false;  // the device counters are zero (cleared by the last resolve)
+    long long* fx = nullptr;            // [(size + 1)][ch] fixed-point accumulators of the order-independent splat
+                                        // (all zero between filter calls: k_fix_to_float clears what it has read)
+    int64_t fx_elems = 0;
+    double* fx_scale = nullptr;         // [32] 2^S_k, [32] 2^-S_k, then 32 unsigned: largest |value| per channel (float bits)
+    const float* fx_scale_key = nullptr;  // the value array the scales were computed for ...
+    int fx_scale_ch = 0;
+    bool fx_scale_static = false;       // ... which the owner promises not to change (FilterReg plan: target moments)
     bool seg_valid = false;             // the arrays describe the current lattice for points >= seg_first
     int64_t seg_first = -1;
     const int* ref_pos = nullptr;       // device, may be null (identity): j-th splatted point of the reference's order ->
@@ -137,6 +158,11 @@ struct EmbedTable {
     int* slot_id;             // may be null (count only)
     unsigned long long* dkeys;
 };
+
+#ifndef PRG_PLAIN_PROBE
+#define PRG_PLAIN_PROBE 1
+#endif
+constexpr bool kPlainProbe = PRG_PLAIN_PROBE != 0;
 
 // Embed one point (features f, scale factors s) and insert its D + 1 vertices into table T.  pslot_i / bary_i: where the
 // point's slots and barycentric weights go, or null (the side table of the speculative with_blur decision only counts).
@@ -227,9 +253,16 @@ __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, floa
                 slot = 0;
                 break;
             }
-            // plain (L2-coherent) read first: once a vertex exists, the ~N/L points sharing it never issue an
-            // atomic - a CAS storm on a few hundred hot keys costs milliseconds when sigma is large
-            unsigned long long cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // An ordinary (cacheable) read first: it may be stale - each XCD has its own L2, coherent with the others only
+            // at kernel boundaries - but an entry of THIS generation never changes once written, so a hit or a slot taken
+            // by another key of this build is final, and only a slot that LOOKS free is asked again at device scope
+            // (that read goes past the L2s to the memory side and costs several times as much).  Once a vertex exists,
+            // the ~N/L points sharing it never issue an atomic - a CAS storm on a few hundred hot keys costs milliseconds
+            // when sigma is large.
+            unsigned long long cur = kPlainProbe ? tkeys[slot] : 0ull;
+            if (kPlainProbe && cur == mine) break;
+            if (!kPlainProbe || (unsigned)(cur >> 48) != gen)
+                cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)(cur >> 48) != gen) {  // empty, or left over from an earlier build
                 const unsigned long long old = atomicCAS(&tkeys[slot], cur, mine);
                 if (old == cur) {
@@ -508,9 +541,26 @@ __global__ __launch_bounds__(kBlock) void k_compact(const unsigned long long* __
     }
 }
 
+// Every (point, remainder) slot index -> the dense vertex id of the slot.  The launch needs nothing the host does not know
+// before the embedding has run, so it is issued right behind it; its first thread PUBLISHES the embedding's counters (vertex
+// count, overflow flag, and the side table's pair) in the host's mapped mailbox - the host learns the lattice size while this
+// kernel runs and enqueues the size-dependent launches behind it, without draining the queue - and clears them for the next
+// build (`mail` null: plain resolve).
 __global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int64_t total,
-                                                    const int* __restrict__ slot_id) {
+                                                    const int* __restrict__ slot_id, int* __restrict__ count,
+                                                    int* __restrict__ count2, LatticeMail* __restrict__ mail,
+                                                    unsigned seq) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0 && mail) {
+        mail->size = count[0];
+        mail->overflow = count[1];
+        mail->side_size = count2 ? count2[0] : 0;
+        mail->side_overflow = count2 ? count2[1] : 0;
+        __threadfence_system();
+        __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        count[0] = count[1] = 0;
+        if (count2) count2[0] = count2[1] = 0;
+    }
     if (i < total) pslot[i] = slot_id[pslot[i]];
 }
 
@@ -553,9 +603,23 @@ __global__ __launch_bounds__(kBlock) void k_neighbours(const unsigned long long*
 
 // ---- filtering (permutohedral.cpp:482-616) --------------------------------------------------------------
 // vals layout: [(size + 1)][C], row 0 is the all-zero row that the missing-neighbour id -1 maps to.
+// FX: the terms are accumulated as 64-bit fixed-point integers (term * 2^S_k, S_k per channel from the largest |value| of the
+// channel: k_chan_scale) - integer addition is associative, so the atomics' arrival order no longer matters: the same bits
+// in every run, and each vertex' value is the correctly rounded EXACT sum of its terms.  !FX: float atomics (arrival order).
+template <bool FX>
+__device__ __forceinline__ void splat_add_global(float* __restrict__ vals, long long* __restrict__ fx, int64_t idx, float term,
+                                                 double mul) {
+    if (FX)
+        atomicAdd(reinterpret_cast<unsigned long long*>(fx + idx), (unsigned long long)__double2ll_rn((double)term * mul));
+    else
+        unsafeAtomicAdd(&vals[idx], term);
+}
+
+template <bool FX>
 __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset, const float* __restrict__ bary,
                                                   const float* __restrict__ in, int64_t first, int64_t n, int d1,
-                                                  int ch, float* __restrict__ vals) {
+                                                  int ch, float* __restrict__ vals, long long* __restrict__ fx,
+                                                  const double* __restrict__ scale) {
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (n - first) * d1) return;
     const int64_t i = first + t / d1;
@@ -564,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset
     const float w = bary[i * d1 + r];
     for (int k = 0; k < ch; ++k) {
         const float p = __fmul_rn(w, in[i * ch + k]);
-        if (p != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], p);
+        if (p != 0.f) splat_add_global<FX>(vals, fx, (int64_t)o * ch + k, p, FX ? scale[k] : 0.0);
     }
 }
 
@@ -573,23 +637,29 @@ __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset
 // lattice is small (sigma large: a few hundred vertices shared by 2M point-vertex incidences) this removes
 // the same-address global atomic storm; when a chunk touches more distinct vertices than the table holds,
 // the overflow goes straight to global memory, where contention is low by then.
-// (256 points / 256 slots per workgroup: 9 KB of LDS, 8 workgroups per CU.  The first version used 2048 / 2048 = 72 KB:
+// (256 points / 256 slots per workgroup: 9 KB of LDS (17 KB in fixed point), 8 workgroups per CU.  The first version used 2048 / 2048 = 72 KB:
 // 245 workgroups of one wave per SIMD each, every lane walking 32 incidences through dependent loads and returning LDS
 // atomics with nobody to hide the latency - 52 % of the wave cycles were waits, profiles/r2_filterreg_500k_pmc.txt)
 constexpr int kSplatBits = 8;
 constexpr int kSplatSlots = 1 << kSplatBits;  // LDS table entries (key + up to 8 channels)
 constexpr int kSplatMaxCh = 8;
 constexpr int kSplatPts = 256;                // points per workgroup
+template <bool FX>
 __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ offset, const float* __restrict__ bary,
                                                       const float* __restrict__ in, int64_t first, int64_t n, int d1,
-                                                      int ch, float* __restrict__ vals) {
+                                                      int ch, float* __restrict__ vals, long long* __restrict__ fx,
+                                                      const double* __restrict__ scale) {
+    typedef typename std::conditional<FX, unsigned long long, float>::type acc_t;
     __shared__ int skey[kSplatSlots];
-    __shared__ float sval[kSplatSlots * kSplatMaxCh];
+    __shared__ acc_t sval[kSplatSlots * kSplatMaxCh];
     __shared__ int sfill;
     for (int t = threadIdx.x; t < kSplatSlots; t += kBlock) skey[t] = -1;
-    for (int t = threadIdx.x; t < kSplatSlots * kSplatMaxCh; t += kBlock) sval[t] = 0.f;
+    for (int t = threadIdx.x; t < kSplatSlots * kSplatMaxCh; t += kBlock) sval[t] = (acc_t)0;
     if (threadIdx.x == 0) sfill = 0;
     __syncthreads();
+    double mul[kSplatMaxCh];
+#pragma unroll
+    for (int k = 0; k < kSplatMaxCh; ++k) mul[k] = (FX && k < ch) ? scale[k] : 0.0;
     const int64_t p0 = first + (int64_t)blockIdx.x * kSplatPts;
     const int64_t p1 = (p0 + kSplatPts < n) ? p0 + kSplatPts : n;
     for (int64_t t = (p0 - first) * d1 + threadIdx.x; t < (p1 - first) * d1; t += kBlock) {
@@ -599,8 +669,9 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
         const int o = offset[i * d1 + r] + 1;
         bool any = false;
         float p[kSplatMaxCh];
-        for (int k = 0; k < ch; ++k) {
-            p[k] = __fmul_rn(w, in[i * ch + k]);
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k) {
+            p[k] = k < ch ? __fmul_rn(w, in[i * ch + k]) : 0.f;
             any |= p[k] != 0.f;
         }
         if (!any) continue;
@@ -615,12 +686,18 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
             if (cur == o) { slot = (int)h; break; }
             h = (h + 1) & (kSplatSlots - 1);
         }
-        if (slot >= 0) {
-            for (int k = 0; k < ch; ++k)
-                if (p[k] != 0.f) atomicAdd(&sval[slot * kSplatMaxCh + k], p[k]);
-        } else {
-            for (int k = 0; k < ch; ++k)
-                if (p[k] != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], p[k]);
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k) {
+            if (k >= ch || p[k] == 0.f) continue;
+            if (slot >= 0) {
+                if (FX)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sval[slot * kSplatMaxCh + k]),
+                              (unsigned long long)__double2ll_rn((double)p[k] * mul[k]));
+                else
+                    atomicAdd(reinterpret_cast<float*>(&sval[slot * kSplatMaxCh + k]), p[k]);
+            } else {
+                splat_add_global<FX>(vals, fx, (int64_t)o * ch + k, p[k], mul[k]);
+            }
         }
     }
     __syncthreads();
@@ -628,10 +705,59 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
         const int o = skey[t];
         if (o < 0) continue;
         for (int k = 0; k < ch; ++k) {
-            const float v = sval[t * kSplatMaxCh + k];
-            if (v != 0.f) unsafeAtomicAdd(&vals[(int64_t)o * ch + k], v);
+            const acc_t v = sval[t * kSplatMaxCh + k];
+            if (v == (acc_t)0) continue;
+            if (FX)
+                atomicAdd(reinterpret_cast<unsigned long long*>(fx + (int64_t)o * ch + k), (unsigned long long)v);
+            else
+                unsafeAtomicAdd(&vals[(int64_t)o * ch + k], (float)v);
         }
     }
+}
+
+// largest |in[i][k]| over the splatted rows, per channel -> maxabs[k] as float bits (non-negative floats order like their
+// bits); one atomic per workgroup and channel
+__global__ __launch_bounds__(kBlock) void k_chan_maxabs(const float* __restrict__ in, int64_t first, int64_t n, int ch,
+                                                        unsigned* __restrict__ maxabs) {
+    __shared__ unsigned smax[32];
+    if (threadIdx.x < 32) smax[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t total = (n - first) * ch;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t step = stride - stride % ch;  // a thread stays on one channel
+    float v = 0.f;
+    for (int64_t z = t; z < total; z += step) v = fmaxf(v, fabsf(in[first * ch + z]));
+    if (t < total && v > 0.f && isfinite(v)) atomicMax(&smax[t % ch], __float_as_uint(v));
+    __syncthreads();
+    if (threadIdx.x < ch && smax[threadIdx.x]) atomicMax(maxabs + threadIdx.x, smax[threadIdx.x]);
+}
+
+// scale[k] = 2^S_k with n * maxabs_k * 2^S_k < 2^61 (no overflow whatever the vertex), scale[ch + k] = 2^-S_k
+__global__ void k_chan_scale(const unsigned* __restrict__ maxabs, int ch, double n_points, double* __restrict__ scale) {
+    const int k = threadIdx.x;
+    if (k >= ch) return;
+    const double m = (double)__uint_as_float(maxabs[k]);
+    int e = 0;
+    if (m > 0.0) {
+        (void)frexp(m * n_points, &e);  // m n < 2^e
+        e = 61 - e;
+        e = e > 120 ? 120 : (e < -120 ? -120 : e);
+    }
+    scale[k] = ldexp(1.0, e);
+    scale[ch + k] = ldexp(1.0, -e);
+}
+
+// fixed-point sums -> the float value plane a (row 0 of both planes: the all-zero row)
+__global__ __launch_bounds__(kBlock) void k_fix_to_float(long long* __restrict__ fx, int64_t elems, int ch,
+                                                         const double* __restrict__ scale, float* __restrict__ vals_a,
+                                                         float* __restrict__ vals_b) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= elems) return;
+    const int k = (int)(t % ch);
+    vals_a[t] = (float)((double)fx[t] * scale[ch + k]);
+    fx[t] = 0;  // ready for the next filter call: the accumulators are never cleared by a fill
+    if (t < ch) vals_b[t] = 0.f;
 }
 
 // ---- order-preserving splat ------------------------------------------------------------------------------------------
@@ -640,10 +766,10 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
 // different order gives different float32 bits.  The atomic splats above accumulate in arrival order: run-to-run
 // noise of ~1e-7 relative that the lattice amplifies from EM iteration to EM iteration (cell assignment is discontinuous
 // in sigma).  Here every vertex' chain is evaluated in the reference's order: the incidences of the splatted points are
-// sorted by vertex id with a STABLE sort from an input written in the reference's point order (lat_segments), then one
-// thread (short chains), 8 lanes or a whole wave (long chains: while the lattice has a few hundred vertices each one
-// collects ~10^4 points) loads the chain's terms in parallel and adds them up one by one - bit for bit the reference's
-// float32 values, the same in every run.
+// sorted by vertex id with a STABLE sort from an input written in the reference's point order (lat_segments); per filter
+// call the terms are gathered into that order (k_seg_gather) and every chain is added up term by term by one thread
+// (k_segchain_thread) or, when it is long, by one wave that keeps several hundred terms in flight (k_segchain_wave) - bit
+// for bit the reference's float32 values, the same in every run.
 __global__ __launch_bounds__(kBlock) void k_seg_keys(const int* __restrict__ offset, const int* __restrict__ ref_pos,
                                                      int64_t first, int64_t n_inc, int d1, unsigned* __restrict__ keys,
                                                      int* __restrict__ vals, int* __restrict__ seg, int64_t seg_elems) {
@@ -667,78 +793,115 @@ __global__ __launch_bounds__(kBlock) void k_seg_bounds(const unsigned* __restric
     if (t + 1 == n_inc || keys[t + 1] != k) seg[size + k] = (int)(t + 1);
 }
 
-// G lanes per vertex (1, 8 or 64).  vals_a / vals_b: the two value planes [(size + 1)][ch]; row 0 (the "no neighbour" row
-// of the blur) is zeroed in both, every other row of plane a is WRITTEN - nothing is cleared beforehand.
-template <int G>
-__global__ __launch_bounds__(kBlock) void k_segsum(const int* __restrict__ seg, const int* __restrict__ sinc,
-                                                   const float* __restrict__ bary, const float* __restrict__ in, int d1,
-                                                   int ch, int size, float* __restrict__ vals_a,
-                                                   float* __restrict__ vals_b) {
-    constexpr int kGroups = kBlock / G;
-    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int64_t v = (int64_t)blockIdx.x * kGroups + grp;
+// Pass 1 of a filter call: the terms `w * in[i]` (permutohedral.cpp:497 / :555, one float multiplication) of every
+// incidence in SORTED order, one plane per channel: prod[k * stride + t].  Fully parallel - this is where the scattered
+// reads happen; the chains below then stream contiguous memory.
+__global__ __launch_bounds__(kBlock) void k_seg_gather(const int* __restrict__ sinc, const float* __restrict__ bary,
+                                                       const float* __restrict__ in, int64_t n_inc, int d1, int ch,
+                                                       float* __restrict__ prod, int64_t stride,
+                                                       int* __restrict__ long_count) {
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t == 0) *long_count = 0;  // (list of the long chains, filled by k_segchain_thread of this filter call)
+    if (t >= n_inc) return;
+    const int inc = sinc[t];
+    const float w = bary[inc];
+    const float* __restrict__ row = in + (int64_t)(inc / d1) * ch;
+    for (int k = 0; k < ch; ++k) prod[k * stride + t] = __fmul_rn(w, row[k]);
+}
+
+// Pass 2a: one thread per vertex adds its chain up, term by term, in order.  Chains longer than kLongSeg are left to
+// k_segchain_wave (their vertices are appended to `long_list`).  vals_a / vals_b: the two value planes [(size + 1)][ch];
+// row 0 (the "no neighbour" row of the blur) is zeroed in both, every other row of plane a is WRITTEN by whoever owns the
+// vertex - nothing is cleared beforehand.
+constexpr int kLongSeg = 64;
+__global__ __launch_bounds__(kBlock) void k_segchain_thread(const int* __restrict__ seg, const float* __restrict__ prod,
+                                                            int64_t stride, int ch, int size, float* __restrict__ vals_a,
+                                                            float* __restrict__ vals_b, int* __restrict__ long_list,
+                                                            int* __restrict__ long_count) {
+    const int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x < ch) {
         vals_a[threadIdx.x] = 0.f;
         vals_b[threadIdx.x] = 0.f;
     }
-    const bool live = v < size;
-    const int start = live ? seg[v] : 0, end = live ? seg[size + v] : 0;
-    if (G == 1) {
-        if (!live) return;
-        float acc[kSplatMaxCh];
-#pragma unroll
-        for (int k = 0; k < kSplatMaxCh; ++k) acc[k] = 0.f;
-        for (int t = start; t < end; ++t) {
-            const int inc = sinc[t];
-            const float w = bary[inc];
-            const float* __restrict__ row = in + (int64_t)(inc / d1) * ch;
-#pragma unroll
-            for (int k = 0; k < kSplatMaxCh; ++k)
-                if (k < ch) acc[k] = __fadd_rn(acc[k], __fmul_rn(w, row[k]));
-        }
-#pragma unroll
-        for (int k = 0; k < kSplatMaxCh; ++k)
-            if (k < ch) vals_a[(v + 1) * ch + k] = acc[k];
+    if (v >= size) return;
+    const int start = seg[v], end = seg[size + v];
+    if (end - start > kLongSeg) {
+        long_list[atomicAdd(long_count, 1)] = (int)v;  // (the order of the list is irrelevant: one wave per entry)
         return;
     }
-    // G > 1: lane gl fetches the term of position base + gl (all channels), the products go through LDS, lane k < ch adds
-    // channel k's products up in order.  The next round's loads are issued before this round's chain starts.
-    __shared__ float prod[kGroups][G][kSplatMaxCh];
-    float acc = 0.f;
-    float pr[kSplatMaxCh];
-    auto fetch = [&](int base) {
-        const int t = base + gl;
+    float acc[kSplatMaxCh];
 #pragma unroll
-        for (int k = 0; k < kSplatMaxCh; ++k) pr[k] = 0.f;
-        if (t < end) {
-            const int inc = sinc[t];
-            const float w = bary[inc];
-            const float* __restrict__ row = in + (int64_t)(inc / d1) * ch;
+    for (int k = 0; k < kSplatMaxCh; ++k) acc[k] = 0.f;
+    // eight terms per channel are fetched before any of them is added: the loads do not depend on the sums, only the
+    // additions form a chain
+    for (int t0 = start; t0 < end; t0 += 8) {
+        float q[8][kSplatMaxCh];
 #pragma unroll
-            for (int k = 0; k < kSplatMaxCh; ++k)
-                if (k < ch) pr[k] = __fmul_rn(w, row[k]);
-        }
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < kSplatMaxCh; ++k) q[j][k] = (k < ch && t0 + j < end) ? prod[k * stride + t0 + j] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (t0 + j < end)
+#pragma unroll
+                for (int k = 0; k < kSplatMaxCh; ++k) acc[k] = __fadd_rn(acc[k], q[j][k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kSplatMaxCh; ++k)
+        if (k < ch) vals_a[(v + 1) * ch + k] = acc[k];
+}
+
+// Pass 2b: one wave per long chain (while the lattice has a few hundred vertices each collects ~10^4 terms).  All 64 lanes
+// fetch - 64 consecutive terms per channel and round, kRing rounds in flight -, lane k < ch adds channel k's terms up in
+// order out of LDS.  The chain itself is what bounds it: one dependent float addition per term.
+constexpr int kRing = 8;
+__global__ __launch_bounds__(kBlock) void k_segchain_wave(const int* __restrict__ seg, const float* __restrict__ prod,
+                                                          int64_t stride, int ch, int size, float* __restrict__ vals_a,
+                                                          const int* __restrict__ long_list,
+                                                          const int* __restrict__ long_count) {
+    __shared__ __attribute__((aligned(16))) float stage[kBlock / 64][kSplatMaxCh][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * (kBlock / 64) + wv;
+    if (w >= *long_count) return;
+    const int v = long_list[w];
+    const int start = seg[v], end = seg[size + v];
+    float pr[kRing][kSplatMaxCh];
+    auto issue = [&](int slot, int base) {
+#pragma unroll
+        for (int k = 0; k < kSplatMaxCh; ++k) pr[slot][k] = (k < ch && base + lane < end) ? prod[k * stride + base + lane] : 0.f;
     };
-    int base = start;
-    fetch(base);
-    while (__any(base < end)) {  // wave-uniform trip count: the groups of a wave wait for the longest chain among them
 #pragma unroll
-        for (int k = 0; k < kSplatMaxCh; ++k) prod[grp][gl][k] = pr[k];
-        const int cnt = base < end ? (end - base < G ? end - base : G) : 0;
-        fetch(base + G);
-        __threadfence_block();  // (LDS is in order within a wave; the fence keeps the compiler from reordering across it)
-        if (gl < ch) {
-            if (cnt == G) {
-#pragma unroll 8
-                for (int j = 0; j < G; ++j) acc = __fadd_rn(acc, prod[grp][j][gl]);
-            } else {
-                for (int j = 0; j < cnt; ++j) acc = __fadd_rn(acc, prod[grp][j][gl]);
+    for (int s = 0; s < kRing; ++s) issue(s, start + 64 * s);
+    float acc = 0.f;
+    float (*lds)[64] = stage[wv];
+    for (int base = start; base < end; base += 64 * kRing) {
+#pragma unroll
+        for (int s = 0; s < kRing; ++s) {
+            const int b = base + 64 * s;
+            if (b < end) {  // wave-uniform
+#pragma unroll
+                for (int k = 0; k < kSplatMaxCh; ++k)
+                    if (k < ch) lds[k][lane] = pr[s][k];
+                issue(s, b + 64 * kRing);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS is in order within a wave: compiler ordering only
+                const int cnt = end - b < 64 ? end - b : 64;
+                if (lane < ch) {
+                    const float* __restrict__ c = lds[lane];
+                    if (cnt == 64) {
+#pragma unroll
+                        for (int j = 0; j < 64; j += 4) {
+                            const float4 q = *reinterpret_cast<const float4*>(c + j);
+                            acc = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(acc, q.x), q.y), q.z), q.w);
+                        }
+                    } else {
+                        for (int j = 0; j < cnt; ++j) acc = __fadd_rn(acc, c[j]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             }
         }
-        __threadfence_block();
-        base += G;
     }
-    if (live && gl < ch) vals_a[(v + 1) * ch + gl] = acc;
+    if (lane < ch) vals_a[(int64_t)(v + 1) * ch + lane] = acc;
 }
 
 // seq_mask bit k set: channel k follows seqCompute (0.5*(n1+n2) evaluated in double, :510), else sseCompute.
@@ -782,9 +945,10 @@ __global__ __launch_bounds__(kBlock) void k_slice(const int* __restrict__ offset
 int lat_free(Lattice* L) {
     void* ptrs[] = {L->feat, L->tkeys, L->slot_id, L->pslot, L->bary, L->dkeys, L->nb, L->count, L->vals, L->io,
                     L->rem0s, L->rank8, L->kfull, L->gcheck, L->scale_dev, L->tkeys2, L->count2,
-                    L->skeys, L->svals, L->seg, L->sort_tmp};
-    L->skeys = nullptr; L->svals = nullptr; L->seg = nullptr; L->sort_tmp = nullptr;
-    L->seg_inc_cap = L->seg_size_cap = 0;
+                    L->skeys, L->svals, L->seg, L->sort_tmp, L->terms, L->long_list, L->fx, L->fx_scale};
+    L->skeys = nullptr; L->svals = nullptr; L->seg = nullptr; L->sort_tmp = nullptr; L->terms = nullptr; L->long_list = nullptr; L->fx = nullptr; L->fx_scale = nullptr;
+    L->fx_elems = 0; L->fx_scale_key = nullptr;
+    L->seg_inc_cap = L->seg_size_cap = L->terms_elems = L->long_cap = 0;
     L->sort_tmp_bytes = 0;
     L->seg_valid = false;
     L->tkeys2 = nullptr; L->count2 = nullptr; L->cap2 = 0;
@@ -800,6 +964,10 @@ int lat_free(Lattice* L) {
     L->cap = 0;
     if (L->pinned) (void)hipHostFree(L->pinned);
     L->pinned = nullptr;
+    if (L->mail) (void)hipHostFree(L->mail);
+    L->mail = nullptr;
+    L->mail_dev = nullptr;
+    L->count_clean = L->count2_clean = false;
     return PRG_OK;
 }
 
@@ -902,15 +1070,20 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
     for (int attempt = 0; attempt < 2; ++attempt) {
         L->cap_used = capu;
         PRG_TRY(next_generation(L->tkeys, L->cap, &L->gen, st));
-        PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
+        if (!L->count_clean) PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));  // (normally left clean by k_resolve)
+        L->count_clean = false;
         const unsigned long long mask = (unsigned long long)capu - 1;
         const EmbedTable main_table = {L->tkeys, mask, L->gen, L->count, L->slot_id, L->dkeys};
         const EmbedTable no_side = {nullptr, 0, 0, nullptr, nullptr, nullptr};
         const float no_sc[3] = {0.f, 0.f, 0.f};
         auto embed = [&](int64_t first, int64_t last) { launch_embed(L, d, first, last, sc, main_table, no_side, no_sc); };
         if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
-        volatile int* host = reinterpret_cast<volatile int*>(L->pinned);
-        host[0] = host[1] = 0;
+        if (!L->mail) {
+            PRG_HIP(hipHostMalloc((void**)&L->mail, sizeof(LatticeMail), hipHostMallocMapped | hipHostMallocCoherent));
+            memset(L->mail, 0, sizeof(LatticeMail));
+            PRG_HIP(hipHostGetDevicePointer((void**)&L->mail_dev, L->mail, 0));
+        }
+        int host[2] = {0, 0};
         int64_t done = 0;
         if (decide_above >= 0 && n >= 4096) {  // stage 1: a sixteenth of the points; the vertex counter tells
             done = n / 16;
@@ -918,6 +1091,8 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
             PRG_HIP(hipGetLastError());
             PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             PRG_HIP(hipStreamSynchronize(st));
+            host[0] = reinterpret_cast<volatile int*>(L->pinned)[0];
+            host[1] = reinterpret_cast<volatile int*>(L->pinned)[1];
             if (host[1] == 0 && host[0] > decide_above) {
                 L->size = host[0];
                 if (getenv("PRG_DEBUG_LATTICE"))
@@ -944,16 +1119,32 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         }
         if (host[1] == 0) {
             embed(done, n);
+            // the resolve pass goes out right behind the embedding and tells the host the counters while it runs: no
+            // device-to-host copy, no stream synchronisation, the queue does not drain (on an overflow - rare - it has
+            // resolved garbage, which the retry overwrites)
+            const unsigned seq = ++L->mail_seq;
+            k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id, L->count,
+                                                                                 L->side_pending ? L->count2 : nullptr,
+                                                                                 L->mail_dev, seq);
             PRG_HIP(hipGetLastError());
-            PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-            if (L->side_pending)  // the speculative decision stage rides on the same synchronisation
-                PRG_HIP(hipMemcpyAsync(reinterpret_cast<int*>(L->pinned) + 4, L->count2, 2 * sizeof(int),
-                                       hipMemcpyDeviceToHost, st));
-            PRG_HIP(hipStreamSynchronize(st));
+            volatile LatticeMail* mb = L->mail;
+            for (uint64_t spins = 0; mb->seq != seq; ++spins) {
+                if ((spins & 0xFFFull) == 0xFFFull && hipStreamQuery(st) != hipErrorNotReady) {
+                    if (mb->seq == seq) break;
+                    PRG_HIP(hipStreamSynchronize(st));
+                    PRG_REQUIRE(mb->seq == seq, PRG_ERR_HIP, "permutohedral lattice: the vertex count never reached the host");
+                }
+                __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            host[0] = mb->size;
+            host[1] = mb->overflow;
+            L->count_clean = true;
             if (L->side_pending) {
-                L->side_size = reinterpret_cast<volatile int*>(L->pinned)[4];
-                L->side_overflow = reinterpret_cast<volatile int*>(L->pinned)[5];
+                L->side_size = mb->side_size;
+                L->side_overflow = mb->side_overflow;
                 L->side_pending = false;
+                L->count2_clean = true;
             }
         }
         L->size = host[0];
@@ -966,9 +1157,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
     }
     L->built = true;
     L->prev_size[mode] = L->size;
-    const unsigned long long mask = (unsigned long long)L->cap_used - 1;
-    k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id);
-    PRG_HIP(hipGetLastError());
+    const unsigned long long mask = (unsigned long long)L->cap_used - 1;  // (k_resolve is already in the queue)
     if (with_blur) {
         const int64_t need = 2 * (int64_t)d1 * L->size;
         if (need > L->nb_alloc) {
@@ -1011,7 +1200,8 @@ int lat_side_stage(Lattice* L, int64_t n, int d) {
     float sc[3];
     lat_scale(d, 1, sc);
     PRG_TRY(next_generation(L->tkeys2, L->cap2, &L->gen2, st));
-    PRG_HIP(hipMemsetAsync(L->count2, 0, 2 * sizeof(int), st));
+    if (!L->count2_clean) PRG_HIP(hipMemsetAsync(L->count2, 0, 2 * sizeof(int), st));
+    L->count2_clean = false;
     (void)sc;
     L->side_fuse = true;  // launched by the next lat_build on this lattice, together with its first sixteenth
     return PRG_OK;
@@ -1067,6 +1257,7 @@ int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
         const unsigned long long mask = (unsigned long long)capu - 1;
         PRG_HIP(hipMemsetAsync(L->tkeys, 0xFF, capu * sizeof(unsigned long long), st));
         PRG_HIP(hipMemsetAsync(L->count, 0, 2 * sizeof(int), st));
+        L->count_clean = false;
         k_embed_g<<<(unsigned)prg::ceil_div(n, kBlock), kBlock, 0, st>>>(L->feat, n, d, L->scale_dev, L->tkeys, mask, seed,
                                                                          L->pslot, L->bary, L->rem0s, L->rank8, L->count + 1);
         k_compact<<<(unsigned)prg::ceil_div(capu, kBlock), kBlock, 0, st>>>(L->tkeys, capu, L->slot_id, L->dkeys, L->count);
@@ -1084,7 +1275,7 @@ int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
             PRG_HIP(hipMalloc((void**)&L->gcheck, want * sizeof(unsigned long long)));
             L->g_alloc_size = want;
         }
-        k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id);
+        k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id, nullptr, nullptr, nullptr, 0u);
         PRG_HIP(hipMemsetAsync(L->gcheck, 0, (size_t)L->size * sizeof(unsigned long long), st));
         PRG_HIP(hipMemsetAsync(L->count + 1, 0, sizeof(int), st));  // now the collision flag
         k_store_keys_g<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n, d, L->rem0s, L->rank8, seed2,
@@ -1114,11 +1305,15 @@ int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
     return PRG_ERR_STATE;
 }
 
-// 1: order-preserving splat (the reference's float32 bits, reproducible), 0: atomic splats.  Process-wide; tools / tests
-// switch it through prg_lattice_set_splat_mode.
-static int g_splat_ordered = []() {
-    const char* e = getenv("PRG_SPLAT_ORDERED");
-    return e ? atoi(e) : 1;
+// How the splat accumulates (prg_lattice_set_splat_mode; process-wide):
+//   0  float atomics in arrival order (round-off level run-to-run noise; measurement baseline)
+//   1  fixed-point atomics (default): order-independent - the same bits in every run, each vertex the correctly rounded exact sum
+//   2  the reference's own order: every vertex one sequential float32 chain in point order - the reference's bits
+//      (permutohedral.cpp:491-500); costs a sort of the incidences per lattice and a strictly sequential chain per vertex
+static int g_splat_mode = []() {
+    const char* e = getenv("PRG_SPLAT_MODE");
+    const int m = e ? atoi(e) : 1;
+    return m < 0 || m > 2 ? 1 : m;
 }();
 
 // Sorted incidence lists of the current lattice for the points >= first (once per lattice build; every filter call on the
@@ -1183,24 +1378,69 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
     }
     float* a = L->vals;
     float* b = L->vals + plane;
-    if (g_splat_ordered && ch <= kSplatMaxCh) {
+    if (g_splat_mode == 2 && ch <= kSplatMaxCh) {
         PRG_TRY(lat_segments(L, first));
         const int* sinc = L->svals + L->seg_inc_cap;
-        const double avg = (double)((L->n - first) * d1) / (double)(L->size > 0 ? L->size : 1);
-        if (avg <= 12.0)
-            k_segsum<1><<<(unsigned)prg::ceil_div(L->size, kBlock), kBlock, 0, st>>>(L->seg, sinc, L->bary, in, d1, ch, L->size, a, b);
-        else if (avg <= 768.0)
-            k_segsum<8><<<(unsigned)prg::ceil_div(L->size, kBlock / 8), kBlock, 0, st>>>(L->seg, sinc, L->bary, in, d1, ch, L->size, a, b);
+        const int64_t n_inc = (L->n - first) * d1;
+        if (n_inc * ch > L->terms_elems) {
+            if (L->terms) (void)hipFree(L->terms);
+            L->terms = nullptr;
+            PRG_HIP(hipMalloc((void**)&L->terms, (size_t)n_inc * ch * sizeof(float)));
+            L->terms_elems = n_inc * ch;
+        }
+        const int64_t max_long = n_inc / (kLongSeg + 1) + 1;
+        if (max_long + 1 > L->long_cap) {
+            if (L->long_list) (void)hipFree(L->long_list);
+            L->long_list = nullptr;
+            PRG_HIP(hipMalloc((void**)&L->long_list, (size_t)(max_long + 1) * sizeof(int)));
+            L->long_cap = max_long + 1;
+        }
+        int* long_count = L->long_list + max_long;
+        k_seg_gather<<<(unsigned)prg::ceil_div(n_inc, kBlock), kBlock, 0, st>>>(sinc, L->bary, in, n_inc, d1, ch, L->terms, n_inc,
+                                                                               long_count);
+        k_segchain_thread<<<(unsigned)prg::ceil_div(L->size, kBlock), kBlock, 0, st>>>(L->seg, L->terms, n_inc, ch, L->size, a, b,
+                                                                                      L->long_list, long_count);
+        k_segchain_wave<<<(unsigned)prg::ceil_div(max_long, kBlock / 64), kBlock, 0, st>>>(L->seg, L->terms, n_inc, ch, L->size, a,
+                                                                                         L->long_list, long_count);
+    } else if (g_splat_mode >= 1) {
+        // fixed point: per-channel scale from the largest |value| (cached while the caller says the values have not changed)
+        if (!L->fx_scale) {
+            PRG_HIP(hipMalloc((void**)&L->fx_scale, (2 * 32 + 32) * sizeof(double)));
+            L->fx_scale_key = nullptr;
+        }
+        unsigned* maxabs = reinterpret_cast<unsigned*>(L->fx_scale + 64);
+        if (L->fx_scale_key != in || L->fx_scale_ch != ch || !L->fx_scale_static) {
+            PRG_HIP(hipMemsetAsync(maxabs, 0, 32 * sizeof(unsigned), st));
+            const int64_t total = (L->n - first) * ch;
+            const unsigned gm = (unsigned)std::min<int64_t>(prg::ceil_div(total, kBlock), 2048);
+            k_chan_maxabs<<<gm, kBlock, 0, st>>>(in, first, L->n, ch, maxabs);
+            k_chan_scale<<<1, 32, 0, st>>>(maxabs, ch, (double)(L->n - first), L->fx_scale);
+            L->fx_scale_key = in;
+            L->fx_scale_ch = ch;
+        }
+        if (plane > L->fx_elems) {
+            if (L->fx) (void)hipFree(L->fx);
+            L->fx = nullptr;
+            const int64_t want = plane + plane / 4 + 1024;
+            PRG_HIP(hipMalloc((void**)&L->fx, (size_t)want * sizeof(long long)));
+            PRG_HIP(hipMemsetAsync(L->fx, 0, (size_t)want * sizeof(long long), st));  // from here on k_fix_to_float keeps it zero
+            L->fx_elems = want;
+        }
+        if (ch <= kSplatMaxCh)
+            k_splat_lds<true><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
+                L->pslot, L->bary, in, first, L->n, d1, ch, a, L->fx, L->fx_scale);
         else
-            k_segsum<64><<<(unsigned)prg::ceil_div(L->size, kBlock / 64), kBlock, 0, st>>>(L->seg, sinc, L->bary, in, d1, ch, L->size, a, b);
+            k_splat<true><<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(
+                L->pslot, L->bary, in, first, L->n, d1, ch, a, L->fx, L->fx_scale);
+        k_fix_to_float<<<(unsigned)prg::ceil_div(plane, kBlock), kBlock, 0, st>>>(L->fx, plane, ch, L->fx_scale, a, b);
     } else {
         PRG_HIP(hipMemsetAsync(a, 0, 2 * plane * sizeof(float), st));
         if (ch <= kSplatMaxCh)
-            k_splat_lds<<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(L->pslot, L->bary, in, first,
-                                                                                            L->n, d1, ch, a);
+            k_splat_lds<false><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
+                L->pslot, L->bary, in, first, L->n, d1, ch, a, nullptr, nullptr);
         else
-            k_splat<<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, in,
-                                                                                            first, L->n, d1, ch, a);
+            k_splat<false><<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(
+                L->pslot, L->bary, in, first, L->n, d1, ch, a, nullptr, nullptr);
     }
     if (L->with_blur) {
         const int* nb1 = L->nb;
@@ -1516,6 +1756,8 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish_pt2pl(const double* __rest
         for (int j = 0; j < 3; ++j) state[3 * i + j] = rn[i][j];
     }
     state[13] = mom[27];  // q = r_sum
+    state[18] = mom[27];  // ... of the last iteration that had anything to fit (a later all-zero one overwrites [13] with NaN)
+    state[19] += 1.0;
     state[17] = state[12];
     state[15] = update_sigma2 ? mom[28] / (3.0 * mom[29]) : state[12];
     if (min_sigma2 >= 0.0) state[12] = fmax(state[15], min_sigma2);  // negative: do not advance (see k_fr_finish)
@@ -1618,6 +1860,8 @@ __global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__
         for (int j = 0; j < 3; ++j) state[3 * i + j] = rn[i][j];
     }
     state[13] = mom[23];
+    state[18] = mom[23];  // q of the last iteration that had anything to fit (a later all-zero one overwrites [13] with NaN)
+    state[19] += 1.0;     // ... and how many of those there were since prg_fr_set_state
     state[17] = state[12];                                               // sigma2 this step was computed with
     state[15] = update_sigma2 ? mom[24] / (3.0 * mom[25]) : state[12];  // :192-195 (3.0 hard-coded there)
     // self._sigma2 = max(res.sigma2, min_sigma2), :140 - for every legal min_sigma2 (0 included); a NEGATIVE value
@@ -1704,9 +1948,10 @@ __global__ __launch_bounds__(kBlock) void k_kabsch_finish(const double* __restri
 
 extern "C" {
 
-int prg_lattice_set_splat_mode(int ordered) {
-    PRG_REQUIRE(ordered == 0 || ordered == 1, PRG_ERR_INVALID, "prg_lattice_set_splat_mode: mode must be 0 (atomic) or 1 (ordered)");
-    g_splat_ordered = ordered;
+int prg_lattice_set_splat_mode(int mode) {
+    PRG_REQUIRE(mode >= 0 && mode <= 2, PRG_ERR_INVALID,
+                "prg_lattice_set_splat_mode: mode must be 0 (float atomics), 1 (fixed-point atomics) or 2 (reference order)");
+    g_splat_mode = mode;
     return PRG_OK;
 }
 
@@ -1794,6 +2039,7 @@ int prg_fr_create(prg_filterreg** out, int device, void* hip_stream) {
         return PRG_ERR_HIP;
     }
     (void)hipMemsetAsync(h->state, 0, 64 * sizeof(double), h->L.stream);
+    h->L.fx_scale_static = true;  // the plan's value array (target moments) only changes in fr_alloc
     *out = h;
     return PRG_OK;
 }
@@ -1816,6 +2062,7 @@ static int fr_alloc(prg_filterreg* h) {
     for (void* p : {(void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->part})
         if (p) (void)hipFree(p);
     h->ts = nullptr; h->vin = nullptr; h->vout = nullptr; h->part = nullptr;
+    h->L.fx_scale_key = nullptr;  // new values: the fixed-point scales are recomputed by the next filter call
     PRG_HIP(hipMalloc((void**)&h->ts, (size_t)h->M * 3 * sizeof(double)));
     PRG_HIP(hipMalloc((void**)&h->vin, (size_t)tot * 8 * sizeof(float)));
     PRG_HIP(hipMalloc((void**)&h->vout, (size_t)h->M * 8 * sizeof(float)));
@@ -1885,10 +2132,12 @@ int prg_fr_set_state(prg_filterreg* h, const double* rot9, const double* t3, dou
     PRG_REQUIRE(h && rot9 && t3, PRG_ERR_INVALID, "prg_fr_set_state: NULL argument");
     PRG_REQUIRE(sigma2 > 0.0, PRG_ERR_INVALID, "prg_fr_set_state: sigma2 must be > 0 (got %g)", sigma2);
     prg::DeviceGuard g(h->L.device);
-    double buf[13];
+    double buf[20];
     for (int i = 0; i < 9; ++i) buf[i] = rot9[i];
     for (int i = 0; i < 3; ++i) buf[9 + i] = t3[i];
     buf[12] = sigma2;
+    for (int i = 13; i < 20; ++i) buf[i] = 0.0;
+    buf[15] = sigma2;
     PRG_HIP(hipMemcpyAsync(h->state, buf, sizeof(buf), hipMemcpyHostToDevice, h->L.stream));
     PRG_HIP(hipStreamSynchronize(h->L.stream));
     h->last_blur = 1;  // a (re)started registration begins with a large sigma2: try the blurred lattice first
@@ -1952,8 +2201,23 @@ int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd)
     return PRG_OK;
 }
 
+static int fr_read_state(prg_filterreg* h, double* out_host, int count) {
+    prg::DeviceGuard g(h->L.device);
+    hipStream_t st = h->L.stream;
+    if (!h->L.pinned) PRG_HIP(hipHostMalloc((void**)&h->L.pinned, 64 * sizeof(double), hipHostMallocDefault));
+    PRG_HIP(hipMemcpyAsync(h->L.pinned, h->state, count * sizeof(double), hipMemcpyDeviceToHost, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    for (int i = 0; i < count; ++i) out_host[i] = h->L.pinned[i];
+    return PRG_OK;
+}
+
+int prg_fr_get_state(prg_filterreg* h, double* out_host) {
+    PRG_REQUIRE(h && out_host, PRG_ERR_INVALID, "prg_fr_get_state: NULL argument");
+    return fr_read_state(h, out_host, 20);
+}
+
 int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host) {
-    PRG_REQUIRE(h && h->have_estep && out_host, PRG_ERR_STATE, "prg_fr_mstep: run prg_fr_estep first");
+    PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_fr_mstep: run prg_fr_estep first");
     PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep: w must be in [0, 1) (got %g)", w);
     prg::DeviceGuard g(h->L.device);
     hipStream_t st = h->L.stream;
@@ -1962,11 +2226,7 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma
     k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, wfac, h->state, h->part);
     k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
-    if (!h->L.pinned) PRG_HIP(hipHostMalloc((void**)&h->L.pinned, 64 * sizeof(double), hipHostMallocDefault));
-    PRG_HIP(hipMemcpyAsync(h->L.pinned, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
-    PRG_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < 18; ++i) out_host[i] = h->L.pinned[i];
-    return PRG_OK;
+    return out_host ? fr_read_state(h, out_host, 18) : PRG_OK;  // NULL: nothing is read back, the stream keeps running
 }
 
 int prg_fr_set_target_normals(prg_filterreg* h, const double* normals_hd) {
@@ -2002,7 +2262,7 @@ int prg_fr_get_nx(prg_filterreg* h, float* nx_hd) {
 }
 
 int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host) {
-    PRG_REQUIRE(h && h->have_estep && out_host, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: run prg_fr_estep first");
+    PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: run prg_fr_estep first");
     PRG_REQUIRE(h->ch == 8, PRG_ERR_STATE, "prg_fr_mstep_pt2pl: target normals have not been set");
     PRG_REQUIRE(w >= 0.0 && w < 1.0, PRG_ERR_INVALID, "prg_fr_mstep_pt2pl: w must be in [0, 1) (got %g)", w);
     prg::DeviceGuard g(h->L.device);
@@ -2012,11 +2272,7 @@ int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min
     k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, wfac, h->state, h->part);
     k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>(h->part, nblk, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
-    if (!h->L.pinned) PRG_HIP(hipHostMalloc((void**)&h->L.pinned, 64 * sizeof(double), hipHostMallocDefault));
-    PRG_HIP(hipMemcpyAsync(h->L.pinned, h->state, 18 * sizeof(double), hipMemcpyDeviceToHost, st));
-    PRG_HIP(hipStreamSynchronize(st));
-    for (int i = 0; i < 18; ++i) out_host[i] = h->L.pinned[i];
-    return PRG_OK;
+    return out_host ? fr_read_state(h, out_host, 18) : PRG_OK;
 }
 
 // RigidFilterReg._maximization_step on explicit arrays (filterreg.py:158-196) - same kernels as prg_fr_mstep /

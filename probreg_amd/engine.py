@@ -76,6 +76,12 @@ class CpdPlan(object):
         check(lib.prg_cpd_last_estep_engine(self._h, ctypes.byref(e)))
         return int(e.value)
 
+    def last_estep_engines(self):
+        """(column pass, row pass) of the last E-step: 1 = matrix cores, 0 = vector-pipe sweeps."""
+        c, r = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib.prg_cpd_last_estep_engines(self._h, ctypes.byref(c), ctypes.byref(r)))
+        return int(c.value), int(r.value)
+
     def set_source(self, source):
         a = self._f32(source)
         self.m, self.dim = int(a.shape[0]), int(a.shape[1])

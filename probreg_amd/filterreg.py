@@ -95,11 +95,21 @@ class _Plan(object):
         check(lib.prg_fr_get_nx(self._h, ptr(nx)))
         return nx
 
-    def mstep(self, w, update_sigma2, objective_type="pt2pt", min_sigma2=-1.0):
-        """``min_sigma2`` >= 0 advances the device sigma2 like the driver (filterreg.py:140); negative leaves it alone."""
-        out = np.zeros(18)
+    def mstep(self, w, update_sigma2, objective_type="pt2pt", min_sigma2=-1.0, read=True):
+        """``min_sigma2`` >= 0 advances the device sigma2 like the driver (filterreg.py:140); negative leaves it alone.
+        ``read=False`` only enqueues the M-step (no read-back, the host does not wait) and returns None."""
         fn = lib.prg_fr_mstep_pt2pl if objective_type == "pt2pl" else lib.prg_fr_mstep
+        if not read:
+            check(fn(self._h, float(w), 1 if update_sigma2 else 0, float(min_sigma2), None))
+            return None
+        out = np.zeros(18)
         check(fn(self._h, float(w), 1 if update_sigma2 else 0, float(min_sigma2), ptr(out)))
+        return out
+
+    def get_state(self):
+        """The 20-double device state (prg_fr_get_state); synchronises."""
+        out = np.zeros(20)
+        check(lib.prg_fr_get_state(self._h, ptr(out)))
         return out
 
     def close(self):
@@ -237,6 +247,25 @@ class FilterReg(abc.ABC):
         scale0 = float(getattr(self._tf_result, "scale", 1.0))
         if scale0 != 1.0:
             plan.set_source(self._source * scale0)
+        # Nobody looks at the intermediate results (no callbacks, no tolerance to test, no DEBUG log): the iterations are
+        # only enqueued - one lattice-size hand-over per E-step, nothing read back - and the state is fetched once at the
+        # end.  An iteration in which every m0 is zero leaves the device state alone (filterreg.py:136-138 would stop there;
+        # the iterations after it repeat it and change nothing either).
+        if not self._callbacks and tol < 0 and not log.isEnabledFor(10) and scale0 == 1.0 and maxiter > 0:
+            for i in range(maxiter):
+                plan.estep()
+                plan.mstep(w, self._update_sigma2, objective_type, min_sigma2, read=False)
+            out = plan.get_state()
+            if out[19] > 0.0:
+                rot = out[:9].reshape(3, 3)[:dim, :dim].copy()
+                res = MstepResult(tf.RigidTransformation(rot, out[9:9 + dim].copy()), float(out[15]), float(out[18]))
+                self._tf_result = res.transformation
+                self._sigma2 = max(res.sigma2, min_sigma2)
+                if out[16] == 0.0:  # the last iterations had nothing to fit: the driver's answer at that point
+                    res = MstepResult(self._tf_result, self._sigma2, res.q)
+            else:
+                res = MstepResult(self._tf_result, self._sigma2, None)
+            return res
         for i in range(maxiter):
             if i == 1 and scale0 != 1.0:
                 plan.set_source(self._source)

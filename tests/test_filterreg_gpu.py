@@ -18,37 +18,45 @@ def fr_golden():
     return Golden(os.path.join(GOLDEN_DIR, "filterreg_golden.npz"))
 
 
+class _splat_mode(object):
+    """prg_lattice_set_splat_mode for the duration of a ``with`` block (1, fixed-point atomics, is the default)."""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        from probreg_amd import _lib
+
+        _lib.check(_lib.lib.prg_lattice_set_splat_mode(self.mode))
+
+    def __exit__(self, *exc):
+        from probreg_amd import _lib
+
+        _lib.check(_lib.lib.prg_lattice_set_splat_mode(1))
+
+
 def test_lattice_vs_reference_vectors(fr_golden):
-    """Same simplices and weights as the vendored lattice and - with the order-preserving splat, the default - the same
-    float32 sums in the same order: vertex count identical, filter outputs BIT-IDENTICAL to the reference's
-    (permutohedral.cpp:482-616)."""
+    """Same simplices and weights as the vendored lattice: vertex count identical; with the splat in the reference's own
+    order (mode 2) the filter outputs are BIT-IDENTICAL to the reference's (permutohedral.cpp:482-616); the default
+    (order-independent fixed-point sums) and the float atomics agree with it up to the reference's own float32 round-off."""
     from probreg_amd import gaussian_filtering as gf
 
-    for name in fr_golden.group("lattice"):
-        c = fr_golden.case("lattice/" + name)
-        lat = gf.Permutohedral(c["points"], "blur1" in name)
-        assert lat.get_lattice_size() == c["size"], name
-        for ch in (1, 3, 5):
-            got = lat.filter(c["values_ch%d" % ch])
-            want = c["out_ch%d" % ch]
-            assert got.shape == want.shape
-            assert np.array_equal(got, want), (name, ch, float(np.max(np.abs(got - want))))
-
-
-def test_atomic_splat_mode_stays_within_round_off(fr_golden):
-    """prg_lattice_set_splat_mode(0): float atomics in arrival order - the reference's values up to the summation order."""
-    from probreg_amd import _lib, gaussian_filtering as gf
-
-    _lib.check(_lib.lib.prg_lattice_set_splat_mode(0))
-    try:
-        for name in fr_golden.group("lattice"):
-            c = fr_golden.case("lattice/" + name)
-            lat = gf.Permutohedral(c["points"], "blur1" in name)
-            for ch in (1, 3, 5):
-                got, want = lat.filter(c["values_ch%d" % ch]), c["out_ch%d" % ch]
-                assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)), (name, ch)
-    finally:
-        _lib.check(_lib.lib.prg_lattice_set_splat_mode(1))
+    for mode in (2, 1, 0):
+        with _splat_mode(mode):
+            for name in fr_golden.group("lattice"):
+                c = fr_golden.case("lattice/" + name)
+                lat = gf.Permutohedral(c["points"], "blur1" in name)
+                assert lat.get_lattice_size() == c["size"], name
+                for ch in (1, 3, 5):
+                    got = lat.filter(c["values_ch%d" % ch])
+                    want = c["out_ch%d" % ch]
+                    assert got.shape == want.shape
+                    if mode == 2:
+                        assert np.array_equal(got, want), (name, ch, float(np.max(np.abs(got - want))))
+                    else:
+                        assert np.max(np.abs(got - want)) <= 2e-5 * np.max(np.abs(want)), (mode, name, ch)
+                    if mode >= 1:  # reproducible to the bit
+                        assert np.array_equal(lat.filter(c["values_ch%d" % ch]), got), (mode, name, ch)
 
 
 @pytest.mark.parametrize("n,d,scale,blur", [(200000, 3, 0.3, True), (200000, 3, 12.0, True), (150000, 3, 150.0, False),
@@ -68,9 +76,28 @@ def test_ordered_splat_bit_exact_over_chain_lengths(n, d, scale, blur):
     assert lat.get_lattice_size() == want_lat.lattice_size
     for ch in (1, 3, 5):
         want = want_lat.filter(vals[:, :ch])
-        got = lat.filter(vals[:, :ch])
-        assert np.array_equal(got, want), (ch, float(np.max(np.abs(got - want))))
-        assert np.array_equal(lat.filter(vals[:, :ch]), got)
+        with _splat_mode(2):
+            got = lat.filter(vals[:, :ch])
+            assert np.array_equal(got, want), (ch, float(np.max(np.abs(got - want))))
+            assert np.array_equal(lat.filter(vals[:, :ch]), got)
+        fixed = lat.filter(vals[:, :ch])  # default mode: exact sums - within the float32 chain's own round-off of it
+        assert np.array_equal(lat.filter(vals[:, :ch]), fixed)
+        assert np.max(np.abs(fixed - want)) <= 1e-4 * np.max(np.abs(want)), ch
+
+
+def test_fixed_point_splat_scales_follow_the_values():
+    """The fixed-point scale is taken from the largest |value| per channel: tiny and huge channels next to each other."""
+    from oracle import permutohedral as po
+    from probreg_amd import gaussian_filtering as gf
+
+    rng = np.random.default_rng(5)
+    pts = (rng.uniform(0.0, 1.0, (30000, 3)) * 6.0).astype(np.float32)
+    vals = rng.normal(size=(30000, 4)).astype(np.float32) * np.array([1e-12, 1.0, 1e9, 0.0], dtype=np.float32)
+    want = po.Lattice(pts, True).filter(vals)
+    got = gf.Permutohedral(pts, True).filter(vals)
+    for k in range(3):
+        assert np.max(np.abs(got[:, k] - want[:, k])) <= 2e-5 * np.max(np.abs(want[:, k])), k
+    assert not np.any(got[:, 3])
 
 
 def test_reference_unit_test_gaussian_filtering():
@@ -98,7 +125,11 @@ def test_estep_vs_oracle():
         got = filterreg.RigidFilterReg(src).expectation_step(src, tgt, tgt, sigma2, True)
         for a, b in ((got.m0, want.m0), (got.m1, want.m1), (got.m2, want.m2)):
             assert a.dtype == np.float32
-            assert np.array_equal(a, b), (sigma2, float(np.max(np.abs(a - b))))  # ordered splat: the reference's bits
+            assert np.max(np.abs(a - b)) <= 3e-5 * np.max(np.abs(b)), sigma2
+        with _splat_mode(2):  # the splat in the reference's order: the reference's bits
+            exact = filterreg.RigidFilterReg(src).expectation_step(src, tgt, tgt, sigma2, True)
+        for a, b in ((exact.m0, want.m0), (exact.m1, want.m1), (exact.m2, want.m2)):
+            assert np.array_equal(a, b), (sigma2, float(np.max(np.abs(a - b))))
 
 
 def _kwargs(c):
@@ -188,6 +219,27 @@ def test_config_c4_size_smoke_properties():
     rot = res.transformation.rot
     assert np.allclose(rot @ rot.T, np.eye(3), atol=1e-9) and abs(np.linalg.det(rot) - 1.0) < 1e-9
     assert np.max(np.abs(rot - r)) < 0.05
+
+
+def test_enqueue_only_driver_equals_the_read_back_driver():
+    """With nothing to look at between the iterations (tol < 0, no callbacks) the driver only enqueues them and reads the
+    state once; a callback forces the per-iteration read-back.  Same kernels, same order: the same bits (the default splat
+    is order independent)."""
+    from probreg_amd import filterreg, synthetic
+
+    src, tgt, _ = synthetic.filterreg_pair(20000, m=15000, seed=3)
+    kw = dict(sigma2=None, update_sigma2=True, w=0.05, maxiter=12, tol=-1.0)
+    a = filterreg.registration_filterreg(src, tgt, **kw)
+    seen = []
+    b = filterreg.registration_filterreg(src, tgt, callbacks=[lambda tr: seen.append(tr)], **kw)
+    assert len(seen) == 12
+    assert np.array_equal(a.transformation.rot, b.transformation.rot) and np.array_equal(a.transformation.t, b.transformation.t)
+    assert a.sigma2 == b.sigma2 and a.q == b.q
+    # nothing to fit at all (every m0 zero from the first iteration): the initial transformation, q = None - either way
+    far = tgt + 1.0e4
+    for cb in ([], [lambda tr: None]):
+        r = filterreg.registration_filterreg(src, far, sigma2=1e-4, maxiter=3, tol=-1.0, callbacks=cb)
+        assert r.q is None and np.array_equal(r.transformation.rot, np.identity(3)) and r.sigma2 == 1e-4
 
 
 def test_unsupported_paths_raise():
