@@ -46,6 +46,8 @@ F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64
 # The same count is charged to the dense-regime iterations that take the exponent (8 of the 21 / 14 flop) from the bf16
 # matrix pipe instead (csrc/cpd_sweeps_mfma.hip): `frac` is useful pair-flops per second over the fp32 vector peak.
 FLOP_ROW, FLOP_COL = 21.0, 14.0
+# SURVEY.md 8(d)'s own count for the two-sweep fused form (scale as a separate multiplication, no min tracking): 20 / 11
+FLOP_ROW_SURVEY, FLOP_COL_SURVEY = 20.0, 11.0
 
 WORKLOADS = {
     # name: (kind, N = M, description)
@@ -196,7 +198,7 @@ def _base(metric, value, elapsed, steps, warmup, desc, dtype, world=1):
 # ----------------------------------------------------------------------------------------------------------------
 # C1 / C2: rigid / affine CPD
 # ----------------------------------------------------------------------------------------------------------------
-def bench_cpd(workload, steps, warmup, tuning=""):
+def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     import torch
     from probreg_amd import _lib, cpd, synthetic
 
@@ -259,9 +261,13 @@ def bench_cpd(workload, steps, warmup, tuning=""):
     acc, first, last = {}, None, None
     pairs_row = pairs_col = 0.0
     first_pairs = last_pairs = None
-    for _ in range(steps):
+    per_iteration = []
+    for it in range(steps):
+        s2_it = float(plan.get_params()[13])
         ms = plan.estep_timed(0.0)
         pc, pr = plan.pair_counts()
+        ce, re_ = plan.last_estep_engines()
+        per_iteration.append((it, s2_it, ce, re_, pc, pr, ms["colpass"], ms["rowpass"], ms["total"]))
         reg._all_reduce_moments(plan)
         plan.mstep(kind_id, True)
         if first is None:
@@ -273,6 +279,24 @@ def bench_cpd(workload, steps, warmup, tuning=""):
             acc[k] = acc.get(k, 0.0) + v / steps
     if rank != 0:
         return None
+    if pairs_log:  # what `roofline.frac` is made of, iteration by iteration (tools/profile_round.sh commits it)
+        with open(pairs_log, "w") as f:
+            f.write("# %s: E-step sweeps of the timed window, HIP events on the plan's stream (prg_cpd_estep_timed) and the device's "
+                    "counters of evaluated pairs (prg_cpd_pair_counts)\n" % desc)
+            f.write("# engine 1 = matrix cores (bf16x3 exponent, csrc/cpd_sweeps_mfma.hip), 0 = culled vector-pipe sweeps; "
+                    "frac = pairs x flop/pair / ms / %.1f TFLOP/s (flop/pair: row %g, column %g)\n"
+                    % (VALU_F32_PEAK_TFLOPS, FLOP_ROW, FLOP_COL))
+            f.write("%3s %12s %4s %4s %14s %14s %9s %9s %9s %8s %8s\n" % ("it", "sigma2", "col", "row", "pairs_col", "pairs_row",
+                                                                       "ms_col", "ms_row", "ms_estep", "frac_col", "frac_row"))
+            for (it, s2_it, ce, re_, pc, pr, mc, mr, mt) in per_iteration:
+                f.write("%3d %12.5e %4d %4d %14.0f %14.0f %9.4f %9.4f %9.4f %8.3f %8.3f\n" % (
+                    it, s2_it, ce, re_, pc, pr, mc, mr, mt, pc * FLOP_COL / (mc * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
+                    pr * FLOP_ROW / (mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
+            tot_r = sum(r[5] for r in per_iteration)
+            tot_mr = sum(r[7] for r in per_iteration)
+            f.write("# window: row pass %.6e pairs in %.4f ms -> %.2f TFLOP/s = frac %.4f\n" % (
+                tot_r, tot_mr, tot_r * FLOP_ROW / (tot_mr * 1e-3) / 1e12,
+                tot_r * FLOP_ROW / (tot_mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
 
     m_pts, n_loc = plan.m, plan.n
     row_s_total, col_s_total = acc["rowpass"] * 1e-3 * steps, acc["colpass"] * 1e-3 * steps
@@ -302,8 +326,17 @@ def bench_cpd(workload, steps, warmup, tuning=""):
         "unit": "TFLOP/s",
         "frac": row_tf / VALU_F32_PEAK_TFLOPS,
         "traffic": _pmc_traffic(workload, "rowpass_hbm_bytes_per_launch"),
+        "traffic_source": "profiles/pmc_traffic.json - STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                          "tools/profile_round.sh, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; not measured in this run",
         "how": "flop = pairs the kernel evaluated (per-workgroup device counters, prg_cpd_pair_counts) x %g flop/pair; "
                "time = HIP events on the plan's stream; both summed over the %d timed-window iterations" % (FLOP_ROW, steps),
+        "flop_per_pair": {"isa_count": {"row": FLOP_ROW, "col": FLOP_COL}, "survey_8d": {"row": FLOP_ROW_SURVEY, "col": FLOP_COL_SURVEY},
+                          "note": "the matrix-core engine takes 8 of these flop per pair (the exponent) from the bf16 matrix "
+                                  "pipe; frac charges them all to the fp32 vector peak = useful pair-flops per second"},
+        "frac_with_survey_flops": row_tf * FLOP_ROW_SURVEY / FLOP_ROW / VALU_F32_PEAK_TFLOPS,
+        "matrix_core_share": {"column_pass_iterations": sum(1 for r in per_iteration if r[2]) / float(steps),
+                              "row_pass_iterations": sum(1 for r in per_iteration if r[3]) / float(steps),
+                              "row_pass_pairs": sum(r[5] for r in per_iteration if r[3]) / max(pairs_row, 1.0)},
         "avg_launch_ms": acc["rowpass"],
         "pairs_evaluated_per_launch": pairs_row / steps,
         "pairs_total_per_launch": float(m_pts) * n_loc,
@@ -532,6 +565,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline and the parity block")
     ap.add_argument("--no-other-workloads", action="store_true", help="C1 only (skip the C2 / C3 / C4 entries)")
     ap.add_argument("--tuning", default="", help="r_col,seg_col,r_row,seg_row (0 = auto)")
+    ap.add_argument("--pairs-log", default="", help="write the per-iteration (engine, pairs, ms) table of the timed window here")
     ap.add_argument("--no-dense-compare", action="store_true",
                     help="non-rigid: skip the M-step through the dense fallback (profiles of the product path alone)")
     args = ap.parse_args()
@@ -569,7 +603,7 @@ def main():
             out = {"filterreg": bench_filterreg, "bcpd": bench_bcpd}[kind](args.workload, args.steps, args.warmup)
         print(json.dumps(out))
         return
-    out = bench_cpd(args.workload, args.steps, args.warmup, args.tuning)
+    out = bench_cpd(args.workload, args.steps, args.warmup, args.tuning, args.pairs_log or None)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline_and_parity(n)

@@ -89,6 +89,12 @@ int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
  * E-step's column pass used (1 = matrix cores). */
 int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound);
 int prg_cpd_last_estep_engine(prg_cpd* h, int* engine);
+/* Sparse regime (sigma2 small: most 128 x 32 blocks of P are exact zeros): 1 (default) - with M and the local N both >= 32768
+ * the vector-pipe sweeps run over a device-built work queue (need-masks -> units -> persistent waves,
+ * csrc/cpd_sweeps_queue.hip), smaller problems on the grid; 2 - the queue always; 0 - always one wave per (128-point block,
+ * 512-point segment) whether it finds work or not (the culled sweeps of csrc/cpd_sweeps_packed.hip).  Same pairs, same
+ * arithmetic, exact either way; tests / measurements. */
+int prg_cpd_set_sparse_engine(prg_cpd* h, int mode);
 /* ... and for both sweeps of the last E-step: 1 = matrix cores, 0 = vector pipe (column pass, row pass). */
 int prg_cpd_last_estep_engines(prg_cpd* h, int* col_engine, int* row_engine);
 

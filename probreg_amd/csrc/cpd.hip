@@ -253,6 +253,29 @@ __global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict_
 
 // (the two pair sweeps live in cpd_sweeps_packed.hip / cpd_sweeps_scalar.hip / cpd_sweeps_mfma.hip)
 
+// Consumers of a sweep over the work queue (cpd_sweeps_queue.hip): the partial results of a block of 128 owned points sit
+// in the slots of its units; chunk[b][c] = (first slot, units) for every chunk of 32 stream segments.  Walking the chunks
+// and their units in order gives every block a fixed summation order, wherever the atomics placed the units.
+constexpr int kQueueEnt = 8;  // chunk-table entries a consumer thread fetches at once (C1 has 7 chunks per block)
+struct QueueView {
+    const int2* chunk;  // null: the sweep did not run over the queue
+    int nchunk;
+    int* ctrl;          // reset for the next E-step by the consumer's first thread
+    int pop_start, cap_soft;
+};
+__device__ __forceinline__ void queue_reset(const QueueView& q) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const int fine = q.ctrl[0] < q.cap_soft ? q.ctrl[0] : q.cap_soft;
+        q.ctrl[8] = fine;                   // fine / coarse units of this sweep (prg_cpd_pair_counts)
+        q.ctrl[9] = q.ctrl[7];
+        q.ctrl[2] = q.ctrl[0];              // the next build sizes its units from this sweep's count ...
+        q.ctrl[3] = q.ctrl[6];              // ... and unit size
+        q.ctrl[0] = 0;                      // it appends from slot 0 ...
+        q.ctrl[7] = 0;
+        q.ctrl[1] = q.pop_start;            // ... and its waves take the first `pop_start` units without asking
+    }
+}
+
 // Merge the S partial (min, sum) pairs of each column in fp64; apply cpd.py:78-82:
 //   den == 0 -> eps32 (then the whole column of P is 0/eps = 0), den += c.
 // Writes b_n = -log2(den_n) into tgt4[n].w so that P_mn = exp2(kk d2 + b_n), and pt1_n = den/(den+c).
@@ -261,8 +284,9 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
                                                      const double* __restrict__ params, double w, double m_over_n,
                                                      int dim, float* __restrict__ colmin, float* __restrict__ colmin_g,
                                                      float* __restrict__ gmeta, int seed_mode,
-                                                     unsigned* __restrict__ stat, int slot) {
+                                                     unsigned* __restrict__ stat, int slot, const QueueView qv) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (qv.chunk) queue_reset(qv);
     float b = 0.f;  // pads keep b = 0
     float cmin = 0.f;  // pads do not widen the seed
     if (i < n) {
@@ -284,6 +308,46 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
             gmin = fminf(gmin, p.x);
             ssum += (double)p.y;
         }
+    } else if (qv.chunk) {
+        // the slots of the column's block of 128, [unit][128] (min, sum) pairs, chunk by chunk, unit by unit
+        const int2* __restrict__ cb = qv.chunk + (i >> 7) * qv.nchunk;
+        auto add_chunk = [&](const int2 e) {
+            const float2* __restrict__ o = colpart + (int64_t)e.x * 128 + (i & 127);
+            for (int j = 0; j < e.y; j += 4) {
+                float2 p[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[k] = (j + k < e.y) ? o[(int64_t)(j + k) * 128] : make_float2(INFINITY, 0.f);
+                const float cm = fminf(fminf(p[0].x, p[1].x), fminf(p[2].x, p[3].x));
+                if (cm < gmin) {
+                    const float noff = prg::col_offset(kkf, cm);
+                    ssum *= (double)__builtin_amdgcn_exp2f(noff - goff);
+                    gmin = cm;
+                    goff = noff;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (p[k].y != 0.f) ssum += (double)(p[k].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, p[k].x)));
+            }
+        };
+        int2 ent[kQueueEnt];  // (the table entries go out together, then the first unit of every chunk, then the rest)
+#pragma unroll
+        for (int c = 0; c < kQueueEnt; ++c) ent[c] = c < qv.nchunk ? cb[c] : make_int2(0, 0);
+        float2 f0[kQueueEnt];
+#pragma unroll
+        for (int c = 0; c < kQueueEnt; ++c)
+            f0[c] = ent[c].y > 0 ? colpart[(int64_t)ent[c].x * 128 + (i & 127)] : make_float2(INFINITY, 0.f);
+#pragma unroll
+        for (int c = 0; c < kQueueEnt; ++c) {
+            if (f0[c].x < gmin) {
+                const float noff = prg::col_offset(kkf, f0[c].x);
+                ssum *= (double)__builtin_amdgcn_exp2f(noff - goff);
+                gmin = f0[c].x;
+                goff = noff;
+            }
+            if (f0[c].y != 0.f) ssum += (double)(f0[c].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, f0[c].x)));
+            if (ent[c].y > 1) add_chunk(make_int2(ent[c].x + 1, ent[c].y - 1));
+        }
+        for (int c = kQueueEnt; c < qv.nchunk; ++c) add_chunk(cb[c]);
     } else
     for (int s0 = 0; s0 < nseg; s0 += 8) {
         float2 p[8];
@@ -379,17 +443,59 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
                                                         const float4* __restrict__ z4, double* __restrict__ rowacc,
                                                         double* __restrict__ mompart,
                                                         const unsigned char* __restrict__ rowflag,
-                                                        const float4* __restrict__ rorig) {
+                                                        const float4* __restrict__ rorig, const QueueView qv) {
+    if (qv.chunk) queue_reset(qv);
     double a[kMomComp];
 #pragma unroll
     for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
     // grid-stride over the rows: few workgroups -> few partials for the single-block final reduction
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double p1 = 0, u[3] = {0, 0, 0}, e = 0;
+        if (qv.chunk) {
+            // the slots of the row's block of 128, [unit][5][128], chunk by chunk, unit by unit, two units in flight
+            const int2* __restrict__ cb = qv.chunk + (i >> 7) * qv.nchunk;
+            // The FIRST unit of every chunk is fetched before anything is added (one memory round trip for all of them - in
+            // the sparse regime most chunks hold zero to two units); the rest of a chunk's units follow two at a time.  The
+            // order of the additions is chunk by chunk, unit by unit either way.
+            int2 ent[kQueueEnt];
+#pragma unroll
+            for (int c = 0; c < kQueueEnt; ++c) ent[c] = c < qv.nchunk ? cb[c] : make_int2(0, 0);
+            float f0[kQueueEnt][5];
+#pragma unroll
+            for (int c = 0; c < kQueueEnt; ++c) {
+                const float* __restrict__ o = rowpart + (int64_t)ent[c].x * 640 + (i & 127);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) f0[c][k] = ent[c].y > 0 ? o[128 * k] : 0.f;
+            }
+            auto add_rest = [&](const int2 en, int from) {
+                const float* __restrict__ o = rowpart + ((int64_t)en.x + from) * 640 + (i & 127);
+                for (int q = from; q < en.y; q += 2, o += 1280) {
+                    const bool two = q + 1 < en.y;
+                    const float v0 = o[0], v1 = o[128], v2 = o[256], v3 = o[384], v4 = o[512];
+                    const float w0 = two ? o[640] : 0.f, w1 = two ? o[768] : 0.f, w2 = two ? o[896] : 0.f,
+                                w3 = two ? o[1024] : 0.f, w4 = two ? o[1152] : 0.f;
+                    p1 += (double)v0 + (double)w0;
+                    u[0] += (double)v1 + (double)w1;
+                    u[1] += (double)v2 + (double)w2;
+                    u[2] += (double)v3 + (double)w3;
+                    e += (double)v4 + (double)w4;
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < kQueueEnt; ++c) {
+                p1 += (double)f0[c][0];
+                u[0] += (double)f0[c][1];
+                u[1] += (double)f0[c][2];
+                u[2] += (double)f0[c][3];
+                e += (double)f0[c][4];
+                if (ent[c].y > 1) add_rest(ent[c], 1);
+            }
+            for (int c = kQueueEnt; c < qv.nchunk; ++c) add_rest(cb[c], 0);
+        }
         // (128-row wave block, segment) partials the culled row pass never touched are absent (neither written nor
         // read): the wave fetches its block's 64 flag bytes once and walks the set bits (<= 64 planes)
-        uint64_t live = nseg >= 64 ? ~0ull : ((1ull << nseg) - 1ull);
-        if (rowflag) {
+        uint64_t live = qv.chunk ? 0ull : (nseg >= 64 ? ~0ull : ((1ull << nseg) - 1ull));
+        if (rowflag && !qv.chunk) {
             const int wb = __builtin_amdgcn_readfirstlane((int)(i >> 7));
             const uint4* __restrict__ f = reinterpret_cast<const uint4*>(rowflag + (int64_t)wb * 64);
             uint64_t bits = 0;
@@ -695,7 +801,25 @@ int auto_segments(int64_t nblk_x, int64_t stream_len, int quantum, int cap) {
     return (int)prg::ceil_div(stream_len, seg);
 }
 
+static QueueView queue_view(const SweepQueue& q, bool active) {
+    QueueView v;
+    v.chunk = active ? q.chunk : nullptr;
+    v.nchunk = q.nchunk;
+    v.ctrl = q.ctrl;
+    v.pop_start = prg::kQueueWorkgroups * (prg::kSweepBlock / 64);
+    v.cap_soft = q.cap_soft;
+    return v;
+}
+
+static void free_queue(SweepQueue& q) {
+    for (void* p : {(void*)q.masks, (void*)q.chunk, (void*)q.units, (void*)q.ctrl, (void*)q.ucount})
+        if (p) (void)hipFree(p);
+    q = SweepQueue();
+}
+
 int free_plan_buffers(prg_cpd* h) {
+    free_queue(h->qcol);
+    free_queue(h->qrow);
     if (h->src4) (void)hipFree(h->src4);
     if (h->z4) (void)hipFree(h->z4);
     if (h->tgt4) (void)hipFree(h->tgt4);
@@ -824,6 +948,7 @@ int prg_cpd_create(prg_cpd** out, int device, void* hip_stream) {
     h->device = device;
     h->stream = (hipStream_t)hip_stream;
     if (const char* eng = getenv("PRG_DENSE_ENGINE")) h->dense_engine = std::max(0, std::min(2, atoi(eng)));  // experiments
+    if (const char* eng = getenv("PRG_SPARSE_ENGINE")) h->sparse_engine = std::max(0, std::min(2, atoi(eng)));
     hipError_t e = hipMalloc((void**)&h->state, (PRG_NMOMENTS + PRG_NPARAMS) * sizeof(double));
     if (e != hipSuccess) {
         delete h;
@@ -1037,6 +1162,13 @@ int prg_cpd_last_estep_engine(prg_cpd* h, int* engine) {
     return PRG_OK;
 }
 
+int prg_cpd_set_sparse_engine(prg_cpd* h, int mode) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_sparse_engine: NULL handle");
+    PRG_REQUIRE(mode >= 0 && mode <= 2, PRG_ERR_INVALID, "prg_cpd_set_sparse_engine: mode must be 0 (grid of culled waves), 1 (work queue for large clouds) or 2 (work queue always)");
+    h->sparse_engine = mode;
+    return PRG_OK;
+}
+
 int prg_cpd_last_estep_engines(prg_cpd* h, int* col_engine, int* row_engine) {
     PRG_REQUIRE(h && col_engine && row_engine, PRG_ERR_INVALID, "prg_cpd_last_estep_engines: NULL argument");
     *col_engine = h->last_estep_mfma ? 1 : 0;
@@ -1138,9 +1270,17 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     static const int mfma_seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;  // 0: fill the chip once
     const int PAm = mfma_possible ? prg::mfma_planes(h->N, h->M, mfma_seg) : 0,
               PBm = mfma_possible ? prg::mfma_planes(h->M, h->N, mfma_seg) : 0;
-    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, (int64_t)std::max(PA, PAm) * h->Ncap));
-    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems, (int64_t)std::max(PB, PBm) * 5 * h->Mcap + (h->Mcap >> 7) * 16));  // + touched flags: 64 bytes per 128 rows
+    // sparse regime: sweeps over a device-built work queue (cpd_sweeps_queue.hip) - partial results per unit, not per plane
+    // ... when both clouds are large: the queue costs a build pass and leaves more partial results than the grid of culled
+    // waves, which only pays off while a sweep is long (measured at C1: ahead with the target on 1 or 2 ranks, behind on 4 and 8)
+    const bool use_queue = use_cull && (h->sparse_engine == 2 || (h->sparse_engine == 1 && h->M >= 32768 && h->N >= 32768));
+    const int64_t qcol_elems = use_queue ? prg::queue_max_units(h->N, h->M) * 128 : 0,
+                  qrow_elems = use_queue ? prg::queue_max_units(h->M, h->N) * 640 : 0;
+    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems)));
+    PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems,
+                          std::max<int64_t>((int64_t)std::max(PB, PBm) * 5 * h->Mcap + (h->Mcap >> 7) * 16, qrow_elems)));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
+    if (use_queue) PRG_TRY(prg::prepare_queues(h));
     if (use_cull) {  // per-workgroup counters of evaluated (wave, group) blocks (prg_cpd_pair_counts)
         const int64_t need = std::max<int64_t>(
             std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->M, 128) * PB),
@@ -1216,8 +1356,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         const bool pred = h->pred_col != 0;
         if (pred)
             prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev);
-        else
+        else if (!use_queue)
             prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev);
+        // (pred == vector pipe with the work queue: nothing goes out ahead - inside the dense regime that engine only runs
+        // when the bracket of the column minima is too wide for the matrix-core offsets, a handful of E-steps at most)
         PRG_HIP(hipGetLastError());
         // the answer: a few microseconds after the transform has finished, long before the column pass has
         volatile EngineDecision* mb = h->eng_host;
@@ -1243,20 +1385,20 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                     (double)mb->sigma2, (double)mb->nk_ext2, ea.col_bound, ea.row_bound, (double)mb->motion, (double)mb->cmax,
                     (double)mb->nk_width, (double)mb->nk_far2, (int)h->have_colmin, (int)use_mfma, (int)first_mfma,
                     pred == use_mfma ? "yes" : "NO", (int)row_mfma, (int)fine_cull);
-        col_launched = pred == use_mfma;
+        col_launched = pred == use_mfma && (pred || !use_queue);
         h->pred_col = use_mfma ? 1 : 0;
-        if (!col_launched) {  // (the guarded launch has returned at once; rare: the engine changes once or twice per registration)
-            if (use_mfma)
-                prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev);
-            else
-                prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);
+        if (!col_launched && use_mfma) {  // (the guarded launch has returned at once; rare: the engine changes once or twice per registration)
+            prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev);
             col_launched = true;
         }
     }
     h->last_estep_mfma = use_mfma;
     h->last_estep_row_mfma = row_mfma;
+    const bool col_queue = !col_launched && use_queue, row_queue = !row_mfma && use_queue;
     if (col_launched) {
-    } else if (use_cull)
+    } else if (col_queue)
+        PRG_TRY(prg::launch_colpass_queue(h, cull_seed, h->qcol_live ? 0 : 32));
+    else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);
     else if (ra < 0)
         prg::launch_colpass_scalar(h, RA, SA, segA);
@@ -1266,10 +1408,13 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, use_mfma ? PAm : PA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
                                                       h->colmin + h->Ncap,
-                                                      use_cull ? h->tmeta : nullptr, use_mfma ? (first_mfma ? 2 : 1) : 0, h->motion, slot);
+                                                      use_cull ? h->tmeta : nullptr, use_mfma ? (first_mfma ? 2 : 1) : 0, h->motion, slot,
+                                                      queue_view(h->qcol, col_queue));
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
         prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap), fine_cull);
+    else if (row_queue)
+        PRG_TRY(prg::launch_rowpass_queue(h, h->qrow_live ? 0 : 32));
     else if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);
     else if (rb < 0)
@@ -1282,13 +1427,15 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                   h->mompart,
                                                   use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)(row_mfma ? PBm : PB) * 5 * h->Mcap)
                                                            : nullptr,
-                                                  row_mfma ? h->rorig : nullptr);
+                                                  row_mfma ? h->rorig : nullptr, queue_view(h->qrow, row_queue));
     // (folding this single-block reduction into the last-finishing workgroup of k_row_moments was measured in round 3:
     // +25 us - that workgroup's 256 threads read the ~400 partial rows through L2 in a few dependent rounds, the 1024
     // threads of this launch do it in 5 us including the launch)
     k_reduce_partials<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk, kMomComp, h->moments, 0);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());
+    h->qcol_live = col_queue;
+    h->qrow_live = row_queue;
     h->have_estep = true;
     h->have_colmin = true;  // colmin now describes the z4 of this E-step (motion is measured against it)
     h->last_w = w;
@@ -1324,6 +1471,23 @@ int prg_cpd_pair_counts(prg_cpd* h, double* col_pairs, double* row_pairs) {
     prg::DeviceGuard g(h->device);
     *col_pairs = h->dense_pairs_col;
     *row_pairs = h->dense_pairs_row;
+    for (int pass = 0; pass < 2; ++pass) {  // sweeps over the work queue: one count of (128 x 32) blocks per unit
+        const SweepQueue& q = pass ? h->qrow : h->qcol;
+        if ((pass ? h->wg_row : h->wg_col) != -1) continue;
+        int nu[2] = {0, 0};  // fine units [0, nu[0]), coarse units [cap_soft, cap_soft + nu[1])
+        PRG_HIP(hipMemcpyAsync(nu, q.ctrl + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        PRG_HIP(hipStreamSynchronize(h->stream));
+        double sum = 0.0;
+        for (int part = 0; part < 2; ++part) {
+            if (nu[part] <= 0) continue;
+            std::vector<unsigned> host((size_t)nu[part]);
+            PRG_HIP(hipMemcpyAsync(host.data(), q.ucount + (part ? q.cap_soft : 0), (size_t)nu[part] * sizeof(unsigned),
+                                   hipMemcpyDeviceToHost, h->stream));
+            PRG_HIP(hipStreamSynchronize(h->stream));
+            for (int i = 0; i < nu[part]; ++i) sum += host[(size_t)i];
+        }
+        *(pass ? row_pairs : col_pairs) = sum * 128.0 * prg::kGroup;
+    }
     if (h->wg_col > 0 || h->wg_row > 0) {
         std::vector<unsigned> host((size_t)h->wg_cap * 2);
         PRG_HIP(hipMemcpyAsync(host.data(), h->wgcount, host.size() * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));

@@ -28,6 +28,20 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     EngineDecision* host;
 };
 
+// Work queue of one sparse-regime sweep (cpd_sweeps_queue.hip): 16-bit need-masks per (owned block of 128 points, segment of 16
+// streamed groups), the number of non-empty segments per block, and the units the persistent waves pop.
+struct SweepQueue {
+    unsigned long long* masks = nullptr;  // [nblocks][nchunk][8] one bit per streamed group of 32: needed or not
+    int2* chunk = nullptr;            // [nblocks][nchunk] (first slot, units) of every chunk of 512 groups
+    int2* units = nullptr;            // [<= max units] (block, first group | count << 26), in append order
+    int* ctrl = nullptr;              // counters, see k_queue_build
+    unsigned* ucount = nullptr;       // [units] (128 x 32) blocks each unit evaluated (prg_cpd_pair_counts)
+    int64_t cap_blocks = 0, cap_units = 0;
+    int cap_chunk = 0;
+    int64_t nblocks = 0;
+    int nchunk = 0, cap_soft = 0;
+};
+
 // Row accumulator block: 4 fp64 planes of Mcap (p1, px0, px1, px2), written by the moment kernel.
 struct prg_cpd {
     int device = 0;
@@ -90,6 +104,11 @@ struct prg_cpd {
     bool last_estep_mfma = false, last_estep_row_mfma = false;  // engines of the last E-step's column / row pass
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)
+    // sparse regime: device-built work queues of the two sweeps; sparse_engine 1 = use them for the
+    // vector-pipe sweeps (default), 0 = the grid-per-(block, segment) culled sweeps of round 1
+    SweepQueue qcol, qrow;
+    int sparse_engine = 1;
+    bool qcol_live = false, qrow_live = false;  // the previous E-step's column / row pass ran over the queue (its unit size adapts from there)
     // measurement hook: evaluated (wave, group) blocks per workgroup of the last culled column / row pass
     // ([0, wg_cap) column pass, [wg_cap, 2 wg_cap) row pass); wg_col / wg_row = workgroups of the last launches,
     // dense_pairs_* = pairs covered by the last NON-culled launches (0 when the culled kernels ran)

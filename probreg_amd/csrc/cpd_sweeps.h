@@ -47,6 +47,18 @@ void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng);
 void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine);  // rowflag: 64 bytes per 128-row block (touched planes)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 
+// ---- sparse-regime work queue (cpd_sweeps_queue.hip) ----
+constexpr int kQueueChunkGroups = 512;   // streamed groups (of 32 points) one wave of the build pass tests: 8 mask words
+constexpr int kQueueTargetUnits = 16384; // the units grow (8 -> 16 -> 32 groups) when a sweep had more than twice as many (~2 per wave slot)
+constexpr int kQueueMaxUnits = 98304;    // fine units the queue holds (250 MB of row-pass partials); beyond, a chunk is one coarse unit
+constexpr int kQueueWorkgroups = 2048;   // persistent grid: 8 workgroups of 4 waves per CU
+// q_init: groups per unit to start from (0: adapt from the previous sweep over the queue; the caller passes 32 when the previous
+// E-step's sweep ran on another engine, i.e. was dense)
+int launch_colpass_queue(prg_cpd* h, bool use_seed, int q_init);  // partial (min, sum) pairs -> colpart[unit][128]
+int launch_rowpass_queue(prg_cpd* h, int q_init);                 // partial sums -> rowpart[unit][5][128]
+int64_t queue_max_units(int64_t owned_points, int64_t streamed_points);
+int prepare_queues(prg_cpd* h);  // allocations of both queues for the plan's current clouds
+
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
 constexpr int kSuper = 256;    // quantum of a culled segment's length (8 groups)
 // culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup

@@ -76,6 +76,11 @@ class CpdPlan(object):
         check(lib.prg_cpd_last_estep_engine(self._h, ctypes.byref(e)))
         return int(e.value)
 
+    def set_sparse_engine(self, mode=1):
+        """1: sparse-regime sweeps over the device-built work queue when both clouds are large (default), 2: always,
+        0: never (the grid-per-(block, segment) culled sweeps)."""
+        check(lib.prg_cpd_set_sparse_engine(self._h, int(mode)))
+
     def last_estep_engines(self):
         """(column pass, row pass) of the last E-step: 1 = matrix cores, 0 = vector-pipe sweeps."""
         c, r = ctypes.c_int(0), ctypes.c_int(0)

@@ -534,6 +534,46 @@ def test_culled_sweeps_equal_dense_sweeps(sigma2, w):
     assert np.max(np.abs(x0 - x1)) <= 2e-6 * np.max(np.abs(x1))
 
 
+@pytest.mark.parametrize("sigma2,w,m,n", [(1e-2, 0.0, 15000, 20000), (1e-3, 0.1, 20000, 9000), (5e-5, 0.0, 30011, 29989),
+                                          (2e-4, 0.3, 700, 5000)])
+def test_queue_sweeps_equal_grid_culled_sweeps(sigma2, w, m, n):
+    """Sparse regime: the sweeps over the device-built work queue (default) evaluate the same (128 x 32) blocks with the same
+    arithmetic as the grid of culled waves (prg_cpd_set_sparse_engine(0)); only the order in which a block's partial sums are
+    combined differs (float32 / fp64 round-off).  The queue result does not depend on which wave popped which unit: two runs
+    agree bit for bit."""
+    from probreg_amd import _lib, synthetic
+    from probreg_amd.engine import CpdPlan
+
+    src, tgt, (r, t, _) = synthetic.rigid_pair(n, m=m, seed=61)
+    z = (src @ r.T + t)
+    s32, t32 = (z - tgt.mean(0)).astype(np.float32), (tgt - tgt.mean(0)).astype(np.float32)
+    params = np.zeros(_lib.PRG_NPARAMS)
+    params[[0, 4, 8, 12]] = 1.0
+    params[13] = sigma2
+    out = []
+    for engine in (2, 0, 2):
+        plan = CpdPlan()
+        plan.set_dense_engine(0)
+        plan.set_sparse_engine(engine)
+        plan.set_source(s32)
+        plan.set_target(t32)
+        plan.set_params(params)
+        plan.estep(w)
+        first, pairs_first = plan.get_moments()[:23], plan.pair_counts()
+        plan.estep(w)                        # second E-step: the column pass runs with the seeded bound
+        out.append((first, plan.get_moments()[:23], plan.pair_counts(), pairs_first) + plan.get_estep())
+        plan.close()
+    q, g, q2 = out
+    scale = np.max(np.abs(g[1]))
+    assert np.max(np.abs(q[0] - g[0])) <= 2e-6 * scale and np.max(np.abs(q[1] - g[1])) <= 2e-6 * scale
+    # the very same blocks were evaluated (the grid's unseeded first column pass also walks the pad groups of its last segments)
+    assert q[2][1] == g[2][1] and q[3][1] == g[3][1] and g[2][0] >= q[2][0] >= 0.95 * g[2][0] and g[3][0] >= q[3][0] > 0, (q[2], g[2], q[3], g[3])
+    assert np.max(np.abs(q[4] - g[4])) <= 2e-6 and np.max(np.abs(q[5] - g[5])) <= 2e-6 * np.max(g[5])
+    assert np.max(np.abs(q[6] - g[6])) <= 2e-6 * np.max(np.abs(g[6]))
+    for a, b in zip(q, q2):                  # reproducible to the bit
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_culled_registration_tracks_dense_registration():
     """30 EM iterations, culled vs dense, parameters compared every iteration (the seed of the column-pass bound
     comes from the previous iteration's minima plus the measured source motion)."""

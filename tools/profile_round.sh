@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r2
 # rocprofv3 kernel traces of the default bench line and PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes;
 # never combined with system / runtime traces) for C1, C3 and C4; summaries land in gpurun_out/prof_<tag>/*.txt.
-tag=${1:-r2}
+tag=${1:-r3}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -13,6 +13,11 @@ rocprofv3 --kernel-trace --stats -d $out/kt_default -o b -- python bench.py --st
 sum $(db $out/kt_default) > $out/${tag}_bench_default_kernel_trace.txt
 
 c1="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads"
+# C1 alone: the un-profiled line with its per-iteration (engine, pairs, ms) table, then the kernel trace of the same command -
+# roofline.frac can be recomputed from these two committed files
+$c1 --pairs-log $out/${tag}_c1_pairs_per_iteration.log > $out/${tag}_bench_c1_line.json 2> $out/c1_line.err
+rocprofv3 --kernel-trace --stats -d $out/kt_c1 -o b -- $c1 > $out/c1_kt_line.json 2> $out/kt_c1.err
+sum $(db $out/kt_c1) > $out/${tag}_bench_c1_kernel_trace.txt
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"; do
   name=$(echo $pass | cut -d' ' -f1)
   rocprofv3 --pmc $pass --kernel-trace -d $out/c1_$name -o b -- $c1 > $out/c1_$name.log 2>&1
@@ -39,4 +44,4 @@ sum --pmc $(db $out/c3_FETCH_SIZE) $(db $out/c3_WRITE_SIZE) $(db $out/c3_SQ_INST
 ls -la $out/*.txt
 # afterwards, locally: cp gpurun_out/prof_$tag/${tag}_*.txt profiles/ && python tools/pmc_traffic_update.py $tag
 # keep the merged output small: the databases stay on the box
-rm -rf $out/kt_default $out/c1_* $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c4_SQ_INSTS_VALU $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE $out/c3_SQ_INSTS_VALU 2>/dev/null
+rm -rf $out/kt_default $out/kt_c1 $out/c1_FETCH_SIZE $out/c1_WRITE_SIZE $out/c1_SQ_INSTS_VALU $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c4_SQ_INSTS_VALU $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE $out/c3_SQ_INSTS_VALU 2>/dev/null
