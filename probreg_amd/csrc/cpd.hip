@@ -1523,8 +1523,17 @@ int prg_cpd_get_params(prg_cpd* h, double* params_host) {
     // reads the parameter block every iteration when it has a tolerance to test
     if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
     PRG_HIP(hipMemcpyAsync(h->pinned, h->params, PRG_NPARAMS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    int* host_info = reinterpret_cast<int*>(h->pinned + 48);
+    *host_info = 0;
+    if (h->nr_info) PRG_HIP(hipMemcpyAsync(host_info, h->nr_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));
     for (int i = 0; i < PRG_NPARAMS; ++i) params_host[i] = h->pinned[i];
+    if (*host_info != 0) {  // a non-rigid M-step since the last read-back hit a non-positive pivot (it does not stall to say so)
+        const int pivot = *host_info - 1;
+        PRG_HIP(hipMemsetAsync(h->nr_info, 0, sizeof(int), h->stream));
+        prg::set_error("prg_cpd_mstep_nonrigid: the reduced system is not positive definite at pivot %d (sigma2 or lmd <= 0?)", pivot);
+        return PRG_ERR_STATE;
+    }
     return PRG_OK;
 }
 

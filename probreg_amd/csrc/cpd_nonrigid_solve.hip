@@ -967,7 +967,9 @@ int ensure_solve_workspace(prg_cpd* h, size_t need) {
     h->nr_solve = nullptr;
     h->nr_solve_bytes = 0;
     PRG_HIP(hipMalloc((void**)&h->nr_solve, need));
+    PRG_HIP(hipMemsetAsync(h->nr_solve, 0, need, h->stream));  // (the sticky pivot flag of the low-rank M-step lives at its end)
     h->nr_solve_bytes = need;
+    h->nr_info = nullptr;
     return PRG_OK;
 }
 
@@ -1001,13 +1003,15 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
     const dim3 ggrid((unsigned)ntile, (unsigned)nsplit);
     const dim3 rgrid = grid1(4 * std::max<int64_t>((int64_t)rp * rp, rp * 3));  // four lanes per element
 
-    PRG_HIP(hipMemsetAsync(info, 0, sizeof(int), st));
+    // (info is sticky: cleared when the workspace is allocated and when prg_cpd_get_params has reported it)
     k_rhs<<<grid1(ld), kBlock, 0, st>>>(h->rowacc, h->Mcap, h->src4, m, ld, h->nr_alpha > 0.0 ? h->nr_prior : nullptr,
                                         h->nr_alpha, h->params, b3, sp);
     // S = c I + F^T D F and z = F^T B in one pass over the factor
     k_lr_gram<<<ggrid, kBlock, 0, st>>>(h->F, ld, m, rank, sp, b3, chunk, part, upart);
     k_lr_gram_reduce<<<rgrid, kBlock, 0, st>>>(part, upart, ntile, nsplit, rank, rp, h->params, lmd, S, z);
     const bool small = rp <= 1024;  // (beyond, the MFMA panel solves of the big factorisation pay for their inverses)
+    // (one workgroup doing the whole r x r solve out of LDS was built in round 3: with the packed triangle's irregular LDS
+    // addressing it took 270 us at r = 176, more than the ten launches below - 240 us - and was removed)
     if (small) {
         PRG_TRY(cholesky_small(h, S, rp, info, rank));
         PRG_TRY(cholesky_small_solve3(h, S, rp, z, rank));  // z = (c I + F^T D F)^-1 F^T B
@@ -1040,13 +1044,9 @@ int mstep_nonrigid_lowrank(prg_cpd* h, double lmd) {
     k_nonrigid_finish<<<1, 64, 0, st>>>(trpart, tr_blk, h->moments, h->params, h->D);
     PRG_HIP(hipGetLastError());
     h->gw_valid = true;
-    if (!h->pinned) PRG_HIP(hipHostMalloc((void**)&h->pinned, 64 * sizeof(double), hipHostMallocDefault));
-    int* host_info = reinterpret_cast<int*>(h->pinned + 48);
-    PRG_HIP(hipMemcpyAsync(host_info, info, sizeof(int), hipMemcpyDeviceToHost, st));
-    PRG_HIP(hipStreamSynchronize(st));
-    PRG_REQUIRE(*host_info == 0, PRG_ERR_STATE,
-                "prg_cpd_mstep_nonrigid: the reduced system is not positive definite at pivot %d (sigma2 or lmd <= 0?)",
-                *host_info - 1);
+    // The pivot check does not stall the stream: the flag is looked at the next time the host synchronises anyway
+    // (prg_cpd_get_params / the next M-step), where a failure of this step is reported.
+    h->nr_info = info;
     return PRG_OK;
 }
 

@@ -139,6 +139,7 @@ struct prg_cpd {
     size_t nr_work_bytes = 0;
     double* nr_solve = nullptr;  // M-step workspace: S (fp64 M x M), block inverses, vectors
     size_t nr_solve_bytes = 0;
+    int* nr_info = nullptr;      // device: first non-positive pivot + 1 of a low-rank M-step since the last report (0: none)
     double* nr_prior = nullptr;            // [4][M]: p1_tilde, px_tilde (3 planes) of ConstrainedNonRigidCPD
     double nr_alpha = 0.0;                 // 0 = no correspondence priors
     hipStream_t nr_stream2 = nullptr;      // side stream of the look-ahead Cholesky
