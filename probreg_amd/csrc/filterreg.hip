@@ -322,8 +322,11 @@ template <int D, bool FR>
 __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat, const FrFeat fr, int64_t first,
                                                   int64_t n, float s0, float s1, float s2, const EmbedTable table,
                                                   int* __restrict__ pslot, float* __restrict__ bary,
-                                                  const EmbedTable side, float t0, float t1, float t2) {
-    const int64_t i = first + (int64_t)blockIdx.x * kBlock + threadIdx.x;  // points [first, n)
+                                                  const EmbedTable side, float t0, float t1, float t2, int sample) {
+    // sample 0: points [first, n); 1: every 16th point of [0, n) (a sample spread over the whole cloud: it creates most
+    // vertices with few lanes of a wave after the same one); 2: all the others
+    const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = sample == 0 ? first + t : (sample == 1 ? 16 * t : t + t / 15 + 1);
     if (i >= n) return;
     constexpr int D1 = D + 1;
     const int lane = threadIdx.x & 63;
@@ -999,18 +1002,20 @@ void lat_scale(int d, int with_blur, float (&sc)[3]) {
 // Embedding launch over points [first, last) into `table`; side (tkeys may be null): the same points also go, with the
 // scale factors ssc, into the side table of the speculative with_blur decision.
 void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&sc)[3], const EmbedTable& table,
-                  const EmbedTable& side, const float (&ssc)[3]) {
-    const unsigned nb = (unsigned)prg::ceil_div(last - first, kBlock);
+                  const EmbedTable& side, const float (&ssc)[3], int sample = 0) {
+    // sample 1 / 2: first must be 0; the every-16th sample has ceil(last / 16) points, the complement the rest
+    const int64_t count = sample == 0 ? last - first : (sample == 1 ? prg::ceil_div(last, 16) : last - prg::ceil_div(last, 16));
+    const unsigned nb = (unsigned)prg::ceil_div(count, kBlock);
     if (nb == 0) return;
     hipStream_t st = L->stream;
     const FrFeat none = {nullptr, nullptr, nullptr, nullptr, 0, 0};
 #define PRG_EMBED(DD)                                                                                              \
     if (L->prod)                                                                                                    \
         k_embed<DD, true><<<nb, kBlock, 0, st>>>(nullptr, *L->prod, first, last, sc[0], sc[1], sc[2], table,        \
-                                                 L->pslot, L->bary, side, ssc[0], ssc[1], ssc[2]);                  \
+                                                 L->pslot, L->bary, side, ssc[0], ssc[1], ssc[2], sample);          \
     else                                                                                                            \
         k_embed<DD, false><<<nb, kBlock, 0, st>>>(L->feat, none, first, last, sc[0], sc[1], sc[2], table,           \
-                                                  L->pslot, L->bary, side, ssc[0], ssc[1], ssc[2])
+                                                  L->pslot, L->bary, side, ssc[0], ssc[1], ssc[2], sample)
     if (d == 1) { PRG_EMBED(1); }
     else if (d == 2) { PRG_EMBED(2); }
     else { PRG_EMBED(3); }
@@ -1076,7 +1081,17 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         const EmbedTable main_table = {L->tkeys, mask, L->gen, L->count, L->slot_id, L->dkeys};
         const EmbedTable no_side = {nullptr, 0, 0, nullptr, nullptr, nullptr};
         const float no_sc[3] = {0.f, 0.f, 0.f};
+        // stage 1 = every 16th point, stage 2 = the others (PRG_EMBED_CONTIGUOUS=1: the first sixteenth / the rest, as in round 2)
+        static const bool contiguous = getenv("PRG_EMBED_CONTIGUOUS") != nullptr;
         auto embed = [&](int64_t first, int64_t last) { launch_embed(L, d, first, last, sc, main_table, no_side, no_sc); };
+        auto embed_stage = [&](int stage, const EmbedTable& side_table, const float (&side_sc)[3]) {
+            if (contiguous) {
+                if (stage == 1) launch_embed(L, d, 0, n / 16, sc, main_table, side_table, side_sc);
+                else launch_embed(L, d, n / 16, n, sc, main_table, side_table, side_sc);
+            } else {
+                launch_embed(L, d, 0, n, sc, main_table, side_table, side_sc, stage);
+            }
+        };
         if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));
         if (!L->mail) {
             PRG_HIP(hipHostMalloc((void**)&L->mail, sizeof(LatticeMail), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1087,7 +1102,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
         int64_t done = 0;
         if (decide_above >= 0 && n >= 4096) {  // stage 1: a sixteenth of the points; the vertex counter tells
             done = n / 16;
-            embed(0, done);
+            embed_stage(1, no_side, no_sc);
             PRG_HIP(hipGetLastError());
             PRG_HIP(hipMemcpyAsync(L->pinned, L->count, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
             PRG_HIP(hipStreamSynchronize(st));
@@ -1110,15 +1125,16 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                 float bsc[3];
                 lat_scale(d, 1, bsc);
                 const EmbedTable side = {L->tkeys2, (unsigned long long)L->cap2 - 1, L->gen2, L->count2, nullptr, nullptr};
-                launch_embed(L, d, 0, done, sc, main_table, side, bsc);
+                embed_stage(1, side, bsc);
                 L->side_fuse = false;
                 L->side_pending = true;
             } else {
-                embed(0, done);
+                embed_stage(1, no_side, no_sc);
             }
         }
         if (host[1] == 0) {
-            embed(done, n);
+            if (done > 0) embed_stage(2, no_side, no_sc);
+            else embed(0, n);
             // the resolve pass goes out right behind the embedding and tells the host the counters while it runs: no
             // device-to-host copy, no stream synchronisation, the queue does not drain (on an overflow - rare - it has
             // resolved garbage, which the retry overwrites)
@@ -1483,6 +1499,7 @@ struct prg_filterreg {
     int64_t part_blocks = 0;
     std::vector<int> tgt_order;  // Morton order of the target (kernel position -> caller's index); see prg_fr_set_target
     int* ref_pos = nullptr;      // [N] device: caller's index -> kernel position (the ordered splat walks the caller's order)
+    int* src_perm = nullptr;     // [M] device: kernel position -> caller's index of the (Morton-sorted) source; null: caller's order
     bool have_src = false, have_tgt = false, have_estep = false;
     FrFeat prod;             // feature producer handed to the embedding kernels
     int last_blur = 1;       // with_blur of the previous E-step: which lattice the next one tries first
@@ -1886,6 +1903,15 @@ __global__ __launch_bounds__(kBlock) void k_fr_pack_estep(const double* __restri
         for (int k = 0; k < 3; ++k) o[5 + k] = nx[i * 3 + k];
 }
 
+// out[perm[i]][0 .. ncols) = vout[i][col0 .. col0 + ncols): the plan's per-source-point values back in the caller's order
+__global__ __launch_bounds__(kBlock) void k_fr_columns(const float* __restrict__ vout, int ch, int col0, int ncols,
+                                                       const int* __restrict__ perm, int64_t m, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const int64_t j = perm ? perm[i] : i;
+    for (int k = 0; k < ncols; ++k) out[j * ncols + k] = vout[i * ch + col0 + k];
+}
+
 // stand-alone Kabsch: moments of (model, target, weight) float32 clouds -> partials [nblk][kFrComp]
 __global__ __launch_bounds__(kBlock) void k_kabsch_terms(const float* __restrict__ model,
                                                          const float* __restrict__ target,
@@ -2050,7 +2076,7 @@ int prg_fr_destroy(prg_filterreg* h) {
     (void)hipStreamSynchronize(h->L.stream);
     lat_free(&h->L);
     for (void* p : {(void*)h->src, (void*)h->tgt, (void*)h->ts, (void*)h->vin, (void*)h->vout, (void*)h->state,
-                    (void*)h->part, (void*)h->nrm, (void*)h->ref_pos})
+                    (void*)h->part, (void*)h->nrm, (void*)h->ref_pos, (void*)h->src_perm})
         if (p) (void)hipFree(p);
     delete h;
     return PRG_OK;
@@ -2083,8 +2109,26 @@ int prg_fr_set_source(prg_filterreg* h, const double* source_hd, int64_t m, int 
     if (h->src) (void)hipFree(h->src);
     h->src = nullptr;
     PRG_HIP(hipMalloc((void**)&h->src, (size_t)m * dim * sizeof(double)));
-    PRG_HIP(hipMemcpyAsync(h->src, source_hd, (size_t)m * dim * sizeof(double), hipMemcpyDefault, h->L.stream));
-    PRG_HIP(hipStreamSynchronize(h->L.stream));
+    if (h->src_perm) (void)hipFree(h->src_perm);
+    h->src_perm = nullptr;
+    static const bool sort_source = getenv("PRG_FR_SOURCE_ORDER") == nullptr;  // (set: keep the caller's order, as in round 2)
+    if (sort_source && m >= 4096) {
+        // The source is stored in Morton order like the target: with the lattice's vertices created by a sample spread over
+        // both clouds (every 16th point, lat_build), the other points only LOOK vertices up, and neighbouring lanes of a
+        // sorted cloud look up the same few table lines.  Every per-point output crosses the ABI through src_perm.
+        std::vector<double> host((size_t)m * dim), sorted((size_t)m * dim);
+        PRG_HIP(hipMemcpy(host.data(), source_hd, host.size() * sizeof(double), hipMemcpyDefault));
+        const std::vector<int> order = prg::morton_order(host.data(), m, dim);
+        for (int64_t i = 0; i < m; ++i)
+            for (int k = 0; k < dim; ++k) sorted[(size_t)i * dim + k] = host[(size_t)order[i] * dim + k];
+        PRG_HIP(hipMalloc((void**)&h->src_perm, (size_t)m * sizeof(int)));
+        PRG_HIP(hipMemcpyAsync(h->src_perm, order.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, h->L.stream));
+        PRG_HIP(hipMemcpyAsync(h->src, sorted.data(), (size_t)m * dim * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
+        PRG_HIP(hipStreamSynchronize(h->L.stream));
+    } else {
+        PRG_HIP(hipMemcpyAsync(h->src, source_hd, (size_t)m * dim * sizeof(double), hipMemcpyDefault, h->L.stream));
+        PRG_HIP(hipStreamSynchronize(h->L.stream));
+    }
     h->M = m;
     h->D = dim;
     h->have_src = true;
@@ -2187,17 +2231,23 @@ int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_bl
     return PRG_OK;
 }
 
+// columns [col0, col0 + ncols) of the filtered values, one row per source point in the CALLER's order -> out_hd
+static int fr_fetch_columns(prg_filterreg* h, int col0, int ncols, float* out_hd) {
+    hipStream_t st = h->L.stream;
+    PRG_TRY(lat_ensure_io(&h->L, (size_t)h->M * ncols * sizeof(float)));
+    k_fr_columns<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, st>>>(h->vout, h->ch, col0, ncols, h->src_perm, h->M, h->L.io);
+    PRG_HIP(hipGetLastError());
+    PRG_HIP(hipMemcpyAsync(out_hd, h->L.io, (size_t)h->M * ncols * sizeof(float), hipMemcpyDefault, st));
+    PRG_HIP(hipStreamSynchronize(st));
+    return PRG_OK;
+}
+
 int prg_fr_get_estep(prg_filterreg* h, float* m0_hd, float* m1_hd, float* m2_hd) {
     PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_fr_get_estep: no E-step has been run");
     prg::DeviceGuard g(h->L.device);
-    hipStream_t st = h->L.stream;
-    const size_t pitch = (size_t)h->ch * sizeof(float);
-    if (m0_hd) PRG_HIP(hipMemcpy2DAsync(m0_hd, sizeof(float), h->vout, pitch, sizeof(float), h->M, hipMemcpyDefault, st));
-    if (m1_hd)
-        PRG_HIP(hipMemcpy2DAsync(m1_hd, h->D * sizeof(float), h->vout + 1, pitch, h->D * sizeof(float), h->M,
-                                 hipMemcpyDefault, st));
-    if (m2_hd) PRG_HIP(hipMemcpy2DAsync(m2_hd, sizeof(float), h->vout + 4, pitch, sizeof(float), h->M, hipMemcpyDefault, st));
-    PRG_HIP(hipStreamSynchronize(st));
+    if (m0_hd) PRG_TRY(fr_fetch_columns(h, 0, 1, m0_hd));
+    if (m1_hd) PRG_TRY(fr_fetch_columns(h, 1, h->D, m1_hd));
+    if (m2_hd) PRG_TRY(fr_fetch_columns(h, 4, 1, m2_hd));
     return PRG_OK;
 }
 
@@ -2255,10 +2305,7 @@ int prg_fr_get_nx(prg_filterreg* h, float* nx_hd) {
     PRG_REQUIRE(h && h->have_estep && h->ch == 8 && nx_hd, PRG_ERR_STATE,
                 "prg_fr_get_nx: needs target normals and an E-step");
     prg::DeviceGuard g(h->L.device);
-    PRG_HIP(hipMemcpy2DAsync(nx_hd, 3 * sizeof(float), h->vout + 5, 8 * sizeof(float), 3 * sizeof(float), h->M,
-                             hipMemcpyDefault, h->L.stream));
-    PRG_HIP(hipStreamSynchronize(h->L.stream));
-    return PRG_OK;
+    return fr_fetch_columns(h, 5, 3, nx_hd);
 }
 
 int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min_sigma2, double* out_host) {
