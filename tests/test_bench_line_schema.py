@@ -1,13 +1,18 @@
-"""The bench contract on the committed line of the round (profiles/r2_bench_default_line_1gpu_a.json = the unprofiled
-`python bench.py` run on one MI355X): every key the driver and the judge read is there, with the promised meaning."""
+"""The bench contract on the committed line of the round (the newest profiles/r<N>_bench_default_line_1gpu*.json = an
+unprofiled `python bench.py` run on one MI355X): every key the driver and the judge read is there, with the promised meaning."""
+import glob
 import json
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    with open(os.path.join(ROOT, "profiles", "r2_bench_default_line_1gpu_a.json")) as f:
+    paths = glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default_line_1gpu*.json"))
+    paths = [p for p in paths if "profiled" not in os.path.basename(p)]
+    newest = max(paths, key=lambda p: (int(re.match(r"r(\d+)_", os.path.basename(p)).group(1)), os.path.basename(p)))
+    with open(newest) as f:
         return json.loads(f.read().strip().splitlines()[-1])
 
 
@@ -42,3 +47,6 @@ def test_other_workloads_ride_in_the_same_line():
     assert nr["kernel_factor"]["rank"] > 0                       # the product path is the kernel factor ...
     assert nr["dense_solver"]["max_dT_over_extent"] < 1e-4       # ... and it agrees with the dense fallback
     assert d["parity"]["ok"] is True
+    if "parity" in other["affine_200k"]:  # (round 3 on: every workload carries its own GPU-vs-oracle block)
+        for name, w in other.items():
+            assert w["parity"]["ok"] is True, (name, w["parity"])

@@ -9,7 +9,9 @@ mkdir -p $out
 sum() { python tools/rocpd_summary.py "$@"; }
 db() { ls $1/*.db $1/*/*.db 2>/dev/null | head -1; }
 
-rocprofv3 --kernel-trace --stats -d $out/kt_default -o b -- python bench.py --steps 20 --warmup 5 > $out/bench_default_line.json 2> $out/kt_default.err
+# the driver's own command, un-profiled: the line tests/test_bench_line_schema.py checks
+python bench.py > $out/${tag}_bench_default_line_1gpu.json 2> $out/default_line.err
+rocprofv3 --kernel-trace --stats -d $out/kt_default -o b -- python bench.py --no-cpu-baseline > $out/bench_default_line_profiled.json 2> $out/kt_default.err
 sum $(db $out/kt_default) > $out/${tag}_bench_default_kernel_trace.txt
 
 c1="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads"
