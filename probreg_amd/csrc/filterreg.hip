@@ -974,6 +974,13 @@ int lat_free(Lattice* L) {
     return PRG_OK;
 }
 
+// capacity for a buffer that has to hold `need` elements now and at most `worst` ever: four times the need, at least 4M
+// elements, never more than the worst case - the lattice of an EM registration grows every iteration, and every
+// reallocation (hipFree synchronises the device) is a bubble in the stream
+int64_t lat_grow(int64_t need, int64_t worst) {
+    return std::max<int64_t>(need, std::min<int64_t>(worst, std::max<int64_t>(4 * need, (int64_t)1 << 22)));
+}
+
 int lat_ensure_io(Lattice* L, size_t bytes) {
     if (L->io && L->io_bytes >= bytes) return PRG_OK;
     if (L->io) (void)hipFree(L->io);
@@ -1177,10 +1184,12 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
     if (with_blur) {
         const int64_t need = 2 * (int64_t)d1 * L->size;
         if (need > L->nb_alloc) {
+            // (generous: the lattice grows from iteration to iteration and hipFree / hipMalloc drain the device)
+            const int64_t want = lat_grow(need, 2 * (int64_t)d1 * n * d1);
             if (L->nb) (void)hipFree(L->nb);
             L->nb = nullptr;
-            PRG_HIP(hipMalloc((void**)&L->nb, need * sizeof(int)));
-            L->nb_alloc = need;
+            PRG_HIP(hipMalloc((void**)&L->nb, want * sizeof(int)));
+            L->nb_alloc = want;
         }
         int* nb1 = L->nb;
         int* nb2 = L->nb + (int64_t)d1 * L->size;
@@ -1387,10 +1396,11 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
     hipStream_t st = L->stream;
     const int64_t plane = (int64_t)(L->size + 1) * ch;
     if (2 * plane > L->vals_elems) {
+        const int64_t want = lat_grow(2 * plane, 2 * (L->n * d1 + 1) * ch);
         if (L->vals) (void)hipFree(L->vals);
         L->vals = nullptr;
-        PRG_HIP(hipMalloc((void**)&L->vals, 2 * plane * sizeof(float)));
-        L->vals_elems = 2 * plane;
+        PRG_HIP(hipMalloc((void**)&L->vals, want * sizeof(float)));
+        L->vals_elems = want;
     }
     float* a = L->vals;
     float* b = L->vals + plane;
@@ -1437,7 +1447,7 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
         if (plane > L->fx_elems) {
             if (L->fx) (void)hipFree(L->fx);
             L->fx = nullptr;
-            const int64_t want = plane + plane / 4 + 1024;
+            const int64_t want = lat_grow(plane, (L->n * d1 + 1) * ch);
             PRG_HIP(hipMalloc((void**)&L->fx, (size_t)want * sizeof(long long)));
             PRG_HIP(hipMemsetAsync(L->fx, 0, (size_t)want * sizeof(long long), st));  // from here on k_fix_to_float keeps it zero
             L->fx_elems = want;
@@ -1537,9 +1547,15 @@ __device__ __forceinline__ double fr_uniform_c(double wfac, int dim, double sigm
     return wfac * pow(2.0 * sigma2 * M_PI, dim * 0.5);
 }
 
+__device__ void fr_finish_body(const double* __restrict__ part, int nblk, int dim, int update_sigma2, double min_sigma2,
+                               double* __restrict__ state);
+
+// done != null: the workgroup that finishes last goes on with the weighted Kabsch / composition / sigma2 update itself
+// (fr_finish_body: what k_fr_finish does) - one launch and one dependent-launch gap less per EM iteration.
 __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout, int ch,
                                                      const double* __restrict__ ts, int64_t m, int dim, double wfac,
-                                                     const double* __restrict__ state, double* __restrict__ part) {
+                                                     double* __restrict__ state, double* __restrict__ part,
+                                                     unsigned* __restrict__ done, int update_sigma2, double min_sigma2) {
     __shared__ double sh[4][kFrComp];
     double a[kFrComp];
 #pragma unroll
@@ -1593,6 +1609,18 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
     if (threadIdx.x < kFrComp)
         part[(int64_t)blockIdx.x * kFrComp + threadIdx.x] =
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+    if (!done) return;
+    __shared__ bool is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        is_last = atomicAdd(done, 1u) == gridDim.x - 1;
+        if (is_last) *done = 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    fr_finish_body(part, (int)gridDim.x, dim, update_sigma2, min_sigma2, state);
 }
 
 // point-to-plane M-step terms (filterreg.py:183-186 -> cc/point_to_plane.cc:6-32): per point with m0 != 0
@@ -1835,6 +1863,11 @@ __device__ void kabsch_from_moments(const double* mom, int dim, double (&dr)[3][
 __global__ __launch_bounds__(kBlock) void k_fr_finish(const double* __restrict__ part, int nblk, int dim,
                                                       int update_sigma2, double min_sigma2,
                                                       double* __restrict__ state) {
+    fr_finish_body(part, nblk, dim, update_sigma2, min_sigma2, state);
+}
+
+__device__ void fr_finish_body(const double* __restrict__ part, int nblk, int dim, int update_sigma2, double min_sigma2,
+                               double* __restrict__ state) {
     __shared__ double sh[8][32];
     __shared__ double mom[32];
     const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
@@ -2273,8 +2306,8 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma
     hipStream_t st = h->L.stream;
     const double wfac = w / (1.0 - w) * (double)h->N / (double)h->M;
     const int nblk = (int)h->part_blocks;
-    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, wfac, h->state, h->part);
-    k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, min_sigma2, h->state);
+    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, wfac, h->state, h->part,
+                                        reinterpret_cast<unsigned*>(h->state + 60), update_sigma2, min_sigma2);
     PRG_HIP(hipGetLastError());
     return out_host ? fr_read_state(h, out_host, 18) : PRG_OK;  // NULL: nothing is read back, the stream keeps running
 }
@@ -2376,7 +2409,7 @@ int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_sourc
         k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>((const double*)b_part.p, nblk, update_sigma2, -1.0, (double*)b_state.p);
     } else {
         k_fr_terms<<<nblk, kBlock, 0, st>>>((const float*)b_v.p, ch, (const double*)b_ts.p, m, dim, wfac,
-                                            (const double*)b_state.p, (double*)b_part.p);
+                                            (double*)b_state.p, (double*)b_part.p, nullptr, 0, 0.0);
         k_fr_finish<<<1, kBlock, 0, st>>>((const double*)b_part.p, nblk, dim, update_sigma2, -1.0, (double*)b_state.p);
     }
     PRG_HIP(hipGetLastError());

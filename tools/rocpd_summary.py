@@ -39,8 +39,35 @@ def pmc_stats(paths):
                 print("%-40s %-22s %16.6g %6d" % (name[:40], r[1], r[2], r[3]))
 
 
+def gap_stats(path, top=25):
+    """Idle time of the device between consecutive kernels (start of one minus end of the previous), grouped by the pair."""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    pairs, busy, idle = {}, 0, 0
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        gap = s1 - e0
+        busy += e0 - s0
+        if gap > 200000:  # > 0.2 ms: host-side phases (setup, read-backs), not part of the steady state
+            continue
+        idle += max(gap, 0)
+        key = (short(n0), short(n1))
+        g = pairs.setdefault(key, [0, 0])
+        g[0] += 1
+        g[1] += max(gap, 0)
+    print("# gaps between consecutive kernels (%s): busy %.1f ms, idle %.1f ms (gaps > 0.2 ms ignored)" % (path, busy / 1e6, idle / 1e6))
+    print("%-34s -> %-34s %6s %10s %10s" % ("previous kernel", "next kernel", "n", "avg_gap_us", "total_ms"))
+    for (a, b), (n, tot) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:top]:
+        print("%-34s -> %-34s %6d %10.1f %10.2f" % (a[:34], b[:34], n, tot / n / 1e3, tot / 1e6))
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "--pmc":
         pmc_stats(sys.argv[2:])
+    elif sys.argv[1] == "--gaps":
+        gap_stats(sys.argv[2])
     else:
         kernel_stats(sys.argv[1])
