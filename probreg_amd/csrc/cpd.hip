@@ -1363,6 +1363,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         PRG_HIP(hipGetLastError());
         // the answer: a few microseconds after the transform has finished, long before the column pass has
         volatile EngineDecision* mb = h->eng_host;
+        (void)hipStreamQuery(h->stream);  // (makes sure everything enqueued so far has been handed to the device)
         for (uint64_t spins = 0; mb->seq != ea.seq; ++spins) {
             if ((spins & 0xFFFull) == 0xFFFull && hipStreamQuery(h->stream) != hipErrorNotReady) {
                 // the stream has drained (or failed): the decision kernel is done, its store must be here by now

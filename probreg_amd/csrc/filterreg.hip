@@ -1151,6 +1151,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                                                                                  L->mail_dev, seq);
             PRG_HIP(hipGetLastError());
             volatile LatticeMail* mb = L->mail;
+            (void)hipStreamQuery(st);  // (makes sure everything enqueued so far has been handed to the device)
             for (uint64_t spins = 0; mb->seq != seq; ++spins) {
                 if ((spins & 0xFFFull) == 0xFFFull && hipStreamQuery(st) != hipErrorNotReady) {
                     if (mb->seq == seq) break;
