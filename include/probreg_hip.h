@@ -180,7 +180,8 @@ int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_ro
  * math_utils.py:36-37 -> cc/math_utils.cc:17-19.
  * The plan does not store the M x M matrix when it does not have to: a Gaussian kernel matrix of a point cloud is
  * numerically low rank, and the plan keeps its pivoted-Cholesky factor G = F F^T (fp64, M x r, columns evaluated on the
- * fly; the factorisation stops when every entry of G - F F^T is below `tol`, default 1e-14).  Every later product with
+ * fly; the factorisation stops when every entry of G - F F^T is below `tol`, default 1e-11 - the reference's float32 G is
+ * 6e-8 from the exact kernel).  Every later product with
  * G and the M-step's solve then cost O(M r) / O(M r^2).  When the rank would exceed max_rank the plan
  * falls back to the dense float32 matrix and the M x M fp64 Cholesky. */
 int prg_cpd_nonrigid_build_g(prg_cpd* h, double beta);

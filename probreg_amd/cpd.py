@@ -334,12 +334,13 @@ class NonRigidCPD(CoherentPointDrift):
 
     beta : width parameter of the Gaussian kernel ``G = exp(-d^2 / (2 beta))`` (note: beta, not beta^2)
     lmd  : weight of the smoothness regulariser
-    The kernel is factorised on the GPU when the source is set (``G = F F^T`` by pivoted Cholesky, exact to 1e-14; the
+    The kernel is factorised on the GPU when the source is set (``G = F F^T`` by pivoted Cholesky, exact to 1e-11 per entry; the
     M x M matrix itself is only kept when its rank is too high for that - see ``prg_cpd_nonrigid_build_g``).
     """
 
     _kind = _lib.PRG_TF_NONRIGID
     _solver_mode = 1  # prg_cpd_nonrigid_set_solver: 1 = low-rank factor when the rank allows, 0 = always the dense matrix
+    _factor_tol = 0.0  # largest entry of G - F F^T the factor may leave (0: the library's default, 1e-11)
 
     def __init__(self, source=None, beta=2.0, lmd=2.0, use_cuda=False, device=None):
         super(NonRigidCPD, self).__init__(source, use_cuda, device)
@@ -355,7 +356,7 @@ class NonRigidCPD(CoherentPointDrift):
         return self._origin, self._origin
 
     def _build(self):
-        self._plan, self._origin = _nonrigid_plan(self._source, self._beta, self._device, self._solver_mode)
+        self._plan, self._origin = _nonrigid_plan(self._source, self._beta, self._device, self._solver_mode, self._factor_tol)
         self._source_uploaded = True
         self._tf_obj = tf.NonRigidTransformation(None, self._source, self._beta, _plan=self._plan,
                                                  _plan_points=self._source - self._origin)
@@ -440,7 +441,7 @@ class NonRigidCPD(CoherentPointDrift):
         return MstepResult(tf_obj, float(out[13]), float(out[14]))
 
 
-def _nonrigid_plan(points, beta, device=None, solver_mode=1):
+def _nonrigid_plan(points, beta, device=None, solver_mode=1, factor_tol=0.0):
     """A GPU plan holding the kernel ``G = exp(-|y_i - y_j|^2 / (2 beta))`` of ``points`` (as its factor when the rank
     allows).  Returns ``(plan, origin)``; the plan works in the frame ``points - origin``."""
     plan = CpdPlan(device)
@@ -457,7 +458,7 @@ def _nonrigid_plan(points, beta, device=None, solver_mode=1):
     ext = float(np.max(points.max(axis=0) - points.min(axis=0)))
     origin = c if float(np.max(np.abs(c))) > 8.0 * max(ext, 1e-300) else np.zeros(points.shape[1])
     plan.set_source(points - origin)
-    plan.set_nonrigid_solver(solver_mode)
+    plan.set_nonrigid_solver(solver_mode, 0, factor_tol)
     plan.build_g(beta)
     return plan, origin
 
