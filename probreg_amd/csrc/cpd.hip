@@ -1136,8 +1136,8 @@ int prg_cpd_set_tuning(prg_cpd* h, int r_col, int seg_col, int r_row, int seg_ro
     auto ok_r = [](int r) { return r == 0 || r == 2 || r == 4 || r == -2 || r == -4; };
     PRG_REQUIRE(ok_r(r_col) && ok_r(r_row), PRG_ERR_INVALID,
                 "prg_cpd_set_tuning: points per lane must be 0 (auto), 2, 4 (packed) or -2, -4 (scalar form)");
-    PRG_REQUIRE(seg_col >= 0 && seg_col <= 256 && seg_row >= 0 && seg_row <= 256, PRG_ERR_INVALID,
-                "prg_cpd_set_tuning: segment counts must be in [0, 256]");
+    PRG_REQUIRE(seg_col >= 0 && seg_col <= 1024 && seg_row >= 0 && seg_row <= 256, PRG_ERR_INVALID,
+                "prg_cpd_set_tuning: segment counts must be in [0, 1024] (column pass) / [0, 256] (row pass)");
     h->r_col = r_col;
     h->seg_col = seg_col;
     h->r_row = r_row;
@@ -1239,13 +1239,16 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // S segments cost S/4 partial planes.  Segments of 512 streamed points keep a wave's chain of dependent
         // scalar loads short - the bound of a sparse E-step (tools/wave_trace.py) - and 256 segments (64 planes,
         // the width of the row pass' touched-flag rows) are the cap; small problems get 256-point segments.
-        auto cull_segments = [](int64_t lane_points, int64_t stream_len) {
-            int64_t s = std::min<int64_t>(prg::ceil_div(stream_len, 512), 256);
-            if (s * prg::ceil_div(lane_points, 128) < 16384) s = std::min<int64_t>(std::max<int64_t>(stream_len / 256, 1), 256);
+        // [r3] Few owned blocks (a target shard's column pass, the row pass against a short shard) leave the chip with
+        // too few waves to hide a chain of 16 groups behind: below 65536 waves the segments are 256 points (8 groups) -
+        // 8 ranks at C1: E-step 0.245 -> 0.213 ms (mid), 0.124 -> 0.105 ms (late), tools/shard_segments.py.
+        auto cull_segments = [](int64_t lane_points, int64_t stream_len, int64_t cap) {
+            int64_t s = std::min<int64_t>(prg::ceil_div(stream_len, 512), cap);
+            if (s * prg::ceil_div(lane_points, 128) < 65536) s = std::min<int64_t>(prg::ceil_div(stream_len, 256), cap);
             return (int)std::max<int64_t>(s, 1);
         };
-        SA = h->seg_col ? h->seg_col : cull_segments(h->N, h->M);
-        SB = h->seg_row ? h->seg_row : cull_segments(h->M, h->N);
+        SA = h->seg_col ? h->seg_col : cull_segments(h->N, h->M, 1024);
+        SB = h->seg_row ? h->seg_row : cull_segments(h->M, h->N, 256);  // (64 planes: the width of the touched-flag rows)
     } else {
         SA = h->seg_col ? h->seg_col : auto_segments(nblkA, h->M, quantum, 256);
         SB = h->seg_row ? h->seg_row : auto_segments(nblkB, h->N, quantum, 64);
