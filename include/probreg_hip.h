@@ -79,14 +79,14 @@ int prg_cpd_destroy(prg_cpd* h);
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
 
 /* Engine of the E-step's DENSE regime (sigma2 large: every pair contributes).  mode 1 (default; clouds of >= 8192 points
- * each): the pair sweeps take
- * their exponents from the matrix cores (bf16x3-split MFMA distance blocks) while
- * |log2(e) / (2 sigma2)| * (squared diagonal of the larger of the source's / local target's bounding box) < bound * (n / 1e5)^1.8,
- * n = sqrt(M N_local) (bound: default 16000, the measured crossover at 1e5 points; the row pass leaves at 1/20 of it, times
- * (n / 1e5)^2 above 1e5 points; both skip exact zeros in blocks of 512 x 256 and, per wave, 128 x 32) - from there on the culled
- * vector-pipe sweeps, which skip 128 x 32 blocks, are faster and the registration stays on them; mode 0: vector-pipe sweeps only; mode 2: both sweeps on the matrix cores whatever the bound says
- * (tests, measurements).  bound = 0 keeps the current value.  prg_cpd_last_estep_engine reports which engine the last
- * E-step's column pass used (1 = matrix cores). */
+ * each): the pair sweeps take their exponents from the matrix cores (bf16x3-split MFMA distance blocks)
+ * while that is the faster engine - decided per E-step on the device from the number of pairs the matrix-core sweeps of
+ * the previous E-step evaluated (they skip exact zeros in blocks of 512 x 256 and, per wave, 128 x 16) against a cost
+ * model of the two engines; from there on the culled vector-pipe sweeps, which skip 128 x 32 blocks and share the work out
+ * evenly, are faster and the registration stays on them (the row pass leaves first).  mode 0: vector-pipe sweeps only;
+ * mode 2: both sweeps on the matrix cores always (tests, measurements).  bound > 0 replaces the model's bound of the
+ * column pass: matrix cores while they evaluate at least `bound` source points per target; 0 keeps the current setting.
+ * prg_cpd_last_estep_engine reports which engine the last E-step's column pass used (1 = matrix cores). */
 int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound);
 int prg_cpd_last_estep_engine(prg_cpd* h, int* engine);
 /* Sparse regime (sigma2 small: most 128 x 32 blocks of P are exact zeros): 1 (default) - with M and the local N both >= 32768

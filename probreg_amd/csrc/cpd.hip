@@ -256,7 +256,6 @@ __global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict_
 // Consumers of a sweep over the work queue (cpd_sweeps_queue.hip): the partial results of a block of 128 owned points sit
 // in the slots of its units; chunk[b][c] = (first slot, units) for every chunk of 32 stream segments.  Walking the chunks
 // and their units in order gives every block a fixed summation order, wherever the atomics placed the units.
-constexpr int kQueueEnt = 8;  // chunk-table entries a consumer thread fetches at once (C1 has 7 chunks per block)
 struct QueueView {
     const int2* chunk;  // null: the sweep did not run over the queue
     int nchunk;
@@ -285,11 +284,15 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
                                                      int dim, float* __restrict__ colmin, float* __restrict__ colmin_g,
                                                      float* __restrict__ gmeta, int seed_mode,
                                                      unsigned* __restrict__ stat, int slot, const QueueView qv) {
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i_own = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (qv.chunk) queue_reset(qv);
     float b = 0.f;  // pads keep b = 0
     float cmin = 0.f;  // pads do not widen the seed
-    if (i < n) {
+    // Lanes past the end redo the last column and store nothing: the wave stays whole, which the queue consumer below
+    // (entries handed round with readlane) relies on.
+    const bool valid = i_own < n;
+    const int64_t i = valid ? i_own : n - 1;
+    {
     const double sigma2 = params[13];
     const float kkf = (float)(-kLog2e / (2.0 * sigma2));
     // Online merge of the segment partials (dmin_s, sum_s), 8 in flight per lane.  sum_s is relative to the
@@ -309,14 +312,33 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
             ssum += (double)p.y;
         }
     } else if (qv.chunk) {
-        // the slots of the column's block of 128, [unit][128] (min, sum) pairs, chunk by chunk, unit by unit
+        // the slots of the column's block of 128, [unit][128] (min, sum) pairs, chunk by chunk, unit by unit: the wave's
+        // 64 columns share the block, so lane c fetches chunk c's (first slot, units) entry once and the walk hands them
+        // round with readlane; four units (four loads) are in flight per trip
         const int2* __restrict__ cb = qv.chunk + (i >> 7) * qv.nchunk;
-        auto add_chunk = [&](const int2 e) {
-            const float2* __restrict__ o = colpart + (int64_t)e.x * 128 + (i & 127);
-            for (int j = 0; j < e.y; j += 4) {
+        const int lane = threadIdx.x & 63;
+        for (int c0 = 0; c0 < qv.nchunk; c0 += 64) {
+            const int2 mine = c0 + lane < qv.nchunk ? cb[c0 + lane] : make_int2(0, 0);
+            const int lim = qv.nchunk - c0 < 64 ? qv.nchunk - c0 : 64;
+            int c = -1, left = 0, next = 0;
+            auto next_slot = [&]() -> int {  // (wave-uniform)
+                while (left == 0) {
+                    if (++c >= lim) return -1;
+                    next = __builtin_amdgcn_readlane(mine.x, c);
+                    left = __builtin_amdgcn_readlane(mine.y, c);
+                }
+                --left;
+                return next++;
+            };
+            for (;;) {
+                int sl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sl[q] = next_slot();
+                if (sl[0] < 0) break;
                 float2 p[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) p[k] = (j + k < e.y) ? o[(int64_t)(j + k) * 128] : make_float2(INFINITY, 0.f);
+                for (int q = 0; q < 4; ++q)
+                    p[q] = sl[q] < 0 ? make_float2(INFINITY, 0.f) : colpart[(int64_t)sl[q] * 128 + (i & 127)];
                 const float cm = fminf(fminf(p[0].x, p[1].x), fminf(p[2].x, p[3].x));
                 if (cm < gmin) {
                     const float noff = prg::col_offset(kkf, cm);
@@ -325,29 +347,11 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
                     goff = noff;
                 }
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (p[k].y != 0.f) ssum += (double)(p[k].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, p[k].x)));
+                for (int q = 0; q < 4; ++q)
+                    if (p[q].y != 0.f) ssum += (double)(p[q].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, p[q].x)));
+                if (sl[3] < 0) break;
             }
-        };
-        int2 ent[kQueueEnt];  // (the table entries go out together, then the first unit of every chunk, then the rest)
-#pragma unroll
-        for (int c = 0; c < kQueueEnt; ++c) ent[c] = c < qv.nchunk ? cb[c] : make_int2(0, 0);
-        float2 f0[kQueueEnt];
-#pragma unroll
-        for (int c = 0; c < kQueueEnt; ++c)
-            f0[c] = ent[c].y > 0 ? colpart[(int64_t)ent[c].x * 128 + (i & 127)] : make_float2(INFINITY, 0.f);
-#pragma unroll
-        for (int c = 0; c < kQueueEnt; ++c) {
-            if (f0[c].x < gmin) {
-                const float noff = prg::col_offset(kkf, f0[c].x);
-                ssum *= (double)__builtin_amdgcn_exp2f(noff - goff);
-                gmin = f0[c].x;
-                goff = noff;
-            }
-            if (f0[c].y != 0.f) ssum += (double)(f0[c].y * __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, f0[c].x)));
-            if (ent[c].y > 1) add_chunk(make_int2(ent[c].x + 1, ent[c].y - 1));
         }
-        for (int c = kQueueEnt; c < qv.nchunk; ++c) add_chunk(cb[c]);
     } else
     for (int s0 = 0; s0 < nseg; s0 += 8) {
         float2 p[8];
@@ -379,10 +383,14 @@ __global__ __launch_bounds__(kBlock) void k_colfinal(float4* __restrict__ tgt4, 
         b = (float)(-log2(tot));
         p = (float)(den / tot);
     }
-    reinterpret_cast<float*>(tgt4 + i)[3] = b;
-    pt1[i] = p;
-    colmin[i] = gmin;  // min_m |x_n - z_m|^2 of this E-step: seed of the next column pass' cull bound
-    cmin = gmin;
+    if (valid) {
+        reinterpret_cast<float*>(tgt4 + i)[3] = b;
+        pt1[i] = p;
+        colmin[i] = gmin;  // min_m |x_n - z_m|^2 of this E-step: seed of the next column pass' cull bound
+        cmin = gmin;
+    } else {
+        b = 0.f;
+    }
     }
     // per group of 32 columns: the largest of these minima - what a wave of the next column pass needs for its seed
     {
@@ -448,49 +456,54 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
     double a[kMomComp];
 #pragma unroll
     for (int c = 0; c < kMomComp; ++c) a[c] = 0.0;
-    // grid-stride over the rows: few workgroups -> few partials for the single-block final reduction
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
+    // grid-stride over the rows: few workgroups -> few partials for the single-block final reduction.  The trip count is the
+    // same for the 64 lanes of a wave (`valid` masks the rows past the end): the queue consumer below talks across lanes.
+    const int lane = threadIdx.x & 63;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i - lane < m; i += (int64_t)gridDim.x * kBlock) {
+        const bool valid = i < m;
         double p1 = 0, u[3] = {0, 0, 0}, e = 0;
         if (qv.chunk) {
-            // the slots of the row's block of 128, [unit][5][128], chunk by chunk, unit by unit, two units in flight
+            // The slots of the row's block of 128, [unit][5][128]: the wave's 64 rows share the block, so lane c fetches chunk
+            // c's table entry once and the (first slot, units) pairs are handed round with readlane; the units are then
+            // taken FOUR at a time (20 loads in flight), in order: chunk by chunk, unit by unit.
             const int2* __restrict__ cb = qv.chunk + (i >> 7) * qv.nchunk;
-            // The FIRST unit of every chunk is fetched before anything is added (one memory round trip for all of them - in
-            // the sparse regime most chunks hold zero to two units); the rest of a chunk's units follow two at a time.  The
-            // order of the additions is chunk by chunk, unit by unit either way.
-            int2 ent[kQueueEnt];
+            for (int c0 = 0; c0 < qv.nchunk; c0 += 64) {
+                const int2 mine = c0 + lane < qv.nchunk ? cb[c0 + lane] : make_int2(0, 0);
+                const int lim = qv.nchunk - c0 < 64 ? qv.nchunk - c0 : 64;
+                int c = -1, left = 0, next = 0;
+                auto next_slot = [&]() -> int {  // (wave-uniform)
+                    while (left == 0) {
+                        if (++c >= lim) return -1;
+                        next = __builtin_amdgcn_readlane(mine.x, c);
+                        left = __builtin_amdgcn_readlane(mine.y, c);
+                    }
+                    --left;
+                    return next++;
+                };
+                for (;;) {
+                    int sl[4];
 #pragma unroll
-            for (int c = 0; c < kQueueEnt; ++c) ent[c] = c < qv.nchunk ? cb[c] : make_int2(0, 0);
-            float f0[kQueueEnt][5];
+                    for (int q = 0; q < 4; ++q) sl[q] = next_slot();
+                    if (sl[0] < 0) break;
+                    float v[4][5];
 #pragma unroll
-            for (int c = 0; c < kQueueEnt; ++c) {
-                const float* __restrict__ o = rowpart + (int64_t)ent[c].x * 640 + (i & 127);
+                    for (int q = 0; q < 4; ++q) {
+                        const float* __restrict__ o = rowpart + (int64_t)(sl[q] < 0 ? sl[0] : sl[q]) * 640 + (i & 127);
 #pragma unroll
-                for (int k = 0; k < 5; ++k) f0[c][k] = ent[c].y > 0 ? o[128 * k] : 0.f;
-            }
-            auto add_rest = [&](const int2 en, int from) {
-                const float* __restrict__ o = rowpart + ((int64_t)en.x + from) * 640 + (i & 127);
-                for (int q = from; q < en.y; q += 2, o += 1280) {
-                    const bool two = q + 1 < en.y;
-                    const float v0 = o[0], v1 = o[128], v2 = o[256], v3 = o[384], v4 = o[512];
-                    const float w0 = two ? o[640] : 0.f, w1 = two ? o[768] : 0.f, w2 = two ? o[896] : 0.f,
-                                w3 = two ? o[1024] : 0.f, w4 = two ? o[1152] : 0.f;
-                    p1 += (double)v0 + (double)w0;
-                    u[0] += (double)v1 + (double)w1;
-                    u[1] += (double)v2 + (double)w2;
-                    u[2] += (double)v3 + (double)w3;
-                    e += (double)v4 + (double)w4;
+                        for (int k = 0; k < 5; ++k) v[q][k] = o[128 * k];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (sl[q] < 0) continue;
+                        p1 += (double)v[q][0];
+                        u[0] += (double)v[q][1];
+                        u[1] += (double)v[q][2];
+                        u[2] += (double)v[q][3];
+                        e += (double)v[q][4];
+                    }
+                    if (sl[3] < 0) break;
                 }
-            };
-#pragma unroll
-            for (int c = 0; c < kQueueEnt; ++c) {
-                p1 += (double)f0[c][0];
-                u[0] += (double)f0[c][1];
-                u[1] += (double)f0[c][2];
-                u[2] += (double)f0[c][3];
-                e += (double)f0[c][4];
-                if (ent[c].y > 1) add_rest(ent[c], 1);
             }
-            for (int c = kQueueEnt; c < qv.nchunk; ++c) add_rest(cb[c], 0);
         }
         // (128-row wave block, segment) partials the culled row pass never touched are absent (neither written nor
         // read): the wave fetches its block's 64 flag bytes once and walks the set bits (<= 64 planes)
@@ -542,12 +555,14 @@ __global__ __launch_bounds__(kBlock) void k_row_moments(const float* __restrict_
         row_moment_terms(t, p1, px, y);
         // sum_n pt1_n |x_n|^2 restricted to this row: sum_n P |x|^2 = p1 |z|^2 + 2 z.u + e
         t[22] = p1 * (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) + 2.0 * (z[0] * u[0] + z[1] * u[1] + z[2] * u[2]) + e;
+        if (valid) {
 #pragma unroll
-        for (int c = 0; c < kMomComp; ++c) a[c] += t[c];
-        rowacc[i] = p1;
-        rowacc[mcap + i] = px[0];
-        rowacc[2 * mcap + i] = px[1];
-        rowacc[3 * mcap + i] = px[2];
+            for (int c = 0; c < kMomComp; ++c) a[c] += t[c];
+            rowacc[i] = p1;
+            rowacc[mcap + i] = px[0];
+            rowacc[2 * mcap + i] = px[1];
+            rowacc[3 * mcap + i] = px[2];
+        }
     }
     block_reduce_store(a, mompart);
 }
@@ -1153,6 +1168,7 @@ int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound) {
     if (bound > 0.0) h->dense_bound = bound;
     h->mfma_off = false;
     h->pred_col = 1;
+    h->eng_reset = true;
     return PRG_OK;
 }
 
@@ -1218,6 +1234,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     h->have_colmin = false;  // a new registration starts: its first column pass takes no seed from the previous one
     h->mfma_off = false;     // ... and it starts in the dense regime
     h->pred_col = 1;
+    h->eng_reset = true;
     return PRG_OK;
 }
 
@@ -1329,22 +1346,47 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
             PRG_HIP(hipHostMalloc((void**)&h->eng_host, sizeof(EngineDecision), hipHostMallocMapped | hipHostMallocCoherent));
             memset(h->eng_host, 0, sizeof(EngineDecision));
             PRG_HIP(hipHostGetDevicePointer((void**)&h->eng_host_dev, h->eng_host, 0));
-            PRG_HIP(hipMalloc((void**)&h->eng_dev, sizeof(EngineDecision)));
-            PRG_HIP(hipMemsetAsync(h->eng_dev, 0, sizeof(EngineDecision), h->stream));
+            PRG_HIP(hipMalloc((void**)&h->eng_dev, sizeof(EngineDecision) + 2 * sizeof(unsigned long long)));
+            PRG_HIP(hipMemsetAsync(h->eng_dev, 0, sizeof(EngineDecision) + 2 * sizeof(unsigned long long), h->stream));
+            h->eng_work = reinterpret_cast<unsigned long long*>(h->eng_dev + 1);
         }
         EngineArgs ea;
         // size of the problem: the (replicated) source's bounding box or the local target's, whichever is larger - a
         // target shard is a small patch, and every rank should leave the dense regime at the same sigma2
         ea.ext2 = std::max(h->sext2, h->text2);
-        // where the culled vector sweeps overtake the matrix-core ones depends on how small the 128 x 32-point blocks of
-        // the cull tests are next to sigma, i.e. on the point density: measured crossovers at 30k / 100k / 200k points
-        // (tools/mfma_vs_valu.py) move like n^1.8 (column pass) and n^2 above 100k (row pass); dense_bound is the
-        // value at n = 1e5
-        // (n = sqrt(M N_local): a rank that holds a shard of the target has fewer, equally dense columns - its matrix-core
-        // sweeps run out of workgroups earlier; tools/shard_steady.py)
-        const double dens = sqrt((double)h->M * (double)h->N) / 1.0e5;
-        ea.col_bound = h->dense_bound * pow(dens, 1.8);
-        ea.row_bound = 0.05 * h->dense_bound * std::max(1.0, dens * dens);
+        // The matrix-core sweeps stay while they evaluate enough pairs per owned point - counted by the sweeps themselves,
+        // one E-step back, so the switch follows the clouds' shape, their density and the size of this rank's shard
+        // instead of a fit in sigma2.  The count P (pairs) is compared with a two-line cost model of the engines
+        // (tools/mfma_vs_valu.py, profiles/r3_engine_switch_*.log):
+        //   matrix cores:  a workgroup owns 512 points and a segment of `cps` 256-point chunks of the other cloud, tau per
+        //                  chunk; in the dense regime some workgroup still needs its whole segment - cps x tau however
+        //                  much the others cull - and when the grid is deeper than the chip's 768 workgroup slots that
+        //                  workgroup may start late: + (1 - 768 / workgroups) x P x tau / (768 x 512 x 256)
+        //   vector pipe:   the evaluated 128 x 32 blocks are shared out evenly: c_v x P
+        // plus a difference `delta` of the fixed costs.  Leave when the vector pipe is shorter:
+        //   P < (cps x tau + delta) / (c_v - (1 - 768 / workgroups) x tau / (768 x 512 x 256))
+        // with  column pass  tau 12 us    c_v 0.200 ps  delta -15 us
+        //       row pass     tau 19.2 us  c_v 0.233 ps  delta  +8 us   (and never above 50 000 targets per source point)
+        // - per-kernel constants of this chip, the same for every cloud: surface, volume and 10:1:1 clouds of 12k ... 250k
+        // points and 1/2, 1/4, 1/8 shards of 100k all cross over within one EM iteration of what this predicts.
+        static const double r_col_env = getenv("PRG_ENGINE_RCOL") ? atof(getenv("PRG_ENGINE_RCOL")) : 0.0;
+        static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
+        auto leave_below = [](int64_t owned, int64_t streamed, double tau, double delta, double c_v) {
+            const double cps = (double)prg::mfma_chunks_per_seg(owned, streamed, mfma_seg);
+            const double wgs = (double)prg::ceil_div(owned, prg::kMfmaWgPoints) * (double)prg::mfma_planes(owned, streamed, mfma_seg);
+            const double late = std::max(0.0, 1.0 - 768.0 / wgs) * tau / (768.0 * 512.0 * 256.0);
+            return std::max(0.0, cps * tau + delta) / (c_v - late) / (double)owned;  // pairs per owned point
+        };
+        ea.r_col_bound = r_col_env > 0.0 ? r_col_env
+                         : h->dense_bound > 0.0 ? h->dense_bound : leave_below(h->N, h->M, 12.0e-6, -15.0e-6, 0.200e-12);
+        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : std::min(50000.0, leave_below(h->M, h->N, 19.2e-6, 8.0e-6, 0.233e-12));
+        ea.streamed_col = (double)h->M;
+        ea.streamed_row = (double)h->N;
+        ea.owned_col = (double)h->N;
+        ea.owned_row = (double)h->M;
+        ea.work = h->eng_work;
+        ea.reset = h->eng_reset ? 1 : 0;
+        h->eng_reset = false;
         for (int k = 0; k < 6; ++k) ea.tbox[k] = h->tbox[k];
         ea.slot = slot;
         ea.have_colmin = h->have_colmin ? 1 : 0;
@@ -1384,9 +1426,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         if (!mb->dense) h->mfma_off = true;
         static const bool debug_engine = getenv("PRG_DEBUG_ENGINE") != nullptr;
         if (debug_engine)
-            fprintf(stderr, "[engine] sigma2 %.4e nk*ext2 %.1f (col bound %.0f, row bound %.0f) motion %.3e cmax %.3e nk*width %.1f "
+            fprintf(stderr, "[engine] sigma2 %.4e nk*ext2 %.1f pairs per owned point col %.0f (bound %.0f) row %.0f (bound %.0f) motion %.3e cmax %.3e nk*width %.1f "
                             "nk*far2 %.1f have_colmin %d -> col %d (first %d, launched ahead: %s) row %d fine %d\n",
-                    (double)mb->sigma2, (double)mb->nk_ext2, ea.col_bound, ea.row_bound, (double)mb->motion, (double)mb->cmax,
+                    (double)mb->sigma2, (double)mb->nk_ext2, (double)mb->r_col, ea.r_col_bound, (double)mb->r_row, ea.r_row_bound,
+                    (double)mb->motion, (double)mb->cmax,
                     (double)mb->nk_width, (double)mb->nk_far2, (int)h->have_colmin, (int)use_mfma, (int)first_mfma,
                     pred == use_mfma ? "yes" : "NO", (int)row_mfma, (int)fine_cull);
         col_launched = pred == use_mfma && (pred || !use_queue);

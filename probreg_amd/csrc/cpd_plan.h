@@ -17,12 +17,21 @@ struct EngineDecision {
     int fine;      // per-wave tile masks on (some groups of a chunk can be skipped by now)
     int dense;     // 0: the registration has left the dense regime for good (the host stops asking)
     float sigma2, motion, cmax, nk_ext2, nk_width, nk_far2;  // what it was decided from (PRG_DEBUG_ENGINE)
-    unsigned pad[4];
+    // the switch's memory (device copy only carries it from E-step to E-step): pairs the matrix-core sweeps last evaluated
+    // per owned point - targets of the column pass, source points of the row pass - and "the row pass has left them"
+    float r_col, r_row;
+    int row_off;
+    unsigned pad;
 };
 struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
-    double ext2, col_bound, row_bound;
+    double ext2;
+    // matrix-core sweeps while they evaluate at least this many pairs per owned point (see estep_impl)
+    double r_col_bound, r_row_bound;
+    double owned_col, owned_row;  // N_local, M
+    double streamed_col, streamed_row;  // M, N_local: what the count is when nothing is culled (the switch's initial memory)
+    unsigned long long* work;     // [2] (128 x 16) tiles the matrix-core column / row pass of the PREVIOUS E-step evaluated
     float tbox[6];
-    int slot, have_colmin, forced;
+    int slot, have_colmin, forced, reset;
     unsigned seq;
     EngineDecision* dev;
     EngineDecision* host;
@@ -95,7 +104,9 @@ struct prg_cpd {
     float* tchunk = nullptr;    // [Ncap/256][8] box + largest b_n of every 256-point chunk of the target (per E-step)
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
                                 // 2: both sweeps on the matrix cores, always (tests)
-    double dense_bound = 16000.0;  // matrix-core column pass while |kk| * (cloud bounding-box diagonal)^2 is below this (C1: sigma2 > ~4e-4)
+    double dense_bound = 0.0;    // > 0: matrix-core column pass while it evaluates at least this many source points per target (0: estep_impl's model)
+    unsigned long long* eng_work = nullptr;  // [2] tiles evaluated by the matrix-core column / row pass (read + cleared by the decision)
+    bool eng_reset = true;       // the switch's memory is void (new registration, engine mode changed)
     bool mfma_off = false;      // this registration has left the dense regime: no more engine decisions
     EngineDecision* eng_dev = nullptr;   // device copy of the current E-step's decision (guard of the column-pass launches)
     EngineDecision* eng_host = nullptr;  // mapped, coherent host memory: the mailbox the host polls

@@ -46,6 +46,7 @@ void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineD
 void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng);
 void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine);  // rowflag: 64 bytes per 128-row block (touched planes)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
+int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  // 256-point chunks one workgroup walks
 
 // ---- sparse-regime work queue (cpd_sweeps_queue.hip) ----
 constexpr int kQueueChunkGroups = 512;   // streamed groups (of 32 points) one wave of the build pass tests: 8 mask words

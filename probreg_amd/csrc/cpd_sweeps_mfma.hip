@@ -189,7 +189,8 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          int64_t m_total, int64_t n_total,
                                                          const double* __restrict__ params,
                                                          float2* __restrict__ colpart, int64_t ncap,
-                                                         unsigned* __restrict__ wgcount, int first, int fine,
+                                                         unsigned* __restrict__ wgcount, unsigned long long* __restrict__ work,
+                                                         int first, int fine,
                                                          const EngineDecision* __restrict__ guard) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
@@ -326,8 +327,11 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     }
     if (lane == 0) wave_tiles[wv] = tiles_done;
     __syncthreads();
-    if (threadIdx.x == 0)
-        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+    if (threadIdx.x == 0) {
+        const unsigned tiles = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tiles;
+        if (tiles) atomicAdd(work, (unsigned long long)tiles);  // what the next E-step's engine decision goes by
+    }
     float2* __restrict__ out = colpart + (int64_t)blockIdx.y * ncap + n0;
 #pragma unroll
     for (int u = 0; u < kOwn; ++u) {
@@ -356,7 +360,8 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
                                                          const double* __restrict__ params, float* __restrict__ rowpart,
                                                          int64_t mcap, float4* __restrict__ rorig,
                                                          unsigned char* __restrict__ rowflag,
-                                                         unsigned* __restrict__ wgcount, int fine) {
+                                                         unsigned* __restrict__ wgcount, unsigned long long* __restrict__ work,
+                                                         int fine) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -470,8 +475,11 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     }
     if (lane == 0) wave_tiles[wv] = tiles_done;
     __syncthreads();
-    if (threadIdx.x == 0)
-        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+    if (threadIdx.x == 0) {
+        const unsigned tiles = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
+        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tiles;
+        if (tiles) atomicAdd(work, (unsigned long long)tiles);  // what the next E-step's engine decision goes by
+    }
     // k_row_moments skips (128-row block, plane) partials that were never touched: neither written nor read
     const bool touched = tiles_done != 0;  // (wave-uniform: this wave's 128 rows)
     if (lane == 0) rowflag[((int64_t)blockIdx.x * 4 + wv) * 64 + blockIdx.y] = touched ? 1 : 0;
@@ -580,9 +588,21 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     const double mo = __uint_as_float(stat[eng.slot]), cmax = __uint_as_float(stat[4 + (eng.slot ^ 1)]), r = sqrt(cmax);
     const double width = r >= mo ? 4.0 * r * mo : (r + mo) * (r + mo);  // of the bracket of a column minimum
     const bool ok = sigma2 > 0.0 && isfinite(sigma2);
-    // where the culled vector sweeps overtake the matrix-core ones depends on how small the 128 x 32-point blocks of the
-    // cull tests are next to sigma, i.e. on the point density (the bounds come from the host: cpd.hip)
-    const bool dense = ok && (eng.forced || nk * eng.ext2 < eng.col_bound);
+    // Which engine?  MEASURED, not predicted from sigma2: the matrix-core sweeps of the previous E-step counted the
+    // (128 x 16) tiles they evaluated; per owned point that is how much of the other cloud still lies within reach.  The
+    // host turns what is known about the two engines into a bound on that number (estep_impl); here the count meets it.
+    // sigma2 only shrinks along a registration, so leaving is for good: the row pass first, the column pass - and with
+    // it the dense regime - later.
+    const EngineDecision prev = *eng.dev;
+    float r_col = eng.reset ? (float)eng.streamed_col : prev.r_col, r_row = eng.reset ? (float)eng.streamed_row : prev.r_row;
+    int row_off = eng.reset ? 0 : prev.row_off;
+    const unsigned long long tc = eng.work[0], tr = eng.work[1];
+    eng.work[0] = 0ull;
+    eng.work[1] = 0ull;
+    if (tc && !eng.reset) r_col = (float)((double)tc * 2048.0 / eng.owned_col);
+    if (tr && !eng.reset) r_row = (float)((double)tr * 2048.0 / eng.owned_row);
+    const bool dense = ok && (eng.forced || r_col >= eng.r_col_bound);
+    if (!(r_row >= eng.r_row_bound)) row_off = 1;
     // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
     // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold
     // (farthest corners of the two bounding boxes: every term of every column is >= 2^-110)
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     const bool first = dense && !eng.have_colmin && isfinite(far2) && nk * far2 < 110.0;
     const bool col = first || (dense && eng.have_colmin && isfinite(cmax) && nk * width < 150.0);
     // the culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
-    const bool row = dense && (eng.forced || nk * eng.ext2 < eng.row_bound);
+    const bool row = dense && (eng.forced || !row_off);
     EngineDecision d;
     d.seq = eng.seq;
     d.col = col ? 1 : 0;
@@ -605,13 +625,14 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     d.dense = dense ? 1 : 0;
     d.sigma2 = (float)sigma2; d.motion = (float)mo; d.cmax = (float)cmax;
     d.nk_ext2 = (float)(nk * eng.ext2); d.nk_width = (float)(nk * width); d.nk_far2 = (float)(nk * far2);
-    d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0u;
+    d.r_col = r_col; d.r_row = r_row; d.row_off = row_off; d.pad = 0u;
     *eng.dev = d;
     // mailbox: payload first, sequence number last, both at system scope
     EngineDecision* hm = eng.host;
     hm->col = d.col; hm->first = d.first; hm->row = d.row; hm->fine = d.fine; hm->dense = d.dense;
     hm->sigma2 = d.sigma2; hm->motion = d.motion; hm->cmax = d.cmax;
     hm->nk_ext2 = d.nk_ext2; hm->nk_width = d.nk_width; hm->nk_far2 = d.nk_far2;
+    hm->r_col = d.r_col; hm->r_row = d.r_row; hm->row_off = d.row_off;
     __threadfence_system();
     __hip_atomic_store(&hm->seq, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -624,7 +645,7 @@ namespace prg {
 // all of them take the same time in the dense regime, so the grid runs in ceil(blocks * S / 768) rounds: S is chosen in
 // [4, 32] to waste the least of the last round (C1: 196 blocks x 19 segments = 4.85 rounds; the first version's 196 x 5 =
 // 1.28 rounds lost 36 %); a segment holds at most 64 chunks (one ballot of box tests).
-static int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S) {
+int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S) {
     const int64_t chunks = ceil_div(streamed_points, kChunk);
     if (S <= 0) {
         const int64_t blocks = ceil_div(owned_points, kWgPoints), slots = 768;
@@ -672,7 +693,7 @@ void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineD
                                                    reinterpret_cast<const BoxMeta*>(h->zmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
                                                    h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
-                                                   h->colpart, h->Ncap, h->wgcount, first ? 1 : 0, fine ? 1 : 0, guard);
+                                                   h->colpart, h->Ncap, h->wgcount, h->eng_work, first ? 1 : 0, fine ? 1 : 0, guard);
     h->wg_col = (int64_t)grid.x * grid.y;
     h->wg_col_pairs = 128.0 * 16.0;  // counted unit: one wave's 128 points x one 16-point tile
     h->dense_pairs_col = 0.0;
@@ -685,7 +706,8 @@ void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine) {
     k_rowpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const BoxMeta*>(h->zmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->tmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->tchunk), cps, h->N, h->M, h->params,
-                                                   h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap, fine ? 1 : 0);
+                                                   h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap, h->eng_work + 1,
+                                                   fine ? 1 : 0);
     h->wg_row = (int64_t)grid.x * grid.y;
     h->wg_row_pairs = 128.0 * 16.0;
     h->dense_pairs_row = 0.0;

@@ -66,8 +66,9 @@ class CpdPlan(object):
         check(lib.prg_cpd_set_options(self._h, int(sort_source), int(sort_target), int(cull)))
 
     def set_dense_engine(self, mode=1, bound=0.0):
-        """0: vector-pipe sweeps only, 1: matrix-core sweeps in the dense regime (default), 2: both sweeps on the matrix
-        cores always (prg_cpd_set_dense_engine)."""
+        """0: vector-pipe sweeps only, 1: matrix-core sweeps while they are the faster engine (default; decided on the device
+        from the pairs the previous E-step evaluated), 2: both sweeps on the matrix cores always.  ``bound`` > 0: leave the
+        matrix-core column pass below that many evaluated source points per target (prg_cpd_set_dense_engine)."""
         check(lib.prg_cpd_set_dense_engine(self._h, int(mode), float(bound)))
 
     def last_estep_engine(self):
