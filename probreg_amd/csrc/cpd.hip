@@ -1366,8 +1366,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // plus a difference `delta` of the fixed costs.  Leave when the vector pipe is shorter:
         //   P < (cps x tau + delta) / (c_v - (1 - 768 / workgroups) x tau / (768 x 512 x 256))
         // with  column pass  tau 12 us    c_v 0.200 ps  delta -15 us
-        //       row pass     tau 19.2 us  c_v 0.233 ps  delta  +8 us   (and never above 50 000 targets per source point)
-        // - per-kernel constants of this chip, the same for every cloud: surface, volume and 10:1:1 clouds of 12k ... 250k
+        //       row pass     tau 19.2 us  c_v 0.233 ps  delta  +8 us
+        // - per-kernel constants of this chip, the same for every cloud: surface, volume and 10:1:1 clouds of 12k ... 400k
         // points and 1/2, 1/4, 1/8 shards of 100k all cross over within one EM iteration of what this predicts.
         static const double r_col_env = getenv("PRG_ENGINE_RCOL") ? atof(getenv("PRG_ENGINE_RCOL")) : 0.0;
         static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
@@ -1379,9 +1379,19 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         };
         ea.r_col_bound = r_col_env > 0.0 ? r_col_env
                          : h->dense_bound > 0.0 ? h->dense_bound : leave_below(h->N, h->M, 12.0e-6, -15.0e-6, 0.200e-12);
-        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : std::min(50000.0, leave_below(h->M, h->N, 19.2e-6, 8.0e-6, 0.233e-12));
+        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : leave_below(h->M, h->N, 19.2e-6, 8.0e-6, 0.233e-12);
         ea.streamed_col = (double)h->M;
         ea.streamed_row = (double)h->N;
+        // the first sweep over the work queue after the matrix cores has no previous build to size its units from: about
+        // `bound` pairs per owned point are needed then - 32 groups per unit unless that overfills the queue (>= 250k points)
+        auto first_unit = [](double bound, int64_t owned, int64_t streamed) {
+            const double groups = std::min(bound, (double)streamed) * (double)owned / (128.0 * prg::kGroup);
+            int q = 32;
+            while (groups / q > 0.75 * prg::kQueueMaxUnits && q < 256) q *= 2;
+            return q;
+        };
+        h->q_first_col = first_unit(ea.r_col_bound, h->N, h->M);
+        h->q_first_row = first_unit(ea.r_row_bound, h->M, h->N);
         ea.owned_col = (double)h->N;
         ea.owned_row = (double)h->M;
         ea.work = h->eng_work;
@@ -1444,7 +1454,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const bool col_queue = !col_launched && use_queue, row_queue = !row_mfma && use_queue;
     if (col_launched) {
     } else if (col_queue)
-        PRG_TRY(prg::launch_colpass_queue(h, cull_seed, h->qcol_live ? 0 : 32));
+        PRG_TRY(prg::launch_colpass_queue(h, cull_seed, h->qcol_live ? 0 : h->q_first_col));
     else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);
     else if (ra < 0)
@@ -1461,7 +1471,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (row_mfma)
         prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap), fine_cull);
     else if (row_queue)
-        PRG_TRY(prg::launch_rowpass_queue(h, h->qrow_live ? 0 : 32));
+        PRG_TRY(prg::launch_rowpass_queue(h, h->qrow_live ? 0 : h->q_first_row));
     else if (use_cull)
         prg::launch_rowpass_cull(h, SB, segB);
     else if (rb < 0)

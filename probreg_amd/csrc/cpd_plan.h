@@ -42,7 +42,7 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
 struct SweepQueue {
     unsigned long long* masks = nullptr;  // [nblocks][nchunk][8] one bit per streamed group of 32: needed or not
     int2* chunk = nullptr;            // [nblocks][nchunk] (first slot, units) of every chunk of 512 groups
-    int2* units = nullptr;            // [<= max units] (block, first group | count << 26), in append order
+    int2* units = nullptr;            // [<= max units] (block, first group | count << 22), in append order
     int* ctrl = nullptr;              // counters, see k_queue_build
     unsigned* ucount = nullptr;       // [units] (128 x 32) blocks each unit evaluated (prg_cpd_pair_counts)
     int64_t cap_blocks = 0, cap_units = 0;
@@ -106,6 +106,7 @@ struct prg_cpd {
                                 // 2: both sweeps on the matrix cores, always (tests)
     double dense_bound = 0.0;    // > 0: matrix-core column pass while it evaluates at least this many source points per target (0: estep_impl's model)
     unsigned long long* eng_work = nullptr;  // [2] tiles evaluated by the matrix-core column / row pass (read + cleared by the decision)
+    int q_first_col = 32, q_first_row = 32;  // groups per unit of the first queue sweep after a matrix-core one
     bool eng_reset = true;       // the switch's memory is void (new registration, engine mode changed)
     bool mfma_off = false;      // this registration has left the dense regime: no more engine decisions
     EngineDecision* eng_dev = nullptr;   // device copy of the current E-step's decision (guard of the column-pass launches)

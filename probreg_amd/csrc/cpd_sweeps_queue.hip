@@ -40,6 +40,7 @@ constexpr int kBuildWaves = 16;                       // waves (= chunks) per wo
 #ifndef PRG_QMIN
 #define PRG_QMIN 16
 #endif
+constexpr int kQmax = 256;                             // largest unit: large clouds early in the sparse regime (250k points: Q = 32 overflowed the queue above 20 % needed groups)
 constexpr int kQmin = PRG_QMIN;                       // smallest unit (groups): fewer, larger partial results for the consumers
 
 __device__ __forceinline__ f2 splat(float a) { return (f2){a, a}; }
@@ -60,9 +61,9 @@ __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&
     return d2;
 }
 
-// unit = (owned block, first group | count << 26): `count` needed groups starting at bit `first` of the block's need-mask
+// unit = (owned block, first group | count << 22): `count` needed groups starting at bit `first` of the block's need-mask
 // (count 0: every needed group up to the end of the chunk - the coarse unit of an overfull queue)
-__device__ __forceinline__ int2 make_unit(int b, int first_group, int count) { return make_int2(b, first_group | (count << 26)); }
+__device__ __forceinline__ int2 make_unit(int b, int first_group, int count) { return make_int2(b, first_group | (int)((unsigned)count << 22)); }
 
 // ---- 1. need-masks and units in one pass ------------------------------------------------------------------------------------
 // grid = (owned blocks of 128 points, ceil(chunks / 16)); one WAVE per (block, chunk of 512 streamed groups).
@@ -85,12 +86,24 @@ __global__ __launch_bounds__(kBuildWaves * 64) void k_queue_build(const GroupMet
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t b = blockIdx.x;
     const int c = blockIdx.y * kBuildWaves + wv;
-    // groups per unit: 8 while the queue stays within what the chip has wave slots for, doubled / halved from there
+    // groups per unit: the previous build's, doubled / halved until the queue holds about `target_units` (kQmin ... kQmax)
     int Q = ctrl[3] < kQmin ? kQmin : ctrl[3];
     const int prev_units = ctrl[2];
     if (q_init) Q = q_init;  // (first sweep over the queue after a dense engine: nothing to adapt from)
-    else if (prev_units > 2 * target_units && Q < 32) Q *= 2;
-    else if (prev_units < target_units / 2 && Q > kQmin) Q /= 2;
+    else {
+        // prev_units counts what the previous build WANTED to append (also past the end of an overfull queue).  Up to 32
+        // groups per unit the size follows the tuned band around `target_units`; beyond, units only grow as far as it takes
+        // to keep the queue from overflowing into coarse units (large clouds early in the sparse regime) and shrink back as
+        // soon as it fits.
+        const int guard = cap_soft / 4 * 3;
+        int want = prev_units;
+        while (Q > 32 && 2 * want <= guard) Q /= 2, want *= 2;
+        if (Q <= 32) {
+            while (want > 2 * target_units && Q < 32) Q *= 2, want /= 2;
+            while (want < target_units / 2 && Q > kQmin) Q /= 2, want *= 2;
+        }
+        while (want > guard && Q < kQmax) Q *= 2, want /= 2;
+    }
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) ctrl[6] = Q;
     unsigned long long word[kChunkWords];  // the chunk's need-mask (wave-uniform)
     int needed = 0;
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_queue(const float4* __restri
             f2 p1 = splat(0.f), ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), e = splat(0.f);
             int ngrp = 0;
             UnitWalk walk;
-            walk.init(masks + (int64_t)b * nwords, un.y & 0x3FFFFFF, (int)((unsigned)un.y >> 26), lane);
+            walk.init(masks + (int64_t)b * nwords, un.y & 0x3FFFFF, (int)((unsigned)un.y >> 22), lane);
             int g = walk.next();
             if (g >= 0) {
                 const Quad* __restrict__ tp = reinterpret_cast<const Quad*>(tgt4);
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_queue(const float4* __restri
             f2 run = splat(INFINITY), off = splat(INFINITY), sm = splat(0.f);
             int ngrp = 0;
             UnitWalk walk;
-            walk.init(masks + (int64_t)b * nwords, un.y & 0x3FFFFFF, (int)((unsigned)un.y >> 26), lane);
+            walk.init(masks + (int64_t)b * nwords, un.y & 0x3FFFFF, (int)((unsigned)un.y >> 22), lane);
             int g = walk.next();
             if (g >= 0) {
                 const Quad* __restrict__ zp = reinterpret_cast<const Quad*>(z4);
@@ -402,7 +415,7 @@ static int build_queue(prg_cpd* h, SweepQueue& q, int64_t owned, int64_t streame
     const int64_t nblocks = ceil_div(owned, 128);
     const int64_t ngroups = ceil_div(streamed, kGroup);
     const int nchunk = queue_chunks(streamed);
-    PRG_REQUIRE(ngroups < ((int64_t)1 << 26) && nblocks < ((int64_t)1 << 31) && queue_max_units(owned, streamed) < ((int64_t)1 << 30),
+    PRG_REQUIRE(ngroups < ((int64_t)1 << 22) && nblocks < ((int64_t)1 << 31) && queue_max_units(owned, streamed) < ((int64_t)1 << 30),
                 PRG_ERR_INVALID, "prg_cpd_estep: cloud too large for the sweep queue");
     PRG_TRY(ensure_queue(h, q, nblocks, nchunk, queue_max_units(owned, streamed)));
     q.nblocks = nblocks;

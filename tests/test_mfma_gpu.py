@@ -116,3 +116,50 @@ def test_forced_matrix_core_engine_through_a_whole_dense_phase_2d():
     assert rel_err(res.transformation.b, p["b"]) < TOL_TF
     assert np.max(np.abs(res.transformation.t - p["t"])) < TOL_TF
     assert abs(res.sigma2 - s2) <= TOL_SIGMA2 * s2
+
+
+def test_engine_switch_goes_by_pair_counts_on_a_non_surface_cloud():
+    """The switch out of the matrix-core sweeps is taken from what those sweeps evaluated one E-step back, not
+    from sigma2: on a 10:1:1 box filled uniformly (no surface anywhere) it still starts on the matrix cores, the row pass
+    leaves no later than the column pass, nothing is re-entered, the evaluated pairs fall monotonically while the matrix
+    cores run, and the registration matches the fp64 oracle's trajectory."""
+    from oracle import cpd_c, cpd_numpy as co
+    from probreg_amd import _lib, cpd, synthetic
+
+    n, k = 32768, 18
+    rng = np.random.default_rng(11)
+    src = rng.random((n, 3)) * np.array([10.0, 1.0, 1.0])
+    tgt = (src @ synthetic.rot_zx(12.0, 5.0).T + np.array([0.05, -0.03, 0.02]) + 0.004 * rng.standard_normal((n, 3)))[rng.permutation(n)]
+    src = src.astype(np.float32).astype(np.float64)
+    tgt = tgt.astype(np.float32).astype(np.float64)
+    reg = cpd.RigidCPD(src)
+    reg._initialize(tgt)
+    plan = reg._plan
+    plan.set_dense_engine(1)
+    engines, pairs = [], []
+    for _ in range(k):
+        plan.estep(0.0)
+        engines.append(plan.last_estep_engines())
+        pairs.append(plan.pair_counts())
+        plan.mstep(_lib.PRG_TF_RIGID, True)
+    res = reg._result_from_params(plan.get_params())
+    col = [e[0] for e in engines]
+    row = [e[1] for e in engines]
+    assert engines[0] == (1, 1)
+    assert engines[-1] == (0, 0)                      # sigma2 ~ 0.03 by now: a ball of 13 sigma holds a fraction of the box
+    assert 0 in col and 0 in row
+    col_off, row_off = col.index(0), row.index(0)
+    assert 2 <= row_off <= col_off                    # dense for a while; the row pass leaves first
+    assert all(e == 0 for e in col[col_off:]) and all(e == 0 for e in row[row_off:])
+    on = [p[0] for p, e in zip(pairs, col) if e == 1]
+    assert all(b <= a * 1.02 for a, b in zip(on, on[1:]))     # fewer and fewer pairs within reach
+    assert on[-1] < 0.9 * on[0]                       # it left because pairs were being culled, not on the first dense E-step
+    params = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
+    sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
+    for _ in range(k):
+        es = co.EstepResult(*cpd_c.expectation_step(co.transform("rigid", params, src), tgt, sigma2, 0.0))
+        params, sigma2, q = co.mstep_rigid(src, tgt, es)
+    assert rel_err(res.transformation.rot, params["rot"]) < TOL_TF
+    assert np.max(np.abs(res.transformation.t - params["t"])) < TOL_TF
+    assert abs(res.transformation.scale - params["scale"]) < TOL_TF * params["scale"]
+    assert abs(res.sigma2 - sigma2) <= TOL_SIGMA2 * sigma2

@@ -55,9 +55,11 @@ for it, state in enumerate(states[:-1], 1):
     for eng in (0, 2, 1):
         plan.set_dense_engine(eng)
         plan.set_params(state)
-        if eng == 1:  # the switch goes by what the previous E-step's sweeps counted (the first one after a mode change
-            for _ in range(3):  # has nothing and takes the matrix cores, the second decides): steady state = fourth
-                plan.estep(0.0)
+        # steady state of every mode: the switch goes by what the previous E-step's sweeps counted (the first E-step after
+        # a mode change has nothing and takes the matrix cores, the second decides), and the work queue of the
+        # vector-pipe sweeps sizes its units from the previous build
+        for _ in range({0: 1, 2: 0, 1: 3}[eng]):
+            plan.estep(0.0)
         ms = plan.estep_timed(0.0)
         used = plan.last_estep_engines()
         pc = plan.pair_counts()

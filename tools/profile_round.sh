@@ -43,7 +43,16 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_
   rocprofv3 --pmc $pass --kernel-trace -d $out/c3_$name -o b -- $c3 > $out/c3_$name.log 2>&1
 done
 sum --pmc $(db $out/c3_FETCH_SIZE) $(db $out/c3_WRITE_SIZE) $(db $out/c3_SQ_INSTS_VALU) > $out/${tag}_nonrigid_50k_pmc.txt
+# measured logs, no profiler: both engines and the switch along registrations (surface / volume / 10:1:1, sizes, shards), the
+# 8-rank window of E-steps, whole registrations
+for cfg in "100000 30 surface 1" "12000 30 surface 1" "30000 30 surface 1" "50000 30 surface 1" "250000 30 surface 1" "400000 26 surface 1" \
+           "100000 120 volume 1" "100000 72 aniso 1" "100000 30 surface 8" "100000 30 surface 4" "100000 30 surface 2"; do
+  set -- $cfg
+  python tools/mfma_vs_valu.py $1 $2 $3 $4 2>&1 | grep -v "amdgpu.ids" > $out/${tag}_engine_switch_$3_$1_w$4.log
+done
+python tools/shard_window.py 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window.log
+python tools/time_registration.py 2>&1 | grep -v "amdgpu.ids" > $out/${tag}_whole_registrations_100k.log
 ls -la $out/*.txt
-# afterwards, locally: cp gpurun_out/prof_$tag/${tag}_*.txt profiles/ && python tools/pmc_traffic_update.py $tag
+# afterwards, locally: cp gpurun_out/prof_$tag/${tag}_* profiles/ && python tools/pmc_traffic_update.py $tag
 # keep the merged output small: the databases stay on the box
 rm -rf $out/kt_default $out/kt_c1 $out/c1_FETCH_SIZE $out/c1_WRITE_SIZE $out/c1_SQ_INSTS_VALU $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c4_SQ_INSTS_VALU $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE $out/c3_SQ_INSTS_VALU 2>/dev/null
