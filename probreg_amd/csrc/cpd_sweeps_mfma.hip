@@ -39,6 +39,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr double kLog2e = 1.4426950408889634;
@@ -156,12 +157,12 @@ __device__ __forceinline__ void stage_point(float* __restrict__ buf, int p, cons
     a[1 * 16 + j] = slots_streamed(split3(dy));
     a[2 * 16 + j] = slots_streamed(split3(dz));
     a[3 * 16 + j] = (bf16x8){one, one, one, z, z, z, z, z};
-    float* f = tile + 256 + j;
-    f[0] = fmaf(kk, sq, v.w);
-    f[16] = dx;
-    f[32] = dy;
-    f[48] = dz;
-    f[64] = sq;
+    // f32 planes behind the operands: c[16], then (dx, dy)[16] and (dz, |d|^2)[16] as PAIRS - the row pass multiplies both
+    // halves of a pair by the same P in one packed fma
+    float* f = tile + 256;
+    f[j] = fmaf(kk, sq, v.w);
+    *reinterpret_cast<float2*>(f + 16 + 2 * j) = make_float2(dx, dy);
+    *reinterpret_cast<float2*>(f + 48 + 2 * j) = make_float2(dz, sq);
 }
 
 // B operand of an owned point (lane l: slots of K group l / 16 for point l % 16): -2kk (x - o) per coordinate, and the
@@ -382,13 +383,14 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     }
     const int k = lane >> 4, j = lane & 15;
     bf16x8 bz[kOwn];
-    float p1[kOwn], ux[kOwn], uy[kOwn], uz[kOwn], e[kOwn];
+    // per owned tile: (sum P over targets 4k, 4k+2 | 4k+1, 4k+3), (sum P dx, sum P dy), (sum P dz, sum P |d|^2) - packed pairs
+    f32x2 pp[kOwn], uxy[kOwn], uze[kOwn];
 #pragma unroll
     for (int t = 0; t < kOwn; ++t) {
         const float4 z = z4[m0 + 16 * t + j];
         const float zx = z.x - o.x, zy = z.y - o.y, zz = z.z - o.z;
         bz[t] = owned_operand(k, kk, zx, zy, zz, kk * fmaf(zz, zz, fmaf(zy, zy, zx * zx)));
-        p1[t] = ux[t] = uy[t] = uz[t] = e[t] = 0.f;
+        pp[t] = uxy[t] = uze[t] = (f32x2){0.f, 0.f};
     }
     const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
     const int64_t nchunks = (n_total + kChunk - 1) / kChunk;
@@ -421,18 +423,22 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
             // tile_step: accumulator d of tile tb (operands a1, cx) -> sums; leaves the first accumulator of the next tile
             auto tile_step = [&](f32x4& d, const float* __restrict__ tb, const bf16x8 a1, const f32x4 cx, const bf16x8 a1n,
                                  const f32x4 cxn) {
-                const f32x4 xx = *reinterpret_cast<const f32x4*>(tb + 272 + 4 * k), xy = *reinterpret_cast<const f32x4*>(tb + 288 + 4 * k),
-                            xz = *reinterpret_cast<const f32x4*>(tb + 304 + 4 * k), xs = *reinterpret_cast<const f32x4*>(tb + 320 + 4 * k);
+                // this lane's four targets 4k .. 4k+3: (dx, dy) and (dz, |d|^2) pairs
+                const f32x4 a01 = *reinterpret_cast<const f32x4*>(tb + 272 + 8 * k), a23 = *reinterpret_cast<const f32x4*>(tb + 276 + 8 * k),
+                            b01 = *reinterpret_cast<const f32x4*>(tb + 304 + 8 * k), b23 = *reinterpret_cast<const f32x4*>(tb + 308 + 8 * k);
+                const f32x2 xy0 = {a01[0], a01[1]}, xy1 = {a01[2], a01[3]}, xy2 = {a23[0], a23[1]}, xy3 = {a23[2], a23[3]};
+                const f32x2 zs0 = {b01[0], b01[1]}, zs1 = {b01[2], b01[3]}, zs2 = {b23[0], b23[1]}, zs3 = {b23[2], b23[3]};
 #pragma unroll
                 for (int u = 0; u < kOwn; ++u) {
                     const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[u + 1], cx, 0, 0, 0)
                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bz[0], cxn, 0, 0, 0);
                     const float q0 = exp2r(d[0]), q1 = exp2r(d[1]), q2 = exp2r(d[2]), q3 = exp2r(d[3]);
-                    p1[u] += (q0 + q1) + (q2 + q3);
-                    ux[u] = fmaf(q3, xx[3], fmaf(q2, xx[2], fmaf(q1, xx[1], fmaf(q0, xx[0], ux[u]))));
-                    uy[u] = fmaf(q3, xy[3], fmaf(q2, xy[2], fmaf(q1, xy[1], fmaf(q0, xy[0], uy[u]))));
-                    uz[u] = fmaf(q3, xz[3], fmaf(q2, xz[2], fmaf(q1, xz[1], fmaf(q0, xz[0], uz[u]))));
-                    e[u] = fmaf(q3, xs[3], fmaf(q2, xs[2], fmaf(q1, xs[1], fmaf(q0, xs[0], e[u]))));
+                    // the contraction in packed fp32: 8 v_pk_fma_f32 + 2 v_pk_add_f32 where 16 fma + 4 add stood
+                    const f32x2 s0 = {q0, q0}, s1 = {q1, q1}, s2 = {q2, q2}, s3 = {q3, q3};
+                    pp[u] += (f32x2){q0, q1};
+                    pp[u] += (f32x2){q2, q3};
+                    uxy[u] = __builtin_elementwise_fma(s3, xy3, __builtin_elementwise_fma(s2, xy2, __builtin_elementwise_fma(s1, xy1, __builtin_elementwise_fma(s0, xy0, uxy[u]))));
+                    uze[u] = __builtin_elementwise_fma(s3, zs3, __builtin_elementwise_fma(s2, zs2, __builtin_elementwise_fma(s1, zs1, __builtin_elementwise_fma(s0, zs0, uze[u]))));
                     d = dn;
                 }
             };
@@ -487,7 +493,8 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
         float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
 #pragma unroll
         for (int u = 0; u < kOwn; ++u) {
-            const float a0 = xor_sum(p1[u]), a1s = xor_sum(ux[u]), a2 = xor_sum(uy[u]), a3 = xor_sum(uz[u]), a4 = xor_sum(e[u]);
+            const float a0 = xor_sum(pp[u][0] + pp[u][1]), a1s = xor_sum(uxy[u][0]), a2 = xor_sum(uxy[u][1]), a3 = xor_sum(uze[u][0]),
+                        a4 = xor_sum(uze[u][1]);
             if (lane < 16) {
                 out[16 * u + lane] = a0;
                 out[mcap + 16 * u + lane] = a1s;
