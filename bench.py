@@ -46,6 +46,8 @@ F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64
 # The same count is charged to the dense-regime iterations that take the exponent (8 of the 21 / 14 flop) from the bf16
 # matrix pipe instead (csrc/cpd_sweeps_mfma.hip): `frac` is useful pair-flops per second over the fp32 vector peak.
 FLOP_ROW, FLOP_COL = 21.0, 14.0
+# the matrix-core row pass without its residual sums (prg_cpd_last_estep_lean): one fma per pair less
+FLOP_ROW_LEAN = 19.0
 # SURVEY.md 8(d)'s own count for the two-sweep fused form (scale as a separate multiplication, no min tracking): 20 / 11
 FLOP_ROW_SURVEY, FLOP_COL_SURVEY = 20.0, 11.0
 
@@ -259,7 +261,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     # the timed region walked).
     reg._restart()
     acc, first, last = {}, None, None
-    pairs_row = pairs_col = 0.0
+    pairs_row = pairs_col = flop_row = 0.0
     first_pairs = last_pairs = None
     per_iteration = []
     for it in range(steps):
@@ -267,12 +269,14 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         ms = plan.estep_timed(0.0)
         pc, pr = plan.pair_counts()
         ce, re_ = plan.last_estep_engines()
-        per_iteration.append((it, s2_it, ce, re_, pc, pr, ms["colpass"], ms["rowpass"], ms["total"]))
+        fr = FLOP_ROW_LEAN if plan.last_estep_lean() else FLOP_ROW
+        flop_row += pr * fr
+        per_iteration.append((it, s2_it, ce, re_, pc, pr, ms["colpass"], ms["rowpass"], ms["total"], fr))
         reg._all_reduce_moments(plan)
         plan.mstep(kind_id, True)
         if first is None:
-            first, first_pairs = dict(ms), (pc, pr)
-        last, last_pairs = dict(ms), (pc, pr)
+            first, first_pairs, first_fr = dict(ms), (pc, pr), fr
+        last, last_pairs, last_fr = dict(ms), (pc, pr), fr
         pairs_col += pc
         pairs_row += pr
         for k, v in ms.items():
@@ -284,25 +288,26 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
             f.write("# %s: E-step sweeps of the timed window, HIP events on the plan's stream (prg_cpd_estep_timed) and the device's "
                     "counters of evaluated pairs (prg_cpd_pair_counts)\n" % desc)
             f.write("# engine 1 = matrix cores (bf16x3 exponent, csrc/cpd_sweeps_mfma.hip), 0 = culled vector-pipe sweeps; "
-                    "frac = pairs x flop/pair / ms / %.1f TFLOP/s (flop/pair: row %g, column %g)\n"
-                    % (VALU_F32_PEAK_TFLOPS, FLOP_ROW, FLOP_COL))
-            f.write("%3s %12s %4s %4s %14s %14s %9s %9s %9s %8s %8s\n" % ("it", "sigma2", "col", "row", "pairs_col", "pairs_row",
-                                                                       "ms_col", "ms_row", "ms_estep", "frac_col", "frac_row"))
-            for (it, s2_it, ce, re_, pc, pr, mc, mr, mt) in per_iteration:
-                f.write("%3d %12.5e %4d %4d %14.0f %14.0f %9.4f %9.4f %9.4f %8.3f %8.3f\n" % (
-                    it, s2_it, ce, re_, pc, pr, mc, mr, mt, pc * FLOP_COL / (mc * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
-                    pr * FLOP_ROW / (mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
+                    "frac = pairs x flop/pair / ms / %.1f TFLOP/s (flop/pair: row %g - %g where the matrix-core row pass ran "
+                    "without its residual sums, column `fr` - column %g)\n"
+                    % (VALU_F32_PEAK_TFLOPS, FLOP_ROW, FLOP_ROW_LEAN, FLOP_COL))
+            f.write("%3s %12s %4s %4s %3s %14s %14s %9s %9s %9s %8s %8s\n" % ("it", "sigma2", "col", "row", "fr", "pairs_col", "pairs_row",
+                                                                           "ms_col", "ms_row", "ms_estep", "frac_col", "frac_row"))
+            for (it, s2_it, ce, re_, pc, pr, mc, mr, mt, fr) in per_iteration:
+                f.write("%3d %12.5e %4d %4d %3.0f %14.0f %14.0f %9.4f %9.4f %9.4f %8.3f %8.3f\n" % (
+                    it, s2_it, ce, re_, fr, pc, pr, mc, mr, mt, pc * FLOP_COL / (mc * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
+                    pr * fr / (mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
             tot_r = sum(r[5] for r in per_iteration)
+            tot_fl = sum(r[5] * r[9] for r in per_iteration)
             tot_mr = sum(r[7] for r in per_iteration)
-            f.write("# window: row pass %.6e pairs in %.4f ms -> %.2f TFLOP/s = frac %.4f\n" % (
-                tot_r, tot_mr, tot_r * FLOP_ROW / (tot_mr * 1e-3) / 1e12,
-                tot_r * FLOP_ROW / (tot_mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
+            f.write("# window: row pass %.6e pairs, %.6e flop in %.4f ms -> %.2f TFLOP/s = frac %.4f\n" % (
+                tot_r, tot_fl, tot_mr, tot_fl / (tot_mr * 1e-3) / 1e12, tot_fl / (tot_mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
 
     m_pts, n_loc = plan.m, plan.n
     row_s_total, col_s_total = acc["rowpass"] * 1e-3 * steps, acc["colpass"] * 1e-3 * steps
-    row_tf = pairs_row * FLOP_ROW / row_s_total / 1e12
+    row_tf = flop_row / row_s_total / 1e12
     col_tf = pairs_col * FLOP_COL / col_s_total / 1e12
-    dense_row_tf = first_pairs[1] * FLOP_ROW / (first["rowpass"] * 1e-3) / 1e12
+    dense_row_tf = first_pairs[1] * first_fr / (first["rowpass"] * 1e-3) / 1e12
     dense_col_tf = first_pairs[0] * FLOP_COL / (first["colpass"] * 1e-3) / 1e12
     # SURVEY.md 8(d) figure kept beside it: algorithmic bytes of the reference's formulation at fp32 (P written once
     # by the column pass, read once by the row pass) over the measured time - an EFFECTIVE rate, not a roofline
@@ -328,15 +333,19 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         "traffic": _pmc_traffic(workload, "rowpass_hbm_bytes_per_launch"),
         "traffic_source": "profiles/pmc_traffic.json - STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                           "tools/profile_round.sh, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; not measured in this run",
-        "how": "flop = pairs the kernel evaluated (per-workgroup device counters, prg_cpd_pair_counts) x %g flop/pair; "
-               "time = HIP events on the plan's stream; both summed over the %d timed-window iterations" % (FLOP_ROW, steps),
-        "flop_per_pair": {"isa_count": {"row": FLOP_ROW, "col": FLOP_COL}, "survey_8d": {"row": FLOP_ROW_SURVEY, "col": FLOP_COL_SURVEY},
+        "how": "flop = pairs the kernel evaluated (per-workgroup device counters, prg_cpd_pair_counts) x %g flop/pair (%g in the "
+               "iterations whose matrix-core row pass ran without its residual sums, prg_cpd_last_estep_lean); "
+               "time = HIP events on the plan's stream; both summed over the %d timed-window iterations" % (FLOP_ROW, FLOP_ROW_LEAN, steps),
+        "flop_per_pair": {"isa_count": {"row": FLOP_ROW, "row_lean": FLOP_ROW_LEAN, "col": FLOP_COL,
+                                        "row_window_average": flop_row / max(pairs_row, 1.0)},
+                          "survey_8d": {"row": FLOP_ROW_SURVEY, "col": FLOP_COL_SURVEY},
                           "note": "the matrix-core engine takes 8 of these flop per pair (the exponent) from the bf16 matrix "
                                   "pipe; frac charges them all to the fp32 vector peak = useful pair-flops per second"},
-        "frac_with_survey_flops": row_tf * FLOP_ROW_SURVEY / FLOP_ROW / VALU_F32_PEAK_TFLOPS,
+        "frac_with_survey_flops": pairs_row * FLOP_ROW_SURVEY / row_s_total / 1e12 / VALU_F32_PEAK_TFLOPS,
         "matrix_core_share": {"column_pass_iterations": sum(1 for r in per_iteration if r[2]) / float(steps),
                               "row_pass_iterations": sum(1 for r in per_iteration if r[3]) / float(steps),
-                              "row_pass_pairs": sum(r[5] for r in per_iteration if r[3]) / max(pairs_row, 1.0)},
+                              "row_pass_pairs": sum(r[5] for r in per_iteration if r[3]) / max(pairs_row, 1.0),
+                              "row_pass_lean_iterations": sum(1 for r in per_iteration if r[9] == FLOP_ROW_LEAN) / float(steps)},
         "avg_launch_ms": acc["rowpass"],
         "pairs_evaluated_per_launch": pairs_row / steps,
         "pairs_total_per_launch": float(m_pts) * n_loc,
@@ -348,7 +357,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
                                      "frac": dense_col_tf / VALU_F32_PEAK_TFLOPS}},
         "late_regime": {"what": "iteration %d of the window" % (steps - 1),
                         "rowpass": {"ms": last["rowpass"], "pairs": last_pairs[1],
-                                    "frac": last_pairs[1] * FLOP_ROW / (last["rowpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS},
+                                    "frac": last_pairs[1] * last_fr / (last["rowpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS},
                         "colpass": {"ms": last["colpass"], "pairs": last_pairs[0],
                                     "frac": last_pairs[0] * FLOP_COL / (last["colpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS}},
         "colpass": {"achieved": col_tf, "frac": col_tf / VALU_F32_PEAK_TFLOPS, "avg_launch_ms": acc["colpass"],
@@ -423,7 +432,7 @@ def bench_nonrigid(workload, steps, warmup, dense_compare=True):
     t_lr = plan.nonrigid_apply()
     out = _base("EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, steps, warmup, desc, "f32 E-step / f64 M-step")
     out["config"]["window"] = "EM iterations 0..%d of the registration (state reset after the warm-up steps)" % (steps - 1)
-    row_tf = row_pairs * FLOP_ROW / (ms["rowpass"] * 1e-3) / 1e12
+    row_tf = row_pairs * (FLOP_ROW_LEAN if plan.last_estep_lean() else FLOP_ROW) / (ms["rowpass"] * 1e-3) / 1e12
     out["roofline"] = {"bound": "valu", "kernel": "k_rowpass (E-step sweep 2 over all M x N pairs; the M-step is no longer "
                        "the dominant kernel: G = F F^T, rank %d)" % rank,
                        "achieved": row_tf, "peak": VALU_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": row_tf / VALU_F32_PEAK_TFLOPS,

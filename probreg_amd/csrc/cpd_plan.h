@@ -21,7 +21,7 @@ struct EngineDecision {
     // per owned point - targets of the column pass, source points of the row pass - and "the row pass has left them"
     float r_col, r_row;
     int row_off;
-    unsigned pad;
+    int lean;      // 1: the matrix-core row pass runs without its residual sums (sigma2 large enough, see k_chunk_meta_bbox)
 };
 struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double ext2;
@@ -29,6 +29,9 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double r_col_bound, r_row_bound;
     double owned_col, owned_row;  // N_local, M
     double streamed_col, streamed_row;  // M, N_local: what the count is when nothing is culled (the switch's initial memory)
+    const double* tsum;           // (sum x, sum y, sum z, sum |x|^2) of the local target
+    double lean_factor;           // lean row pass while mean |x|^2 / (sigma2 D) <= this
+    int dim;
     unsigned long long* work;     // [2] (128 x 16) tiles the matrix-core column / row pass of the PREVIOUS E-step evaluated
     float tbox[6];
     int slot, have_colmin, forced, reset;
@@ -105,6 +108,7 @@ struct prg_cpd {
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,
                                 // 2: both sweeps on the matrix cores, always (tests)
     double dense_bound = 0.0;    // > 0: matrix-core column pass while it evaluates at least this many source points per target (0: estep_impl's model)
+    double* tsum_local = nullptr;            // (sum x, sum y, sum z, sum |x|^2) of the local target, beside the decision
     unsigned long long* eng_work = nullptr;  // [2] tiles evaluated by the matrix-core column / row pass (read + cleared by the decision)
     int q_first_col = 32, q_first_row = 32;  // groups per unit of the first queue sweep after a matrix-core one
     bool eng_reset = true;       // the switch's memory is void (new registration, engine mode changed)
@@ -113,6 +117,7 @@ struct prg_cpd {
     EngineDecision* eng_host = nullptr;  // mapped, coherent host memory: the mailbox the host polls
     EngineDecision* eng_host_dev = nullptr;  // ... as the device addresses it
     int pred_col = 1;           // the column-pass engine the host launches ahead of the decision (= the previous decision)
+    bool last_estep_row_lean = false;  // ... matrix-core row pass without its residual sums
     bool last_estep_mfma = false, last_estep_row_mfma = false;  // engines of the last E-step's column / row pass
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)

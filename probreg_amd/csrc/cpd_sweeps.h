@@ -44,7 +44,8 @@ __device__ __forceinline__ float col_seed_offset(float kk, float cm, float mo) {
 void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard);  // S segments of the streamed cloud (0 = fill the chip once)
 // zchunk + bounding box of z4 -> motion[8..13]; eng != null: the last thread also takes the engine decision (EngineArgs)
 void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng);
-void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine);  // rowflag: 64 bytes per 128-row block (touched planes)
+void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine, bool lean);  // lean: without the residual sums (plane 4)
+//  // rowflag: 64 bytes per 128-row block (touched planes)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  // 256-point chunks one workgroup walks
 

@@ -146,7 +146,8 @@ __device__ __forceinline__ bf16x8 slots_owned(const Split3 s) {
 
 // one streamed point -> its A-operand slots (three coordinate groups + the group of ones that picks up the owned
 // point's constant) and its f32 planes.  Pads (1e18 away) give c = -huge or -inf: every exponential of theirs is 0.
-__device__ __forceinline__ void stage_point(float* __restrict__ buf, int p, const float4 v, const float4 o, float kk) {
+__device__ __forceinline__ void stage_point(float* __restrict__ buf, int p, const float4 v, const float4 o, float kk,
+                                            bool lean = false) {
     const float dx = v.x - o.x, dy = v.y - o.y, dz = v.z - o.z;
     const float sq = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     float* tile = buf + (p >> 4) * kTileFloats;
@@ -158,11 +159,11 @@ __device__ __forceinline__ void stage_point(float* __restrict__ buf, int p, cons
     a[2 * 16 + j] = slots_streamed(split3(dz));
     a[3 * 16 + j] = (bf16x8){one, one, one, z, z, z, z, z};
     // f32 planes behind the operands: c[16], then (dx, dy)[16] and (dz, |d|^2)[16] as PAIRS - the row pass multiplies both
-    // halves of a pair by the same P in one packed fma
+    // halves of a pair by the same P in one packed fma (lean row pass: (dz, 1) - sum P dz | sum P)
     float* f = tile + 256;
     f[j] = fmaf(kk, sq, v.w);
     *reinterpret_cast<float2*>(f + 16 + 2 * j) = make_float2(dx, dy);
-    *reinterpret_cast<float2*>(f + 48 + 2 * j) = make_float2(dz, sq);
+    *reinterpret_cast<float2*>(f + 48 + 2 * j) = make_float2(dz, lean ? 1.f : sq);
 }
 
 // B operand of an owned point (lane l: slots of K group l / 16 for point l % 16): -2kk (x - o) per coordinate, and the
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
 // four lanes of a row are added up at the end).  Output plane blockIdx.y, relative to the workgroup's origin o (stored
 // in rorig[row block of 512]): p1, u' = sum P (x - o), e' = sum P |x - o|^2 - k_row_moments' residual form with o as
 // the reference point.
+template <bool LEAN>
 __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
                                                          const BoxMeta* __restrict__ zmeta,
                                                          const BoxMeta* __restrict__ tmeta,
@@ -383,14 +385,18 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     }
     const int k = lane >> 4, j = lane & 15;
     bf16x8 bz[kOwn];
-    // per owned tile: (sum P over targets 4k, 4k+2 | 4k+1, 4k+3), (sum P dx, sum P dy), (sum P dz, sum P |d|^2) - packed pairs
-    f32x2 pp[kOwn], uxy[kOwn], uze[kOwn];
+    // per owned tile, over this lane's targets, in packed pairs: (sum P dx, sum P dy), (sum P dz, sum P |d|^2) and the
+    // halves of sum P.  LEAN: (sum P dx, sum P dy), (sum P dz, sum P) - the residual sums sum P |d|^2 are not carried: all
+    // the M-step wants from them is sum_n pt1_n |x_n|^2, which the column side has (k_colfinal -> k_xpx_columns), and while
+    // sigma2 is large that sum does not have to match the row sums to the last bit (the decision kernel says when).
+    f32x2 uxy[kOwn], uze[kOwn], pp[LEAN ? 1 : kOwn];
 #pragma unroll
     for (int t = 0; t < kOwn; ++t) {
         const float4 z = z4[m0 + 16 * t + j];
         const float zx = z.x - o.x, zy = z.y - o.y, zz = z.z - o.z;
         bz[t] = owned_operand(k, kk, zx, zy, zz, kk * fmaf(zz, zz, fmaf(zy, zy, zx * zx)));
-        pp[t] = uxy[t] = uze[t] = (f32x2){0.f, 0.f};
+        uxy[t] = uze[t] = (f32x2){0.f, 0.f};
+        if (!LEAN) pp[t] = (f32x2){0.f, 0.f};
     }
     const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
     const int64_t nchunks = (n_total + kChunk - 1) / kChunk;
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
         mask &= mask - 1;
         float4 ra = tgt4[(c0 + cur) * kChunk + threadIdx.x];
         BoxMeta gm = tmeta[wave_cull ? (c0 + cur) * 8 + (lane & 7) : 0];  // the chunk's eight groups (box, largest b_n)
-        stage_point(stage[0], threadIdx.x, ra, o, kk);
+        stage_point(stage[0], threadIdx.x, ra, o, kk, LEAN);
         __syncthreads();
         for (int bsel = 0;; bsel ^= 1) {
             const float* __restrict__ buf = stage[bsel];
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
             // tile_step: accumulator d of tile tb (operands a1, cx) -> sums; leaves the first accumulator of the next tile
             auto tile_step = [&](f32x4& d, const float* __restrict__ tb, const bf16x8 a1, const f32x4 cx, const bf16x8 a1n,
                                  const f32x4 cxn) {
-                // this lane's four targets 4k .. 4k+3: (dx, dy) and (dz, |d|^2) pairs
+                // this lane's four targets 4k .. 4k+3: (dx, dy) and (dz, 1) pairs
                 const f32x4 a01 = *reinterpret_cast<const f32x4*>(tb + 272 + 8 * k), a23 = *reinterpret_cast<const f32x4*>(tb + 276 + 8 * k),
                             b01 = *reinterpret_cast<const f32x4*>(tb + 304 + 8 * k), b23 = *reinterpret_cast<const f32x4*>(tb + 308 + 8 * k);
                 const f32x2 xy0 = {a01[0], a01[1]}, xy1 = {a01[2], a01[3]}, xy2 = {a23[0], a23[1]}, xy3 = {a23[2], a23[3]};
@@ -433,10 +439,12 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
                     const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bz[u + 1], cx, 0, 0, 0)
                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bz[0], cxn, 0, 0, 0);
                     const float q0 = exp2r(d[0]), q1 = exp2r(d[1]), q2 = exp2r(d[2]), q3 = exp2r(d[3]);
-                    // the contraction in packed fp32: 8 v_pk_fma_f32 + 2 v_pk_add_f32 where 16 fma + 4 add stood
+                    // the contraction in packed fp32: 8 v_pk_fma_f32 (+ 2 v_pk_add_f32) where 16 fma + 4 add stood
                     const f32x2 s0 = {q0, q0}, s1 = {q1, q1}, s2 = {q2, q2}, s3 = {q3, q3};
-                    pp[u] += (f32x2){q0, q1};
-                    pp[u] += (f32x2){q2, q3};
+                    if (!LEAN) {
+                        pp[u] += (f32x2){q0, q1};
+                        pp[u] += (f32x2){q2, q3};
+                    }
                     uxy[u] = __builtin_elementwise_fma(s3, xy3, __builtin_elementwise_fma(s2, xy2, __builtin_elementwise_fma(s1, xy1, __builtin_elementwise_fma(s0, xy0, uxy[u]))));
                     uze[u] = __builtin_elementwise_fma(s3, zs3, __builtin_elementwise_fma(s2, zs2, __builtin_elementwise_fma(s1, zs1, __builtin_elementwise_fma(s0, zs0, uze[u]))));
                     d = dn;
@@ -474,7 +482,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
                     cx = cxn;
                 }
             }
-            if (nxt >= 0) stage_point(stage[bsel ^ 1], threadIdx.x, ra, o, kk);
+            if (nxt >= 0) stage_point(stage[bsel ^ 1], threadIdx.x, ra, o, kk, LEAN);
             __syncthreads();
             if (nxt < 0) break;
         }
@@ -493,14 +501,17 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
         float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
 #pragma unroll
         for (int u = 0; u < kOwn; ++u) {
-            const float a0 = xor_sum(pp[u][0] + pp[u][1]), a1s = xor_sum(uxy[u][0]), a2 = xor_sum(uxy[u][1]), a3 = xor_sum(uze[u][0]),
-                        a4 = xor_sum(uze[u][1]);
+            const float a0 = xor_sum(LEAN ? uze[u][1] : pp[LEAN ? 0 : u][0] + pp[LEAN ? 0 : u][1]), a1s = xor_sum(uxy[u][0]),
+                        a2 = xor_sum(uxy[u][1]), a3 = xor_sum(uze[u][0]);
+            if (!LEAN) {  // (LEAN: plane 4, the residual sums, stays unwritten and unread)
+                const float a4 = xor_sum(uze[u][1]);
+                if (lane < 16) out[4 * mcap + 16 * u + lane] = a4;
+            }
             if (lane < 16) {
                 out[16 * u + lane] = a0;
                 out[mcap + 16 * u + lane] = a1s;
                 out[2 * mcap + 16 * u + lane] = a2;
                 out[3 * mcap + 16 * u + lane] = a3;
-                out[4 * mcap + 16 * u + lane] = a4;
             }
         }
     }
@@ -623,6 +634,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     const bool col = first || (dense && eng.have_colmin && isfinite(cmax) && nk * width < 150.0);
     // the culled vector-pipe row pass overtakes the matrix-core one earlier than the column pass does
     const bool row = dense && (eng.forced || !row_off);
+    // The matrix-core row pass may drop its residual sums (k_rowpass_mfma<LEAN>) while the M-step's
+    // sigma2 = (sum pt1 |x|^2 - ...) / (Np D) does not cancel much: the column-side sum differs from what the row sums imply
+    // by ~1e-6 relative (fp32 tails), amplified by mean |x|^2 / (sigma2 D) - at most eng.lean_factor here.
+    const bool lean = row && eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.lean_factor * eng.owned_col >= eng.tsum[3];
     EngineDecision d;
     d.seq = eng.seq;
     d.col = col ? 1 : 0;
@@ -632,14 +647,14 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     d.dense = dense ? 1 : 0;
     d.sigma2 = (float)sigma2; d.motion = (float)mo; d.cmax = (float)cmax;
     d.nk_ext2 = (float)(nk * eng.ext2); d.nk_width = (float)(nk * width); d.nk_far2 = (float)(nk * far2);
-    d.r_col = r_col; d.r_row = r_row; d.row_off = row_off; d.pad = 0u;
+    d.r_col = r_col; d.r_row = r_row; d.row_off = row_off; d.lean = lean ? 1 : 0;
     *eng.dev = d;
     // mailbox: payload first, sequence number last, both at system scope
     EngineDecision* hm = eng.host;
     hm->col = d.col; hm->first = d.first; hm->row = d.row; hm->fine = d.fine; hm->dense = d.dense;
     hm->sigma2 = d.sigma2; hm->motion = d.motion; hm->cmax = d.cmax;
     hm->nk_ext2 = d.nk_ext2; hm->nk_width = d.nk_width; hm->nk_far2 = d.nk_far2;
-    hm->r_col = d.r_col; hm->r_row = d.r_row; hm->row_off = d.row_off;
+    hm->r_col = d.r_col; hm->r_row = d.r_row; hm->row_off = d.row_off; hm->lean = d.lean;
     __threadfence_system();
     __hip_atomic_store(&hm->seq, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -706,15 +721,15 @@ void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineD
     h->dense_pairs_col = 0.0;
 }
 
-void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine) {
+void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine, bool lean) {
     const int cps = mfma_chunks_per_seg(h->M, h->N, S);
     dim3 grid((unsigned)ceil_div(h->M, kWgPoints), (unsigned)ceil_div(ceil_div(h->N, kChunk), cps));
     launch_chunk_meta(h, h->tmeta, h->Ncap, h->tchunk);  // target boxes with this E-step's b_n ranges (after k_colfinal)
-    k_rowpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const BoxMeta*>(h->zmeta),
-                                                   reinterpret_cast<const BoxMeta*>(h->tmeta),
-                                                   reinterpret_cast<const BoxMeta*>(h->tchunk), cps, h->N, h->M, h->params,
-                                                   h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap, h->eng_work + 1,
-                                                   fine ? 1 : 0);
+    auto kernel = lean ? k_rowpass_mfma<true> : k_rowpass_mfma<false>;
+    kernel<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const BoxMeta*>(h->zmeta),
+                                           reinterpret_cast<const BoxMeta*>(h->tmeta), reinterpret_cast<const BoxMeta*>(h->tchunk), cps,
+                                           h->N, h->M, h->params, h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap,
+                                           h->eng_work + 1, fine ? 1 : 0);
     h->wg_row = (int64_t)grid.x * grid.y;
     h->wg_row_pairs = 128.0 * 16.0;
     h->dense_pairs_row = 0.0;

@@ -88,6 +88,12 @@ class CpdPlan(object):
         check(lib.prg_cpd_last_estep_engines(self._h, ctypes.byref(c), ctypes.byref(r)))
         return int(c.value), int(r.value)
 
+    def last_estep_lean(self):
+        """1 if the last E-step's matrix-core row pass ran without its residual sums (prg_cpd_last_estep_lean)."""
+        v = ctypes.c_int(0)
+        check(lib.prg_cpd_last_estep_lean(self._h, ctypes.byref(v)))
+        return int(v.value)
+
     def set_source(self, source):
         a = self._f32(source)
         self.m, self.dim = int(a.shape[0]), int(a.shape[1])
