@@ -43,6 +43,7 @@ if world > 1:
     plan = engine.CpdPlan()
     plan.set_source(src - reg._cy)
     plan.set_target(tgt[rows] - reg._cx, n_global=tgt.shape[0])
+    plan.init_sums()  # (as registration does: the local target's sums decide where the lean row pass may run)
     n_local = len(rows)
 print("%s cloud, M = %d, N = %d (rank 0 of %d: %d targets)" % (kind, src.shape[0], tgt.shape[0], world, n_local))
 print("iter sigma2      nk      | valu: col row total ms | mfma: col row total ms | d sigma2 rel, d rot, d t | pairs | "

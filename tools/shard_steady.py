@@ -27,6 +27,7 @@ for world in (1, 2, 4, 8):
     p2 = engine.CpdPlan()
     p2.set_source(src - cy)
     p2.set_target(tgt[rows] - cx, n_global=n)
+    p2.init_sums()  # (as registration does: the local target's sums decide where the lean row pass may run)
     out = []
     for it, st in sorted(states.items()):
         p2.set_params(st)

@@ -34,6 +34,7 @@ for world in (1, 2, 4, 8):
     p2 = engine.CpdPlan()
     p2.set_source(src - cy)
     p2.set_target(tgt[rows] - cx, n_global=n)
+    p2.init_sums()  # (as registration does: the local target's sums decide where the lean row pass may run)
     ms = []
     for it, st in enumerate(states):
         # a faithful E-step needs the PREVIOUS iteration's column minima as seeds: run the previous state first
