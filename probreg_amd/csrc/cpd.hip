@@ -1137,6 +1137,8 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
                 "prg_cpd_set_target: dim %d does not match source dim %d", dim, h->D);
     prg::DeviceGuard g(h->device);
     PRG_HIP(hipStreamSynchronize(h->stream));
+    // (the sums of the previous target no longer describe this one: no lean row pass until prg_cpd_init_sums has run)
+    if (h->tsum_local) PRG_HIP(hipMemsetAsync(h->tsum_local, 0, 4 * sizeof(double), h->stream));
     const int64_t cap = cap_for(n_local);
     if (cap != h->Ncap) {
         if (h->tgt4) (void)hipFree(h->tgt4);
