@@ -89,6 +89,10 @@ int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull);
  * prg_cpd_last_estep_engine reports which engine the last E-step's column pass used (1 = matrix cores). */
 int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound);
 int prg_cpd_last_estep_engine(prg_cpd* h, int* engine);
+/* The bounds of that decision for a source of m points and a local target of n_local (host arithmetic, no device needed):
+ * the matrix-core column pass is left below *col_bound evaluated source points per target, the row pass below *row_bound
+ * evaluated targets per source point. */
+int prg_cpd_engine_bounds(int64_t m, int64_t n_local, double* col_bound, double* row_bound);
 /* Sparse regime (sigma2 small: most 128 x 32 blocks of P are exact zeros): 1 (default) - with M and the local N both >= 32768
  * the vector-pipe sweeps run over a device-built work queue (need-masks -> units -> persistent waves,
  * csrc/cpd_sweeps_queue.hip), smaller problems on the grid; 2 - the queue always; 0 - always one wave per (128-point block,

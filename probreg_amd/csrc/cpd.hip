@@ -1302,6 +1302,26 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     return PRG_OK;
 }
 
+// Below how many evaluated pairs per owned point does a matrix-core sweep lose to the vector-pipe sweep?  The two-line cost
+// model of DESIGN.md 3.1c (see estep_impl): segment chain of a workgroup + late start on grids deeper than the chip, against
+// evenly shared blocks.  Host arithmetic only.
+static double engine_leave_below(int64_t owned, int64_t streamed, double tau, double delta, double c_v) {
+    static const int seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;
+    const double cps = (double)prg::mfma_chunks_per_seg(owned, streamed, seg);
+    const double wgs = (double)prg::ceil_div(owned, prg::kMfmaWgPoints) * (double)prg::mfma_planes(owned, streamed, seg);
+    const double late = std::max(0.0, 1.0 - 768.0 / wgs) * tau / (768.0 * 512.0 * 256.0);
+    return std::max(0.0, cps * tau + delta) / (c_v - late) / (double)owned;  // pairs per owned point
+}
+static double engine_col_bound(int64_t m, int64_t n_local) { return engine_leave_below(n_local, m, 12.0e-6, -15.0e-6, 0.200e-12); }
+static double engine_row_bound(int64_t m, int64_t n_local) { return engine_leave_below(m, n_local, 19.2e-6, 8.0e-6, 0.233e-12); }
+
+int prg_cpd_engine_bounds(int64_t m, int64_t n_local, double* col_bound, double* row_bound) {
+    PRG_REQUIRE(m > 0 && n_local > 0 && col_bound && row_bound, PRG_ERR_INVALID, "prg_cpd_engine_bounds: need m, n_local > 0 and two outputs");
+    *col_bound = engine_col_bound(m, n_local);
+    *row_bound = engine_row_bound(m, n_local);
+    return PRG_OK;
+}
+
 // Device / mapped-host state of the engine decision: the decision itself, the matrix-core sweeps' tile counters and the LOCAL
 // target's sum |x|^2 (prg_cpd_init_sums keeps a copy here: the caller all-reduces the moments block it also writes it to).
 static int ensure_engine_state(prg_cpd* h) {
@@ -1444,15 +1464,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // points and 1/2, 1/4, 1/8 shards of 100k all cross over within one EM iteration of what this predicts.
         static const double r_col_env = getenv("PRG_ENGINE_RCOL") ? atof(getenv("PRG_ENGINE_RCOL")) : 0.0;
         static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
-        auto leave_below = [](int64_t owned, int64_t streamed, double tau, double delta, double c_v) {
-            const double cps = (double)prg::mfma_chunks_per_seg(owned, streamed, mfma_seg);
-            const double wgs = (double)prg::ceil_div(owned, prg::kMfmaWgPoints) * (double)prg::mfma_planes(owned, streamed, mfma_seg);
-            const double late = std::max(0.0, 1.0 - 768.0 / wgs) * tau / (768.0 * 512.0 * 256.0);
-            return std::max(0.0, cps * tau + delta) / (c_v - late) / (double)owned;  // pairs per owned point
-        };
-        ea.r_col_bound = r_col_env > 0.0 ? r_col_env
-                         : h->dense_bound > 0.0 ? h->dense_bound : leave_below(h->N, h->M, 12.0e-6, -15.0e-6, 0.200e-12);
-        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : leave_below(h->M, h->N, 19.2e-6, 8.0e-6, 0.233e-12);
+        ea.r_col_bound = r_col_env > 0.0 ? r_col_env : h->dense_bound > 0.0 ? h->dense_bound : engine_col_bound(h->M, h->N);
+        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N);
         ea.streamed_col = (double)h->M;
         ea.streamed_row = (double)h->N;
         // the first sweep over the work queue after the matrix cores has no previous build to size its units from: about

@@ -25,6 +25,15 @@ def _current_device_and_stream(device=None):
     return (0 if device is None else int(device)), 0
 
 
+def engine_bounds(m, n_local):
+    """(column bound, row bound) of the dense-regime engine switch for a source of ``m`` points and a local target of
+    ``n_local``: evaluated pairs per owned point below which the matrix-core sweep is left (prg_cpd_engine_bounds; host
+    arithmetic, no GPU needed)."""
+    a, b = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(lib.prg_cpd_engine_bounds(int(m), int(n_local), ctypes.byref(a), ctypes.byref(b)))
+    return float(a.value), float(b.value)
+
+
 class CpdPlan(object):
     """Owns one ``prg_cpd`` handle."""
 
