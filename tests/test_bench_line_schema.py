@@ -50,3 +50,21 @@ def test_other_workloads_ride_in_the_same_line():
     if "parity" in other["affine_200k"]:  # (round 3 on: every workload carries its own GPU-vs-oracle block)
         for name, w in other.items():
             assert w["parity"]["ok"] is True, (name, w["parity"])
+
+
+def test_roofline_flop_accounting_is_self_consistent():
+    """`frac` charges every launch the flop its kernel spends per pair: 21 for the row pass, 19 where the matrix-core row
+    pass ran without its residual sums (prg_cpd_last_estep_lean); the window's average and the shares are in the line."""
+    r = _line()["roofline"]
+    f = r["flop_per_pair"]["isa_count"]
+    if "row_lean" not in f:  # (lines of earlier rounds)
+        return
+    assert f["row"] == 21.0 and f["row_lean"] == 19.0 and f["col"] == 14.0
+    assert f["row_lean"] <= f["row_window_average"] <= f["row"]
+    share = r["matrix_core_share"]
+    assert 0.0 <= share["row_pass_lean_iterations"] <= share["row_pass_iterations"] <= 1.0
+    # achieved = (pairs x flop/pair) / time, per launch: the line's own per-launch figures reproduce it
+    pairs, ms = r["pairs_evaluated_per_launch"], r["avg_launch_ms"]
+    achieved = pairs * f["row_window_average"] / (ms * 1e-3) / 1e12
+    assert abs(achieved - r["achieved"]) < 1e-6 * r["achieved"]
+    assert r["frac_with_survey_flops"] < r["frac"] * 20.0 / f["row_lean"] + 1e-12
