@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the CPD / FilterReg EM hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps 20 --warmup 3        (N > 1 without WORLD_SIZE in the environment: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -317,7 +317,14 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     out["config"].update({
         "window": "EM iterations 0..%d of the registration (state reset after the warm-up steps)" % (steps - 1),
         "target_sharding": "contiguous runs of the target's Morton order over %d rank(s)" % world,
-        "collective": "1 all-reduce of 32 fp64 per iteration" if world > 1 else "none",
+        "collective": (("1 ncclAllReduce (RCCL, issued by libprobreg_hip.so on the plan's stream) of 32 fp64 per iteration"
+                        if getattr(plan, "_comm", None) is not None else
+                        "1 torch.distributed all_reduce (%s) of 32 fp64 per iteration" % torch.distributed.get_backend())
+                       if world > 1 else "none"),
+        "collective_path": ("library-side RCCL (prg_cpd_set_comm: ncclAllReduce inside prg_cpd_estep, plan's stream)"
+                            if getattr(plan, "_comm", None) is not None else
+                            "torch.distributed (%s)" % torch.distributed.get_backend()
+                            if torch.distributed.is_available() and torch.distributed.is_initialized() else "none: one process"),
         "m": m_pts, "n_local": n_loc, "n_global": n})
     out["trajectory_it_s"] = steps / elapsed
     out["dense_it_s"] = 1.0 / t_dense
@@ -579,11 +586,33 @@ def main():
                     help="non-rigid: skip the M-step through the dense fallback (profiles of the product path alone)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU under torch.distributed.run,
+        # exactly the command the docstring gives); rank 0 of that run prints the one JSON line on this stdout
+        import socket
+        import subprocess
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("OMP_NUM_THREADS", "8")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree (n_gpus in the line is the "
+                         "number of ranks that ran)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
     if os.environ.get("PROBREG_SHARE_GPU") == "1":  # test rig only: N ranks on one GPU (use with PROBREG_DIST_BACKEND=gloo)
@@ -636,6 +665,9 @@ def main():
         print(json.dumps(out))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
+        from probreg_amd import dist as pdist
+
+        pdist.reset_native_comms()
         torch.distributed.destroy_process_group()
 
 

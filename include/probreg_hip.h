@@ -122,6 +122,34 @@ int prg_cpd_bind_moments(prg_cpd* h, double* moments_dev);
 int prg_cpd_moments_ptr(prg_cpd* h, double** moments_dev);
 int prg_cpd_params_ptr(prg_cpd* h, double** params_dev);
 
+/* ---- multi-GPU: the one exchange step of the path ---------------------------------------------
+ * The reference is single-process (its EM loop, cpd.py:106-120, is what gets sharded): every rank keeps the whole
+ * source, owns a run of target rows, and the partial MOMENTS of its E-step (cpd.py:84-88 restricted to its columns)
+ * are summed over the ranks before the M-step (cpd.py:160-192 / 219-244), which every rank then runs identically.
+ * A prg_comm wraps an RCCL communicator (librccl is bound with dlopen on first use - a single-GPU caller never
+ * loads it): rank 0 calls prg_comm_unique_id and hands the PRG_COMM_ID_BYTES bytes to the other ranks by any means
+ * (the Python layer broadcasts them through torch.distributed), every rank calls prg_comm_create (ncclCommInitRank;
+ * collective).  prg_comm_adopt wraps an ncclComm_t the caller already has (not destroyed by prg_comm_destroy).
+ * With prg_cpd_set_comm(plan, comm) the plan's prg_cpd_init_sums and prg_cpd_estep END with the SUM all-reduce of
+ * MOMENTS (a non-rigid plan: of the per-point block of prg_cpd_rowacc_ptr as well) on the plan's own stream: an EM
+ * iteration is enqueue-only, nothing between the E-step's last kernel and the M-step leaves the library.
+ * comm == NULL detaches (the caller all-reduces MOMENTS itself, e.g. through prg_cpd_bind_moments). */
+#define PRG_COMM_ID_BYTES 128
+typedef struct prg_comm prg_comm;
+int prg_comm_available(int* rccl_version);            /* PRG_OK when librccl could be bound (version: ncclGetVersion) */
+int prg_comm_unique_id(unsigned char* id_out);        /* [PRG_COMM_ID_BYTES], host */
+int prg_comm_create(prg_comm** out, const unsigned char* id, int rank, int nranks, int device);
+int prg_comm_adopt(prg_comm** out, void* nccl_comm, int device);
+int prg_comm_info(prg_comm* c, int* rank, int* nranks, int64_t* all_reduces_issued);
+int prg_comm_destroy(prg_comm* c);
+/* In-place SUM all-reduce of `count` doubles at a device address, on `hip_stream` (what the plan issues itself). */
+int prg_comm_all_reduce_f64(prg_comm* c, double* buf_dev, int64_t count, void* hip_stream);
+int prg_cpd_set_comm(prg_cpd* h, prg_comm* comm);
+/* `n_iter` EM iterations of the rigid / affine registration enqueued back to back: transform + E-step [+ all-reduce]
+ * + M-step, the loop body of CoherentPointDrift.registration (cpd.py:110-113) without its host-side convergence test
+ * (tol < 0, no callbacks).  Nothing is read back; prg_cpd_get_params afterwards synchronises. */
+int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter);
+
 /* sigma2 initialiser, step 1: local target sums -> MOMENTS[24..27] (others zeroed).
  * Replaces: mu.squared_kernel_sum, math_utils.py:28-29 -> cc/math_utils.cc:5-15
  * (closed form, never materialises M x N). All-reduce MOMENTS between step 1 and 2. */

@@ -23,6 +23,7 @@ PRG_TF_NONRIGID = 2
 
 PRG_NMOMENTS = 32
 PRG_NPARAMS = 32
+PRG_COMM_ID_BYTES = 128
 
 
 class ProbregHipError(RuntimeError):
@@ -74,6 +75,15 @@ SIGNATURES = {
     "prg_cpd_bind_moments": [_vp, _vp],
     "prg_cpd_moments_ptr": [_vp, _pp],
     "prg_cpd_params_ptr": [_vp, _pp],
+    "prg_comm_available": [_c.POINTER(_i)],
+    "prg_comm_unique_id": [_vp],
+    "prg_comm_create": [_pp, _vp, _i, _i, _i],
+    "prg_comm_adopt": [_pp, _vp, _i],
+    "prg_comm_info": [_vp, _c.POINTER(_i), _c.POINTER(_i), _c.POINTER(_i64)],
+    "prg_comm_destroy": [_vp],
+    "prg_comm_all_reduce_f64": [_vp, _vp, _i64, _vp],
+    "prg_cpd_set_comm": [_vp, _vp],
+    "prg_cpd_iterate": [_vp, _i, _i, _d, _i],
     "prg_cpd_init_sums": [_vp],
     "prg_cpd_init_params": [_vp, _vp],
     "prg_cpd_estep": [_vp, _d],

@@ -139,13 +139,20 @@ class CoherentPointDrift(abc.ABC):
         if not getattr(self, "_source_uploaded", False):
             plan.set_source(source - cy)
         plan.set_target(target[rows] - cx, n_global=target.shape[0])
-        mom = plan.moments_tensor() if pdist.initialized() else None
+        # the per-iteration collective: issued by the library itself on the plan's stream (RCCL, prg_cpd_set_comm) when the
+        # process group is an nccl one; through torch.distributed on the bound moment tensor otherwise (gloo)
+        comm = pdist.native_comm(plan.device) if hasattr(plan, "set_comm") else None
+        if comm is not None and getattr(plan, "_comm", None) is not comm:
+            plan.set_comm(comm)
+        mom = plan.moments_tensor() if comm is None and pdist.initialized() else None
         plan.init_sums()
         if mom is not None:
             pdist.all_reduce_sum_(mom, getattr(plan, "stream", None))
         return plan
 
     def _all_reduce_moments(self, plan):
+        if getattr(plan, "_comm", None) is not None:
+            return  # done inside prg_cpd_estep
         if plan._moments_tensor is not None:
             pdist.all_reduce_sum_(plan._moments_tensor, getattr(plan, "stream", None))
 
@@ -153,7 +160,7 @@ class CoherentPointDrift(abc.ABC):
         """Put an initialised plan back to the start of its registration (sigma2 initialiser, q0, initial transform)
         without re-uploading the clouds - bench.py times the SAME EM iterations whatever its warm-up did."""
         plan = self._plan
-        mom = plan.moments_tensor() if pdist.initialized() else None
+        mom = plan.moments_tensor() if getattr(plan, "_comm", None) is None and pdist.initialized() else None
         plan.init_sums()
         if mom is not None:
             pdist.all_reduce_sum_(mom, getattr(plan, "stream", None))
@@ -167,6 +174,17 @@ class CoherentPointDrift(abc.ABC):
     @abc.abstractmethod
     def _device_mstep(self, plan):
         pass
+
+    def _iterate_native(self, plan, w, n_iter):
+        """Rigid / affine: the whole loop enqueued inside the library (prg_cpd_iterate) when nothing between the E-step and
+        the M-step has to go through Python - one rank, or the library's own RCCL all-reduce.  False: not taken."""
+        kind = getattr(self, "_kind", None)
+        if kind not in (_lib.PRG_TF_RIGID, _lib.PRG_TF_AFFINE) or not hasattr(plan, "iterate"):
+            return False
+        if getattr(plan, "_comm", None) is None and pdist.initialized():
+            return False  # the collective is torch.distributed's: one Python round trip per iteration
+        plan.iterate(kind, getattr(self, "_update_scale", True), w, n_iter)
+        return True
 
     @abc.abstractmethod
     def _result_from_params(self, params):
@@ -184,6 +202,8 @@ class CoherentPointDrift(abc.ABC):
         plan = self._plan
         q = res.q
         need_host = bool(self._callbacks) or tol >= 0 or log.isEnabledFor(10)
+        if not need_host and maxiter > 0 and self._iterate_native(plan, w, maxiter):
+            return self._result_from_params(plan.get_params())
         for i in range(maxiter):
             plan.estep(w)
             self._all_reduce_moments(plan)
@@ -375,7 +395,7 @@ class NonRigidCPD(CoherentPointDrift):
 
     def _all_reduce_moments(self, plan):
         super(NonRigidCPD, self)._all_reduce_moments(plan)
-        if pdist.initialized():
+        if pdist.initialized() and getattr(plan, "_comm", None) is None:
             self._all_reduce_rowacc(plan)
 
     def _all_reduce_rowacc(self, plan):
@@ -421,11 +441,15 @@ class NonRigidCPD(CoherentPointDrift):
         if source.shape != ctrl.shape or not np.array_equal(source, ctrl):
             raise ValueError("NonRigidCPD._maximization_step: source must be the control points tf_obj was built on "
                              "(the reference reads G from tf_obj and Y from source; both are the same cloud).")
+        key = (_device, _solver_mode, float(tf_obj._beta))
         cache = getattr(tf_obj, "_mstep_plan", None)
+        if cache is not None and cache[2] != key:  # another device / solver / kernel width: the old factor is void
+            cache[0].close()
+            cache = None
         if cache is None:
-            cache = _nonrigid_plan(ctrl, tf_obj._beta, _device, _solver_mode)
-            tf_obj._mstep_plan = cache
-        plan, origin = cache
+            cache = _nonrigid_plan(ctrl, tf_obj._beta, _device, _solver_mode) + (key,)
+            tf_obj._mstep_plan = cache  # released by NonRigidTransformation.close() / __del__
+        plan, origin = cache[0], cache[1]
         pt1, p1, px, _n_p = estep_res
         plan.set_target(target - origin, n_global=target.shape[0])
         if _priors is not None:

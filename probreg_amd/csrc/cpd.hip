@@ -1275,6 +1275,15 @@ int prg_cpd_init_sums(prg_cpd* h) {
     PRG_HIP(hipGetLastError());
     PRG_TRY(ensure_engine_state(h));
     PRG_HIP(hipMemcpyAsync(h->tsum_local, h->moments + 24, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));  // (after the LOCAL sums were kept)
+    return PRG_OK;
+}
+
+int prg_cpd_set_comm(prg_cpd* h, prg_comm* comm) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_comm: NULL handle");
+    PRG_REQUIRE(!comm || comm->device == h->device, PRG_ERR_INVALID, "prg_cpd_set_comm: the communicator lives on device %d, the plan on %d",
+                comm ? comm->device : -1, h->device);
+    h->comm = comm;
     return PRG_OK;
 }
 
@@ -1510,17 +1519,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         PRG_HIP(hipGetLastError());
         // the answer: a few microseconds after the transform has finished, long before the column pass has
         volatile EngineDecision* mb = h->eng_host;
-        (void)hipStreamQuery(h->stream);  // (makes sure everything enqueued so far has been handed to the device)
-        for (uint64_t spins = 0; mb->seq != ea.seq; ++spins) {
-            if ((spins & 0xFFFull) == 0xFFFull && hipStreamQuery(h->stream) != hipErrorNotReady) {
-                // the stream has drained (or failed): the decision kernel is done, its store must be here by now
-                if (mb->seq == ea.seq) break;
-                PRG_HIP(hipStreamSynchronize(h->stream));
-                PRG_REQUIRE(mb->seq == ea.seq, PRG_ERR_HIP, "prg_cpd_estep: the engine decision never reached the host");
-            }
-            __builtin_ia32_pause();
+        {
+            hipError_t werr;
+            const bool got = prg::wait_mailbox(&mb->seq, ea.seq, h->stream, &werr);
+            PRG_HIP(werr);
+            PRG_REQUIRE(got, PRG_ERR_HIP, "prg_cpd_estep: the engine decision never reached the host");
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
         use_mfma = mb->col != 0;
         first_mfma = mb->first != 0;
         row_mfma = mb->row != 0;
@@ -1588,6 +1592,11 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (row_lean) k_xpx_columns<<<1, kBlock, 0, h->stream>>>(xpart, (int)prg::ceil_div(h->N, kBlock), h->moments);
     if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
     PRG_HIP(hipGetLastError());
+    // target sharded over ranks: the one exchange step of the path - partial moments -> moments, on this stream
+    if (h->comm) {
+        PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));
+        if (h->nonrigid) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->rowacc, 4 * h->Mcap, h->stream));
+    }
     h->qcol_live = col_queue;
     h->qrow_live = row_queue;
     h->have_estep = true;
@@ -1657,6 +1666,11 @@ int prg_cpd_pair_counts(prg_cpd* h, double* col_pairs, double* row_pairs) {
             *row_pairs = s * h->wg_row_pairs;
         }
     }
+    // counted blocks include the pad points that fill the last block of either cloud (C1: 1.00448e10 counted for 1e10 real
+    // pairs in a dense sweep): never report more than the pairs there are
+    const double all_pairs = (double)h->M * (double)h->N;
+    *col_pairs = std::min(*col_pairs, all_pairs);
+    *row_pairs = std::min(*row_pairs, all_pairs);
     return PRG_OK;
 }
 
@@ -1666,6 +1680,20 @@ int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {
                 "prg_cpd_mstep: kind must be PRG_TF_RIGID or PRG_TF_AFFINE (use prg_cpd_mstep_nonrigid)");
     prg::DeviceGuard g(h->device);
     k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter) {
+    PRG_REQUIRE(h && h->have_source && h->have_target, PRG_ERR_STATE, "prg_cpd_iterate: clouds not set");
+    PRG_REQUIRE(kind == PRG_TF_RIGID || kind == PRG_TF_AFFINE, PRG_ERR_INVALID,
+                "prg_cpd_iterate: kind must be PRG_TF_RIGID or PRG_TF_AFFINE");
+    PRG_REQUIRE(n_iter >= 0, PRG_ERR_INVALID, "prg_cpd_iterate: n_iter must be >= 0");
+    prg::DeviceGuard g(h->device);
+    for (int it = 0; it < n_iter; ++it) {
+        PRG_TRY(estep_impl(h, w, nullptr));  // (ends with the all-reduce when a communicator is attached)
+        k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
+    }
     PRG_HIP(hipGetLastError());
     return PRG_OK;
 }

@@ -449,6 +449,7 @@ int nonrigid_free(prg_cpd* h) {
     if (h->nr_solve) (void)hipFree(h->nr_solve);
     h->nr_solve = nullptr;
     h->nr_solve_bytes = 0;
+    h->nr_info = nullptr;  // the sticky pivot flag lives at the end of nr_solve: it goes with it
     if (h->G) (void)hipFree(h->G);
     if (h->F) (void)hipFree(h->F);
     h->F = nullptr;

@@ -54,6 +54,15 @@ struct SweepQueue {
     int nchunk = 0, cap_soft = 0;
 };
 
+// Communicator of the per-iteration all-reduce (comm.hip): an RCCL communicator the library created (prg_comm_create) or
+// one the caller handed over (prg_comm_adopt).
+struct prg_comm {
+    void* nccl = nullptr;  // ncclComm_t
+    int rank = 0, nranks = 1, device = 0;
+    bool owned = true;     // prg_comm_destroy calls ncclCommDestroy
+    int64_t calls = 0;     // all-reduces issued (tests / measurements)
+};
+
 // Row accumulator block: 4 fp64 planes of Mcap (p1, px0, px1, px2), written by the moment kernel.
 struct prg_cpd {
     int device = 0;
@@ -174,9 +183,15 @@ struct prg_cpd {
 
     bool have_source = false, have_target = false, have_estep = false;
     double last_w = 0.0;
+
+    // multi-GPU: when set, prg_cpd_estep / prg_cpd_init_sums end with the SUM all-reduce of the moment block (and, for a
+    // non-rigid plan, of the per-point block) on the plan's stream; not owned by the plan
+    prg_comm* comm = nullptr;
 };
 
 namespace prg {
+struct UniqueId { char bytes[PRG_COMM_ID_BYTES]; };  // ncclUniqueId
+int comm_all_reduce_f64(prg_comm* c, double* buf_dev, int64_t count, hipStream_t st);
 int ensure_stage(prg_cpd* h, size_t bytes);
 // non-rigid (cpd_nonrigid.hip)
 int nonrigid_displacement(prg_cpd* h, const double** gw_out);  // G W of the current W (device, [M][3])

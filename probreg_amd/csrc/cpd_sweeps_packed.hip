@@ -539,6 +539,7 @@ void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const En
                                                    h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap,
                                                    h->wgcount, guard);
     h->wg_col = (int64_t)grid.x * grid.y;
+    h->wg_col_pairs = 128.0 * kGroup;  // (a mispredicted matrix-core launch ahead of this one has left its own unit here)
     h->dense_pairs_col = 0.0;
 }
 
@@ -551,6 +552,7 @@ void launch_rowpass_cull(prg_cpd* h, int S, int seg_len) {
                                                    reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)planes * 5 * h->Mcap),
                                                    h->wgcount + h->wg_cap);
     h->wg_row = (int64_t)grid.x * grid.y;
+    h->wg_row_pairs = 128.0 * kGroup;
     h->dense_pairs_row = 0.0;
 }
 

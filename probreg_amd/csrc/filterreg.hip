@@ -1151,16 +1151,12 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                                                                                  L->mail_dev, seq);
             PRG_HIP(hipGetLastError());
             volatile LatticeMail* mb = L->mail;
-            (void)hipStreamQuery(st);  // (makes sure everything enqueued so far has been handed to the device)
-            for (uint64_t spins = 0; mb->seq != seq; ++spins) {
-                if ((spins & 0xFFFull) == 0xFFFull && hipStreamQuery(st) != hipErrorNotReady) {
-                    if (mb->seq == seq) break;
-                    PRG_HIP(hipStreamSynchronize(st));
-                    PRG_REQUIRE(mb->seq == seq, PRG_ERR_HIP, "permutohedral lattice: the vertex count never reached the host");
-                }
-                __builtin_ia32_pause();
+            {
+                hipError_t werr;
+                const bool got = prg::wait_mailbox(&mb->seq, seq, st, &werr);
+                PRG_HIP(werr);
+                PRG_REQUIRE(got, PRG_ERR_HIP, "permutohedral lattice: the vertex count never reached the host");
             }
-            std::atomic_thread_fence(std::memory_order_acquire);
             host[0] = mb->size;
             host[1] = mb->overflow;
             L->count_clean = true;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
+#include <chrono>
 #include <string>
 
 #include "../../include/probreg_hip.h"
@@ -56,5 +58,31 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+
+// Wait for a device-written sequence number in a mapped host mailbox without draining the queue: a short spin (the
+// answer normally arrives within microseconds of the kernel that writes it), bounded by a time budget - a stream that
+// is blocked behind a cross-stream event or a collective must not keep a host core at 100 % - after which the wait
+// becomes a plain hipStreamSynchronize.  Returns false if the stream has drained and the number never came.
+static inline bool wait_mailbox(volatile const unsigned* seq_ptr, unsigned seq, hipStream_t st, hipError_t* err) {
+    *err = hipSuccess;
+    (void)hipStreamQuery(st);  // (makes sure everything enqueued so far has been handed to the device)
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *seq_ptr != seq; ++spins) {
+        if ((spins & 0xFFFull) == 0xFFFull) {
+            const bool late = std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5);
+            if (late || hipStreamQuery(st) != hipErrorNotReady) {
+                // the stream has drained (or failed), or the budget is spent: block instead of spinning
+                if (*seq_ptr == seq) break;
+                *err = hipStreamSynchronize(st);
+                if (*err != hipSuccess || *seq_ptr != seq) return false;
+                break;
+            }
+        }
+        __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
 
 }  // namespace prg

@@ -5,7 +5,15 @@ every rank keeps the whole source cloud, owns a spatially compact block of targe
 run of the target's Morton order) and all-reduces
 the 32-double moment block once per EM iteration (rigid / affine), or the per-point fp64 block
 (non-rigid).  With the ``gloo`` backend the same helpers work on CPU tensors (used by the tests).
+
+The per-iteration collective itself is issued by the library (``NativeComm``: RCCL bound inside libprobreg_hip.so, on the
+plan's stream - an EM iteration is enqueue-only) whenever the process group's backend is ``nccl``; ``torch.distributed``
+then only carries the one-off hand-over of the communicator id.  The torch path stays for ``gloo`` (CPU tests, the
+two-ranks-on-one-GPU rig) and as the fallback when RCCL cannot be bound.
 """
+import os
+import warnings
+
 import numpy as np
 
 
@@ -114,3 +122,127 @@ def all_reduce_sum_numpy(arr):
         t = t.cuda()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the library's own RCCL communicator (include/probreg_hip.h: prg_comm_*)
+# ----------------------------------------------------------------------------------------------------------------
+class NativeComm(object):
+    """An RCCL communicator owned by libprobreg_hip.so (``prg_comm_create``): what ``CpdPlan.set_comm`` takes."""
+
+    def __init__(self, id_bytes, rank, nranks, device):
+        import ctypes
+
+        from . import _lib
+
+        self._lib = _lib
+        self._h = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * _lib.PRG_COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
+        _lib.check(_lib.lib.prg_comm_create(ctypes.byref(self._h), buf, int(rank), int(nranks), int(device)))
+        self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+
+        from . import _lib
+
+        buf = (ctypes.c_ubyte * _lib.PRG_COMM_ID_BYTES)()
+        _lib.check(_lib.lib.prg_comm_unique_id(buf))
+        return bytes(buf)
+
+    def all_reduce_f64_(self, tensor, stream=0):
+        """In-place SUM all-reduce of a contiguous fp64 device tensor on the raw hipStream_t ``stream``."""
+        import ctypes
+
+        self._lib.check(self._lib.lib.prg_comm_all_reduce_f64(self._h, ctypes.c_void_p(tensor.data_ptr()), int(tensor.numel()),
+                                                              ctypes.c_void_p(int(stream))))
+        return tensor
+
+    def calls(self):
+        import ctypes
+
+        n = ctypes.c_int64(0)
+        self._lib.check(self._lib.lib.prg_comm_info(self._h, None, None, ctypes.byref(n)))
+        return int(n.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.lib.prg_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+
+_native = {}  # device -> NativeComm or None (None: tried and given up - every rank took the same decision)
+
+
+def native_comm(device):
+    """The library-side communicator of this process for ``device``, created on first use - or None when the collective
+    stays with torch.distributed.
+
+    PROBREG_NATIVE_RCCL: unset - native whenever a process group with the ``nccl`` backend exists; ``0`` - never;
+    ``1`` - also for a single process without any process group (a one-rank communicator: tests, measurements).
+    Creation is collective: rank 0 draws the id, ``broadcast_object_list`` hands it round, every rank joins, a test
+    all-reduce of (1, rank + 1) must come back as (N, N (N + 1) / 2) on every rank - the verdicts are all-reduced (MIN)
+    so that all ranks use the same path.
+    """
+    device = int(device)
+    if device in _native:
+        return _native[device]
+    mode = os.environ.get("PROBREG_NATIVE_RCCL", "")
+    comm = None
+    if mode != "0":
+        import torch
+
+        rank, nranks = world()
+        have_pg = initialized()
+        if have_pg:
+            import torch.distributed as tdist
+
+            wanted = tdist.get_backend() == "nccl"
+        else:
+            wanted = mode == "1"
+        if wanted:
+            ok, why = 1, ""
+            try:
+                ids = [NativeComm.unique_id() if rank == 0 else None]
+                if have_pg:
+                    tdist.broadcast_object_list(ids, src=0)
+                comm = NativeComm(ids[0], rank, nranks, device)
+                with torch.cuda.device(device):
+                    probe = torch.tensor([1.0, rank + 1.0], dtype=torch.float64, device="cuda:%d" % device)
+                    st = torch.cuda.current_stream().cuda_stream
+                    comm.all_reduce_f64_(probe, st)
+                    got = probe.cpu().tolist()
+                if got != [float(nranks), nranks * (nranks + 1) / 2.0]:
+                    ok, why = 0, "test all-reduce returned %r" % (got,)
+            except Exception as e:  # RCCL not bindable, init failure: fall back together
+                ok, why = 0, "%s: %s" % (type(e).__name__, e)
+            if have_pg:
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda:%d" % device)
+                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
+                all_ok = int(flag.item())
+            else:
+                all_ok = ok
+            if not all_ok:
+                if not ok:
+                    warnings.warn("probreg_amd: library-side RCCL communicator unavailable (%s); the per-iteration "
+                                  "all-reduce goes through torch.distributed" % why)
+                if comm is not None:
+                    comm.close()
+                comm = None
+    _native[device] = comm
+    return comm
+
+
+def reset_native_comms():
+    """Drop the cached communicators (before ``destroy_process_group`` / in tests)."""
+    for c in _native.values():
+        if c is not None:
+            c.close()
+    _native.clear()

@@ -47,6 +47,7 @@ class CpdPlan(object):
         self._h = ctypes.c_void_p()
         check(lib.prg_cpd_create(ctypes.byref(self._h), dev, ctypes.c_void_p(st)))
         self._moments_tensor = None
+        self._comm = None
         self.m = self.n = self.dim = 0
 
     # -- life cycle -------------------------------------------------------------------------
@@ -116,7 +117,17 @@ class CpdPlan(object):
     def set_tuning(self, r_col=0, seg_col=0, r_row=0, seg_row=0):
         check(lib.prg_cpd_set_tuning(self._h, r_col, seg_col, r_row, seg_row))
 
-    # -- moment block as a torch tensor (for RCCL all-reduce) --------------------------------
+    # -- multi-GPU: the library's own RCCL all-reduce on the plan's stream -------------------
+    def set_comm(self, comm):
+        """Attach a ``dist.NativeComm`` (None detaches): init_sums / estep then end with the all-reduce themselves."""
+        check(lib.prg_cpd_set_comm(self._h, comm._h if comm is not None else None))
+        self._comm = comm  # keeps the communicator alive as long as the plan uses it
+
+    def iterate(self, kind, update_scale, w, n_iter):
+        """``n_iter`` EM iterations enqueued back to back inside the library (prg_cpd_iterate)."""
+        check(lib.prg_cpd_iterate(self._h, int(kind), 1 if update_scale else 0, float(w), int(n_iter)))
+
+    # -- moment block as a torch tensor (for a caller-side all-reduce: gloo, tests) -----------
     def moments_tensor(self):
         """Allocate (once) a torch fp64 tensor on the plan's device and bind it as MOMENTS."""
         if self._moments_tensor is None:

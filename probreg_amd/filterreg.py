@@ -229,9 +229,15 @@ class FilterReg(abc.ABC):
         target = _as_points(target)
         if self._source.shape[1] != target.shape[1] or target.shape[1] not in (2, 3):
             raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
+        if feature_fn is None:  # documented selector of the device-resident path
+            feature_fn = _identity
+        if feature_fn is not _identity and feature_fn(self._source) is self._source:
+            # the reference's own idiom `feature_fn=lambda x: x` (filterreg.py:121): a callable that hands the very
+            # object it was given back IS the identity - no numerical probe on a sample (an extractor that needs
+            # neighbourhoods would misbehave on one), just the one call on the whole source cloud
+            feature_fn = _identity
         if feature_fn is not _identity:
-            # any callable other than the module's own identity takes the reference's loop (features on the host every
-            # iteration); it is not probed on a sample - an extractor that needs neighbourhoods would misbehave on one
+            # any other callable takes the reference's loop (features on the host every iteration)
             return self._registration_features(target, w, objective_type, maxiter, tol, min_sigma2, feature_fn)
         q = None
         if self._sigma2 is None:

@@ -103,6 +103,18 @@ class NonRigidTransformation(Transformation):
                 self._g = mu.rbf_kernel(self._points, self._points, self._beta)
         return self._g
 
+    def close(self):
+        """Release the GPU plan an explicit-array M-step (``NonRigidCPD._maximization_step``) cached on this object."""
+        cache = self.__dict__.pop("_mstep_plan", None)
+        if cache is not None:
+            cache[0].close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the library may be gone already
+            pass
+
     def _transform(self, points):
         # same contract as the reference: ``points`` must be the control points the kernel was built on
         if self._plan is not None:

@@ -118,3 +118,96 @@ def test_bench_under_torchrun_with_rccl_when_two_gpus_are_present():
     assert b["n_gpus"] == 2 and b["value"] > 0
     assert abs(a["result"]["sigma2"] - b["result"]["sigma2"]) <= 1e-5 * a["result"]["sigma2"]
     assert abs(a["result"]["q"] - b["result"]["q"]) <= 1e-5 * abs(a["result"]["q"])
+
+
+def _bench_line(args, extra_env, timeout=900):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(extra_env)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, universal_newlines=True, timeout=timeout)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks itself and report n_gpus = 2
+    (round 3: --gpus was parsed and ignored - an 8-GPU scaling run would have recorded one rank).  One GPU here, so both
+    ranks share it and the collective is gloo's; launcher, sharding, per-iteration all-reduce and the line are the code an
+    8-GPU node runs.  The EM state after the window must be the 1-rank run's."""
+    common = ["--steps", "6", "--warmup", "1", "--workload", "rigid_20k", "--no-cpu-baseline", "--no-other-workloads"]
+    one = _bench_line(["--gpus", "1"] + common, {})
+    two = _bench_line(["--gpus", "2"] + common, {"PROBREG_SHARE_GPU": "1", "PROBREG_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["n_local"] * 2 == two["config"]["n_global"]
+    assert "gloo" in two["config"]["collective"]
+    assert abs(one["result"]["sigma2"] - two["result"]["sigma2"]) <= 1e-5 * one["result"]["sigma2"]
+    assert abs(one["result"]["q"] - two["result"]["q"]) <= 1e-5 * abs(one["result"]["q"])
+
+
+def test_world_size_and_gpus_flag_must_agree():
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--workload", "rigid_20k"], cwd=root,
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert run.returncode != 0 and "must agree" in (run.stderr + run.stdout)
+
+
+def test_library_side_rccl_all_reduce_one_rank():
+    """The per-iteration collective inside the C-ABI (prg_comm_*, ncclAllReduce on the plan's stream): with a one-rank
+    communicator the registration must be BIT-identical to the plain one, and the library must have issued exactly one
+    all-reduce per EM iteration plus one for the sigma2 initialiser (+ the probe of the communicator's creation)."""
+    import torch
+
+    from probreg_amd import cpd, dist, synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(20000, seed=5)
+    plain = cpd.registration_cpd(src, tgt, "rigid", maxiter=12, tol=-1.0)
+    os.environ["PROBREG_NATIVE_RCCL"] = "1"
+    try:
+        dist.reset_native_comms()
+        comm = dist.native_comm(torch.cuda.current_device())
+        assert comm is not None and comm.nranks == 1
+        before = comm.calls()
+        reg = cpd.RigidCPD(src)
+        res = reg.registration(tgt, maxiter=12, tol=-1.0)
+        assert reg._plan._comm is comm
+        assert comm.calls() - before == 12 + 1
+        assert res.sigma2 == plain.sigma2 and res.q == plain.q
+        assert np.array_equal(res.transformation.rot, plain.transformation.rot)
+        # with a tolerance to test (host reads q every iteration) the Python loop runs: same collective, same numbers
+        res2 = cpd.registration_cpd(src, tgt, "rigid", maxiter=12, tol=0.0)
+        assert res2.sigma2 == plain.sigma2
+        # non-rigid: the per-point block goes through the library's all-reduce as well
+        s_n, t_n = synthetic.nonrigid_pair(3000, seed=6)
+        os.environ["PROBREG_NATIVE_RCCL"] = "0"
+        dist.reset_native_comms()
+        ref = cpd.registration_cpd(s_n, t_n, "nonrigid", maxiter=4, tol=-1.0)
+        os.environ["PROBREG_NATIVE_RCCL"] = "1"
+        dist.reset_native_comms()
+        got = cpd.registration_cpd(s_n, t_n, "nonrigid", maxiter=4, tol=-1.0)
+        assert got.sigma2 == ref.sigma2 and np.array_equal(got.transformation.w, ref.transformation.w)
+    finally:
+        os.environ.pop("PROBREG_NATIVE_RCCL", None)
+        dist.reset_native_comms()
+
+
+def test_nccl_process_group_selects_the_library_side_collective():
+    """A (single-rank) nccl process group: `bench.py` must report the library-side RCCL collective in its line - the path an
+    8-GPU run takes - and reproduce the run without any process group."""
+    common = ["--gpus", "1", "--steps", "6", "--warmup", "1", "--workload", "rigid_20k", "--no-cpu-baseline", "--no-other-workloads"]
+    plain = _bench_line(common, {})
+    forced = _bench_line(common, {"PROBREG_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())})
+    assert forced["config"]["collective_path"].startswith("library-side RCCL"), forced["config"]
+    assert forced["result"]["sigma2"] == plain["result"]["sigma2"] and forced["result"]["q"] == plain["result"]["q"]
