@@ -271,10 +271,13 @@ int prg_cpd_bcpd_solve(prg_cpd* h, double lmd, double cfac, const double* nu_hd,
 
 /* ---- direct Gauss transform ------------------------------------------------------------ */
 /* out[c*t + i] = sum_j weights[c*s + j] * exp(-|target_i - source_j|^2 / h^2), float64 out.
+ * Unlike the CPD clouds these are FLOAT64 (row-major count x dim): the reference's direct path works on the arrays as
+ * given (float64), and a narrow kernel is sensitive to the rounding of the coordinates - the differences are formed in
+ * fp64, distance and exponential in fp32, weights and sums in fp64; up to four weight rows share one sweep.
  * Replaces: gauss_transform._gauss_transform_direct / Direct.compute / GaussTransform.compute
  * (gauss_transform.py:10-25, 46-60). */
-int prg_gauss_transform_direct(int device, void* hip_stream, const float* source_hd, int64_t s,
-                               const float* target_hd, int64_t t, int dim, const double* weights_hd,
+int prg_gauss_transform_direct(int device, void* hip_stream, const double* source_hd, int64_t s,
+                               const double* target_hd, int64_t t, int dim, const double* weights_hd,
                                int n_weight_rows, double h, double* out_hd);
 
 /* sum_{m,n} |x_m - y_n|^2 / (M*D*N), closed form in fp64 on the device.

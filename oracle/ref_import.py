@@ -113,6 +113,38 @@ def load_bcpd():
     return importlib.import_module("probreg.bcpd")
 
 
+def load_gauss():
+    """The reference's ``probreg.gauss_transform`` and ``probreg.cost_functions`` as they lie on disk.
+
+    ``probreg._ifgt`` (cc/ifgt.cc needs Eigen: not buildable here) is stood in for by the reference's OWN ``Direct``
+    class (gauss_transform.py:19-25): IFGT approximates exactly that sum to ``eps`` (1e-4 by default), so above the
+    ``sw_h`` switch the fixtures hold the value the reference's IFGT approximates, below it the value its direct path returns.
+    ``transforms3d`` is only touched by the rigid cost function's quaternion code, never by ``compute_l2_dist``."""
+    if "gauss" in _loaded:
+        return _loaded["gauss"]
+    load(with_filterreg=False)
+    for name in ("transforms3d", "transforms3d.quaternions", "transforms3d.euler"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if "probreg._ifgt" not in sys.modules or getattr(sys.modules["probreg._ifgt"], "Ifgt", None) is None:
+        sys.modules["probreg._ifgt"] = types.ModuleType("probreg._ifgt")
+    sys.modules["probreg._ifgt"].Ifgt = None
+    ns = types.SimpleNamespace()
+    ns.gauss_transform = importlib.import_module("probreg.gauss_transform")
+
+    class _IfgtAsDirect(object):  # same constructor / compute signature as cc/ifgt_py.cc:14
+        def __init__(self, source, h, eps):
+            self._impl = ns.gauss_transform.Direct(np.asarray(source, dtype=np.float64), h)
+
+        def compute(self, target, weights):
+            return self._impl.compute(np.asarray(target, dtype=np.float64), np.asarray(weights, dtype=np.float64))
+
+    sys.modules["probreg._ifgt"].Ifgt = _IfgtAsDirect
+    ns.gauss_transform._ifgt.Ifgt = _IfgtAsDirect
+    ns.cost_functions = importlib.import_module("probreg.cost_functions")
+    _loaded["gauss"] = ns
+    return ns
+
+
 def load(with_filterreg=False):
     """Return a namespace with the reference's ``cpd`` (and optionally ``filterreg``) modules."""
     if not available():

@@ -105,37 +105,59 @@ __global__ __launch_bounds__(kBlock) void k_rbf(const float* __restrict__ x, int
     }
 }
 
-// out[c][i] = sum_j w[c][j] exp2(kk |t_i - s_j|^2); lane owns a target point, source streamed
-// through SGPRs as (x, y, z, w_c) float4; fp32 pair arithmetic, fp64 accumulation per 256-chunk.
-__global__ __launch_bounds__(kBlock) void k_gauss_direct(const float4* __restrict__ src4, int64_t s_cap,
-                                                         const float* __restrict__ tgt, int64_t t, int dim, float kk,
-                                                         double* __restrict__ out) {
+// out[c][i] = sum_j w[c][j] exp2(kk |t_i - s_j|^2) for C weight rows in ONE sweep (one exponential per pair whatever C is).
+// The reference's direct path works on float64 arrays (gauss_transform.py:10-16), and a narrow kernel (h ~ 1e-2 of the cloud)
+// is sensitive to the coordinates' rounding: the differences are formed in fp64 (exact to 1e-16 of the coordinates) and only
+// then rounded to fp32 - squared distance and exponential in fp32 (relative error of a term ~ (d/h)^2 x 1.2e-7), sums and
+// weights in fp64.  A lane owns a target point; the source (x, y, z as doubles) and the weight rows are read through
+// wave-uniform addresses (scalar loads), four points per trip.
+template <int C>
+__global__ __launch_bounds__(kBlock) void k_gauss_direct(const double* __restrict__ src3, int64_t s_cap,
+                                                         const double* __restrict__ wrows, const double* __restrict__ tgt,
+                                                         int64_t t, int dim, float kk, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    float tx = 0.f, ty = 0.f, tz = 0.f;
+    double tx = 0.0, ty = 0.0, tz = 0.0;
     if (i < t) {
         tx = tgt[i * dim];
         ty = tgt[i * dim + 1];
-        tz = dim > 2 ? tgt[i * dim + 2] : 0.f;
+        tz = dim > 2 ? tgt[i * dim + 2] : 0.0;
     }
-    double acc = 0.0;
-    for (int64_t j0 = 0; j0 < s_cap; j0 += 256) {
-        float part = 0.f;
-        for (int j = 0; j < 256; j += 4) {
+    double acc[C];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float4 q = src4[j0 + j + c];
-                const float dx = tx - q.x, dy = ty - q.y, dz = tz - q.z;
-                float d = dx * dx;
-                d = fmaf(dy, dy, d);
-                d = fmaf(dz, dz, d);
-                part = fmaf(q.w, __builtin_amdgcn_exp2f(kk * d), part);
-            }
+    for (int c = 0; c < C; ++c) acc[c] = 0.0;
+    for (int64_t j0 = 0; j0 < s_cap; j0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u;
+            const float dx = (float)(tx - src3[3 * j]), dy = (float)(ty - src3[3 * j + 1]), dz = (float)(tz - src3[3 * j + 2]);
+            float d = dx * dx;
+            d = fmaf(dy, dy, d);
+            d = fmaf(dz, dz, d);
+            const double e = (double)__builtin_amdgcn_exp2f(kk * d);
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = fma(wrows[(int64_t)c * s_cap + j], e, acc[c]);
         }
-        acc += (double)part;
     }
-    if (i < t) out[i] = acc;
+    if (i < t) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[(int64_t)c * t + i] = acc[c];
+    }
 }
 
+// source rows (dim doubles each) -> [cap][3] doubles, pads far away; weight rows -> [rows][cap], pads 0
+__global__ __launch_bounds__(kBlock) void k_pack_gauss(const double* __restrict__ s, const double* __restrict__ w, int64_t n,
+                                                       int dim, int rows, int64_t cap, double* __restrict__ src3,
+                                                       double* __restrict__ wrows) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cap) return;
+    const bool in = i < n;
+    src3[3 * i] = in ? s[i * dim] : (double)prg::kSrcPad;
+    src3[3 * i + 1] = in ? s[i * dim + 1] : (double)prg::kSrcPad;
+    src3[3 * i + 2] = in ? (dim > 2 ? s[i * dim + 2] : 0.0) : (double)prg::kSrcPad;
+    for (int c = 0; c < rows; ++c) wrows[(int64_t)c * cap + i] = in ? w[(int64_t)c * n + i] : 0.0;
+}
+
+// points (+ optional per-point weight in .w) -> float4, pads far away
 __global__ __launch_bounds__(kBlock) void k_pack_weighted(const float* __restrict__ s, const double* __restrict__ w,
                                                           int64_t n, int dim, int64_t cap,
                                                           float4* __restrict__ out) {
@@ -365,7 +387,7 @@ int prg_nn_mean_distance(int device, void* hip_stream, const float* a_hd, int64_
     return PRG_OK;
 }
 
-int prg_gauss_transform_direct(int device, void* hip_stream, const float* source_hd, int64_t s, const float* target_hd,
+int prg_gauss_transform_direct(int device, void* hip_stream, const double* source_hd, int64_t s, const double* target_hd,
                                int64_t t, int dim, const double* weights_hd, int n_weight_rows, double h,
                                double* out_hd) {
     PRG_REQUIRE(source_hd && target_hd && weights_hd && out_hd, PRG_ERR_INVALID,
@@ -376,24 +398,37 @@ int prg_gauss_transform_direct(int device, void* hip_stream, const float* source
     PRG_REQUIRE(g.ok, PRG_ERR_HIP, "prg_gauss_transform_direct: hipSetDevice(%d) failed", device);
     hipStream_t st = (hipStream_t)hip_stream;
     const int64_t cap = prg::round_up(s, 256);
-    TmpBuf bs, bt, bw, b4, bo;
-    PRG_HIP(hipMalloc(&bs.p, (size_t)s * dim * sizeof(float)));
-    PRG_HIP(hipMalloc(&bt.p, (size_t)t * dim * sizeof(float)));
-    PRG_HIP(hipMalloc(&bw.p, (size_t)s * n_weight_rows * sizeof(double)));
-    PRG_HIP(hipMalloc(&b4.p, (size_t)cap * sizeof(float4)));
-    PRG_HIP(hipMalloc(&bo.p, (size_t)t * n_weight_rows * sizeof(double)));
-    PRG_HIP(hipMemcpyAsync(bs.p, source_hd, (size_t)s * dim * sizeof(float), hipMemcpyDefault, st));
-    PRG_HIP(hipMemcpyAsync(bt.p, target_hd, (size_t)t * dim * sizeof(float), hipMemcpyDefault, st));
-    PRG_HIP(hipMemcpyAsync(bw.p, weights_hd, (size_t)s * n_weight_rows * sizeof(double), hipMemcpyDefault, st));
+    const int rows = n_weight_rows;
+    TmpBuf bs, bt, bw, b3, bwr, bo;
+    PRG_HIP(hipMalloc(&bs.p, (size_t)s * dim * sizeof(double)));
+    PRG_HIP(hipMalloc(&bt.p, (size_t)t * dim * sizeof(double)));
+    PRG_HIP(hipMalloc(&bw.p, (size_t)s * rows * sizeof(double)));
+    PRG_HIP(hipMalloc(&b3.p, (size_t)cap * 3 * sizeof(double)));
+    PRG_HIP(hipMalloc(&bwr.p, (size_t)cap * rows * sizeof(double)));
+    PRG_HIP(hipMalloc(&bo.p, (size_t)t * rows * sizeof(double)));
+    PRG_HIP(hipMemcpyAsync(bs.p, source_hd, (size_t)s * dim * sizeof(double), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bt.p, target_hd, (size_t)t * dim * sizeof(double), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(bw.p, weights_hd, (size_t)s * rows * sizeof(double), hipMemcpyDefault, st));
     const float kk = (float)(-1.4426950408889634 / (h * h));
-    for (int c = 0; c < n_weight_rows; ++c) {
-        k_pack_weighted<<<(unsigned)prg::ceil_div(cap, kBlock), kBlock, 0, st>>>(
-            (const float*)bs.p, (const double*)bw.p + (size_t)c * s, s, dim, cap, (float4*)b4.p);
-        k_gauss_direct<<<(unsigned)prg::ceil_div(t, kBlock), kBlock, 0, st>>>(
-            (const float4*)b4.p, cap, (const float*)bt.p, t, dim, kk, (double*)bo.p + (size_t)c * t);
+    k_pack_gauss<<<(unsigned)prg::ceil_div(cap, kBlock), kBlock, 0, st>>>((const double*)bs.p, (const double*)bw.p, s, dim, rows, cap,
+                                                                         (double*)b3.p, (double*)bwr.p);
+    const unsigned grid = (unsigned)prg::ceil_div(t, kBlock);
+    for (int c = 0; c < rows;) {  // four weight rows per sweep (compute_l2_dist: 1 + D rows = one sweep), then 2, then 1
+        const double* w = (const double*)bwr.p + (size_t)c * cap;
+        double* o = (double*)bo.p + (size_t)c * t;
+        if (rows - c >= 4) {
+            k_gauss_direct<4><<<grid, kBlock, 0, st>>>((const double*)b3.p, cap, w, (const double*)bt.p, t, dim, kk, o);
+            c += 4;
+        } else if (rows - c >= 2) {
+            k_gauss_direct<2><<<grid, kBlock, 0, st>>>((const double*)b3.p, cap, w, (const double*)bt.p, t, dim, kk, o);
+            c += 2;
+        } else {
+            k_gauss_direct<1><<<grid, kBlock, 0, st>>>((const double*)b3.p, cap, w, (const double*)bt.p, t, dim, kk, o);
+            c += 1;
+        }
     }
     PRG_HIP(hipGetLastError());
-    PRG_HIP(hipMemcpyAsync(out_hd, bo.p, (size_t)t * n_weight_rows * sizeof(double), hipMemcpyDefault, st));
+    PRG_HIP(hipMemcpyAsync(out_hd, bo.p, (size_t)t * rows * sizeof(double), hipMemcpyDefault, st));
     PRG_HIP(hipStreamSynchronize(st));
     return PRG_OK;
 }

@@ -16,8 +16,8 @@ from .engine import _current_device_and_stream
 def _gauss_transform_direct(source, target, weights, h):
     r"""\sum_j weights[j] * exp(-||target[i] - source[j]||^2 / h^2)   (gauss_transform.py:10-16)."""
     _lib.require_gpu()
-    source = np.ascontiguousarray(source, dtype=np.float32)
-    target = np.ascontiguousarray(target, dtype=np.float32)
+    source = np.ascontiguousarray(source, dtype=np.float64)  # float64 across the ABI: differences are formed in fp64
+    target = np.ascontiguousarray(target, dtype=np.float64)
     weights = np.ascontiguousarray(weights, dtype=np.float64)
     if weights.ndim == 1:
         rows = 1

@@ -473,7 +473,68 @@ def main_features():
     print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
 
 
+def main_gauss():
+    """the reference's own ``GaussTransform.compute`` (gauss_transform.py:46-60; 1-D and 2-D
+    weights, bandwidth below and above the ``sw_h`` switch - above it through ``ref_import.load_gauss``'s Ifgt stand-in, which
+    is the reference's Direct class) and ``compute_l2_dist`` (cost_functions.py:33-41: value and gradient), at 5k x 5k and
+    on small / 2-D / far-from-origin inputs."""
+    ref = ref_import.load_gauss()
+    gt, cf = ref.gauss_transform, ref.cost_functions
+    flat = {}
+    rng = np.random.default_rng(77)
+
+    def gt_case(name, src, tgt, weights, h):
+        out = gt.GaussTransform(src, h).compute(tgt, weights)
+        pre = "gt/%s/" % name
+        flat[pre + "source"], flat[pre + "target"], flat[pre + "h"] = src, tgt, np.asarray(float(h))
+        if weights is not None:
+            flat[pre + "weights"] = weights
+        flat[pre + "out"] = np.asarray(out)
+        print("gauss transform %-28s h=%.4g out[0..1]=%s" % (name, h, np.asarray(out).ravel()[:2]))
+
+    def l2_case(name, mu_s, phi_s, mu_t, phi_t, sigma):
+        f, g = cf.compute_l2_dist(mu_s, phi_s, mu_t, phi_t, sigma)
+        pre = "l2/%s/" % name
+        flat[pre + "mu_source"], flat[pre + "phi_source"] = mu_s, phi_s
+        flat[pre + "mu_target"], flat[pre + "phi_target"] = mu_t, phi_t
+        flat[pre + "sigma"], flat[pre + "out_f"], flat[pre + "out_g"] = np.asarray(float(sigma)), np.asarray(float(f)), np.asarray(g)
+        print("l2 distance     %-28s sigma=%.4g f=%.10e |g|max=%.4e" % (name, sigma, f, np.max(np.abs(g))))
+
+    src5, tgt5, _ = synthetic.rigid_pair(5000, seed=71)
+    w1 = rng.uniform(0.2, 1.5, 5000)
+    w2 = rng.normal(size=(4, 5000))
+    # h < sw_h = 0.01: the reference's direct path; targets = jittered source points, so every target has neighbours within h
+    near = src5[rng.permutation(5000)] + rng.normal(scale=0.004, size=(5000, 3))
+    gt_case("surf5k_direct_h0.008_w1d", src5, near, w1, 0.008)
+    gt_case("surf5k_direct_h0.008_none", src5, near, None, 0.008)    # weights=None -> ones
+    gt_case("surf5k_direct_h0.008_far", src5, tgt5[:500], w1, 0.008)  # nothing within ~10 h: values down to 1e-180
+    gt_case("surf5k_wide_h0.35_w2d", src5, tgt5, w2, 0.35)           # h >= sw_h: what its IFGT approximates; 2-D weights
+    gt_case("surf5k_mid_h0.05_w1d", src5, tgt5, w1, 0.05)
+    s2 = rng.normal(size=(700, 2))
+    t2 = rng.normal(size=(900, 2)) * 1.1 + 0.2
+    gt_case("blob2d_h0.6_w2d", s2, t2, rng.uniform(-1, 1, size=(3, 700)), 0.6)
+    far = np.array([250.0, -120.0, 1277.0])
+    gt_case("far_offset_h0.2_w1d", src5[:1500] + far, tgt5[:1300] + far, w1[:1500], 0.2)
+    gt_case("tiny_3x2", rng.normal(size=(3, 3)), rng.normal(size=(2, 3)), np.array([1.0, -2.0, 0.5]), 1.3)
+
+    phi_s = rng.uniform(0.5, 1.5, 5000)
+    phi_s /= phi_s.sum()
+    phi_t = rng.uniform(0.5, 1.5, 5000)
+    phi_t /= phi_t.sum()
+    l2_case("surf5k_sigma0.05", src5, phi_s, tgt5, phi_t, 0.05)
+    l2_case("surf5k_sigma0.005_direct", src5, phi_s, tgt5, phi_t, 0.005)   # sqrt(2) sigma < sw_h: the reference's direct path
+    l2_case("surf5k_sigma0.3", src5, phi_s, tgt5, phi_t, 0.3)
+    l2_case("blob2d_sigma0.4", s2, np.full(700, 1.0 / 700), t2, np.full(900, 1.0 / 900), 0.4)
+    l2_case("self_sigma0.1", src5[:2000], phi_s[:2000], src5[:2000], phi_s[:2000], 0.1)  # TPSCostFunction's f1 (cost_functions.py:106)
+    out = os.path.join(HERE, "gauss_golden.npz")
+    np.savez_compressed(out, **flat)
+    print("wrote %s (%d arrays, %.1f KB)" % (out, len(flat), os.path.getsize(out) / 1024.0))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gauss":
+        main_gauss()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "features":
         main_features()
         sys.exit(0)
