@@ -1252,6 +1252,12 @@ int prg_cpd_last_estep_lean(prg_cpd* h, int* lean) {
     return PRG_OK;
 }
 
+int prg_cpd_set_lean_factor(prg_cpd* h, double factor) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_lean_factor: NULL handle");
+    h->lean_factor = factor;
+    return PRG_OK;
+}
+
 int prg_cpd_set_options(prg_cpd* h, int sort_source, int sort_target, int cull) {
     PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_options: NULL handle");
     PRG_REQUIRE(!h->have_source && !h->have_target, PRG_ERR_STATE,
@@ -1495,7 +1501,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         static const double lean_env = getenv("PRG_LEAN_FACTOR") ? atof(getenv("PRG_LEAN_FACTOR")) : -1.0;
         // (tools/lean_error.py, profiles/r3_lean_error_*.log: with the row-sum scaling of k_xpx_columns sigma2 stays within
         // 2.7e-6 of the oracle's up to an amplification of 190; without it the error was 6e-7 per unit - 16 is safe either way)
-        ea.lean_factor = lean_env >= 0.0 ? lean_env : 16.0;
+        ea.lean_factor = h->lean_factor >= 0.0 ? h->lean_factor : lean_env >= 0.0 ? lean_env : 16.0;
         ea.reset = h->eng_reset ? 1 : 0;
         h->eng_reset = false;
         for (int k = 0; k < 6; ++k) ea.tbox[k] = h->tbox[k];

@@ -104,6 +104,10 @@ class CpdPlan(object):
         check(lib.prg_cpd_last_estep_lean(self._h, ctypes.byref(v)))
         return int(v.value)
 
+    def set_lean_factor(self, factor=-1.0):
+        """Lean matrix-core row pass while mean |x|^2 / (sigma2 D) <= factor (default 16; 0 never; < 0 restores the default)."""
+        check(lib.prg_cpd_set_lean_factor(self._h, float(factor)))
+
     def set_source(self, source):
         a = self._f32(source)
         self.m, self.dim = int(a.shape[0]), int(a.shape[1])

@@ -81,6 +81,9 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
 
     # ---- from the identity: every pair is evaluated (dense regime) ----
     res = reg.registration(tgt, w=0.0, maxiter=k_dense, tol=-1.0)
+    # the iteration just compared ran on the matrix cores with the LEAN row pass (no residual sums; default factor 16):
+    # what is held to the oracle below is that kernel, by name
+    assert reg._plan.last_estep_engines() == (1, 1) and reg._plan.last_estep_lean() == 1
     s2_0 = co.squared_kernel_sum_closed_form(src, tgt)
     p, s2, q = _oracle_iterations(kind, src, tgt, ident, s2_0, k_dense)
     _check(kind, res, p, s2, q)
