@@ -102,11 +102,11 @@ int prg_cpd_set_sparse_engine(prg_cpd* h, int mode);
 /* ... and for both sweeps of the last E-step: 1 = matrix cores, 0 = vector pipe (column pass, row pass). */
 int prg_cpd_last_estep_engines(prg_cpd* h, int* col_engine, int* row_engine);
 /* 1 if the last E-step's matrix-core row pass ran WITHOUT its residual sums sum_n P_mn |x_n - o|^2 (19 instead of 21 flop
- * per pair): while sigma2 * D * 16 >= mean |x|^2 of the local target the M-step's sum_n pt1_n |x_n|^2 is taken from the column
+ * per pair): while sigma2 * D * 64 >= mean |x|^2 of the local target the M-step's sum_n pt1_n |x_n|^2 is taken from the column
  * side instead. */
 int prg_cpd_last_estep_lean(prg_cpd* h, int* lean);
 /* The amplification up to which the row pass may run lean: while mean |x|^2 / (sigma2 D) of the local target <= factor
- * (default 16; 0 = never; a huge value = wherever the matrix-core row pass runs - tests and tools/lean_error.py measure the
+ * (default 64; 0 = never; a huge value = wherever the matrix-core row pass runs - tests and tools/lean_error.py measure the
  * sigma2 error of the lean pass far beyond where the default allows it); negative restores the default. */
 int prg_cpd_set_lean_factor(prg_cpd* h, double factor);
 

@@ -127,7 +127,7 @@ struct prg_cpd {
     EngineDecision* eng_host_dev = nullptr;  // ... as the device addresses it
     int pred_col = 1;           // the column-pass engine the host launches ahead of the decision (= the previous decision)
     bool last_estep_row_lean = false;  // ... matrix-core row pass without its residual sums
-    double lean_factor = -1.0;         // lean row pass while mean |x|^2 / (sigma2 D) <= this (< 0: the default, 16; prg_cpd_set_lean_factor)
+    double lean_factor = -1.0;         // lean row pass while mean |x|^2 / (sigma2 D) <= this (< 0: the default, 64; prg_cpd_set_lean_factor)
     bool last_estep_mfma = false, last_estep_row_mfma = false;  // engines of the last E-step's column / row pass
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)

@@ -224,8 +224,8 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
 #pragma unroll
             for (int sh = 1; sh < 16; sh <<= 1) cm = fmaxf(cm, __shfl_xor(cm, sh, 64));
             const float r = sqrtf(cm) + mo, rw = sqrtf(cw) + mo;
-            thr = r * r * 1.00001f + (-127.0f) / kk;
-            thr_w = rw * rw * 1.00001f + (-127.0f) / kk;
+            thr = r * r * 1.00001f + (-prg::kCullExp) / kk;
+            thr_w = rw * rw * 1.00001f + (-prg::kCullExp) / kk;
         }
     } else {
         o = tgt4[n0wg];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     const int nc = (int)((c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks) - c0);  // <= 64
     // a chunk is skipped when every P of the (patch, chunk) block is an exact zero: kk dist^2(boxes) + max b_n < -127
     const BoxMeta cm = tchunk[c0 + (lane < nc ? lane : nc - 1)];
-    unsigned long long mask = __ballot(lane < nc && !(fmaf(box_gap2(lo, hi, cm), kk, cm.aux) < -127.0f));
+    unsigned long long mask = __ballot(lane < nc && !(fmaf(box_gap2(lo, hi, cm), kk, cm.aux) < -prg::kCullExp));
     unsigned tiles_done = 0;
     if (mask) {
         int cur = __builtin_ctzll(mask);
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
             unsigned tmask = 0xFFFFu;
             if (wave_cull)
                 tmask = tiles_of_groups(
-                    (unsigned)__ballot(lane < 8 && !(fmaf(box_gap2(wb.lo, wb.hi, gm), kk, gm.aux) < -127.0f)) & 0xFFu);
+                    (unsigned)__ballot(lane < 8 && !(fmaf(box_gap2(wb.lo, wb.hi, gm), kk, gm.aux) < -prg::kCullExp)) & 0xFFu);
             const int nxt = mask ? __builtin_ctzll(mask) : -1;
             mask &= mask - 1;
             if (nxt >= 0) {
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     d.col = col ? 1 : 0;
     d.first = first ? 1 : 0;
     d.row = row ? 1 : 0;
-    d.fine = nk * eng.ext2 > 200.0 ? 1 : 0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2): the test is overhead
+    d.fine = nk * eng.ext2 > 200.0 * (prg::kCullExp / 127.0) ? 1 : 0;  // below, every group of every chunk is needed (C1: sigma2 > 3e-2): the test is overhead
     d.dense = dense ? 1 : 0;
     d.sigma2 = (float)sigma2; d.motion = (float)mo; d.cmax = (float)cmax;
     d.nk_ext2 = (float)(nk * eng.ext2); d.nk_width = (float)(nk * width); d.nk_far2 = (float)(nk * far2);

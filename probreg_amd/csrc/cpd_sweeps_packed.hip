@@ -199,7 +199,7 @@ void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len) {
 // =============================================================================================
 namespace {
 
-constexpr float kCullLog2 = -127.0f;
+constexpr float kCullLog2 = -prg::kCullExp;  // (cpd_sweeps.h)
 
 #ifdef PRG_WAVE_TRACE
 // Instrumented build (tools/wave_trace.py): every wave of the culled sweeps records its start / end shader clock,

@@ -33,7 +33,7 @@ struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; }
 
 constexpr double kLog2e = 1.4426950408889634;
 constexpr int kBlock = prg::kSweepBlock;
-constexpr float kCullLog2 = -127.0f;
+constexpr float kCullLog2 = -prg::kCullExp;  // (cpd_sweeps.h)
 constexpr int kChunkGroups = prg::kQueueChunkGroups;  // 512 streamed groups = 8 mask words per (block, chunk)
 constexpr int kChunkWords = kChunkGroups / 64;
 constexpr int kBuildWaves = 16;                       // waves (= chunks) per workgroup of the build kernel

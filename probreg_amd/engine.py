@@ -105,7 +105,7 @@ class CpdPlan(object):
         return int(v.value)
 
     def set_lean_factor(self, factor=-1.0):
-        """Lean matrix-core row pass while mean |x|^2 / (sigma2 D) <= factor (default 16; 0 never; < 0 restores the default)."""
+        """Lean matrix-core row pass while mean |x|^2 / (sigma2 D) <= factor (default 64; 0 never; < 0 restores the default)."""
         check(lib.prg_cpd_set_lean_factor(self._h, float(factor)))
 
     def set_source(self, source):

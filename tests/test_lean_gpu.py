@@ -2,7 +2,7 @@
 the M-step takes sum_n pt1_n |x_n|^2 from the column side, k_colfinal's partials -> k_xpx_columns) by name: it is ON by
 default for the first EM iterations of C1 / C2 (tests/test_fullsize_gpu.py asserts that on the compared iteration); here it
 is FORCED (prg_cpd_set_lean_factor(1e30): lean wherever the matrix-core row pass runs) far beyond the amplification
-mean |x|^2 / (sigma2 D) <= 16 where the default allows it, and sigma2 after the M-step (cpd.py:186-191: sigma2 and q from
+mean |x|^2 / (sigma2 D) <= 64 where the default allows it, and sigma2 after the M-step (cpd.py:186-191: sigma2 and q from
 the moments) is held to 1e-5 of the fp64 oracle's - with w = 0 and w = 0.1, and on a 2-rank shard."""
 import os
 import socket
@@ -60,31 +60,37 @@ def test_forced_lean_pass_along_a_100k_rigid_registration(w):
 
 
 def test_default_lean_window_and_switch_off():
-    """Default factor: the first iterations of C1 run lean, and the pass turns itself off when sigma2 has fallen below
-    mean |x|^2 / (16 D); factor 0 never runs it; both give the oracle's sigma2."""
+    """Default factor (64): every matrix-core row pass of C1 runs lean - iterations 0..11 -, and the flag is off once the row
+    pass has gone to the vector pipe; factor 16 (rounds 3's default) turns it off while the matrix cores still run (iterations
+    8+); factor 0 never runs it; all give the oracle's sigma2."""
     from probreg_amd import cpd, synthetic
 
     src, tgt, _ = synthetic.rigid_pair(100000, seed=0)
     seen = {}
-    for factor in (-1.0, 0.0):
+    for factor in (-1.0, 16.0, 0.0):
         reg = cpd.RigidCPD(src)
         reg._initialize(tgt)
         plan = reg._plan
         plan.set_lean_factor(factor)
-        flags = []
-        for it in range(12):
-            st = reg._result_from_params(plan.get_params()) if it == 3 else None
+        flags, rows = [], []
+        for it in range(15):
+            st = reg._result_from_params(plan.get_params()) if it == 9 else None
             plan.estep(0.0)
             flags.append(plan.last_estep_lean())
+            rows.append(plan.last_estep_engines()[1])
             reg._device_mstep(plan)
-            if it == 3:
+            if it == 9:  # amplification 24: lean with the default, not with 16
                 _, s2, _ = _oracle_step("rigid", src, tgt, st, 0.0)
                 out = reg._result_from_params(plan.get_params())
                 assert abs(out.sigma2 - s2) <= TOL_SIGMA2 * s2
-        seen[factor] = flags
-    assert seen[-1.0][:6] == [1] * 6 and seen[-1.0][-1] == 0, seen[-1.0]   # on for the first iterations, off by iteration 11
-    assert seen[-1.0] == sorted(seen[-1.0], reverse=True)                  # ... and never back on
-    assert seen[0.0] == [0] * 12
+        seen[factor] = (flags, rows)
+    flags, rows = seen[-1.0]
+    assert flags[:10] == [1] * 10 and flags[-1] == 0 and rows[-1] == 0, (flags, rows)
+    assert flags == sorted(flags, reverse=True)                      # ... never back on
+    assert all(f == r for f, r in zip(flags, rows)), (flags, rows)   # lean exactly where the matrix-core row pass ran
+    f16, r16 = seen[16.0]
+    assert f16[:6] == [1] * 6 and f16[9] == 0 and r16[9] == 1, (f16, r16)
+    assert seen[0.0][0] == [0] * 15
 
 
 def _free_port():
