@@ -107,6 +107,7 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
                 "relative_residuals": resid},
         "reference_numpy_probe": REFERENCE_NUMPY_PROBE,
     }
+    baseline["reference_numpy"] = reference_numpy_baseline(n_full)
     # parity: the product on the SAME 40k input for the SAME number of iterations
     src, tgt, p, s2 = last
     res = cpd.registration_cpd(src, tgt, "rigid", maxiter=iters, tol=-1.0)
@@ -125,6 +126,41 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
     parity["ok"] = bool(parity["rot_max_abs_err"] < 1e-4 and parity["t_max_abs_err"] < 1e-4
                         and parity["scale_rel_err"] < 1e-4 and parity["sigma2_rel_err"] < 1e-5)
     return baseline, parity
+
+
+def reference_numpy_baseline(n_full, sizes=(2000, 5000, 10000), iters=2):
+    """probreg's own NumPy formulation of the EM iteration (cpd.py:71-88 as ONE dense M x N float64 matrix: scipy cdist,
+    exp, divide, sums, dot - oracle/cpd_numpy.expectation_step_unchunked, held to the reference's outputs at 1e-12 by
+    tests/test_oracle_golden.py - plus the M-step of cpd.py:160-192) timed on THIS host at three sizes the matrix fits,
+    fitted t_iter = a M N and extrapolated to the bench size.  NumPy / BLAS use the threads they find (all cores)."""
+    from oracle import cpd_numpy as co
+    from probreg_amd import synthetic
+
+    per_iter = []
+    src, tgt, _ = synthetic.rigid_pair(500, seed=0)
+    co.expectation_step_unchunked(src, tgt, 1.0, 0.0)  # imports, thread pools
+    for ns in sizes:
+        src, tgt, _ = synthetic.rigid_pair(ns, seed=0)
+        sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
+        params = dict(rot=np.identity(3), t=np.zeros(3), scale=1.0)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            es = co.expectation_step_unchunked(co.transform("rigid", params, src), tgt, sigma2, 0.0)
+            params, sigma2, _q = co.mstep_rigid(src, tgt, es)
+        per_iter.append((time.perf_counter() - t0) / iters)
+    mn = np.array([float(s) * s for s in sizes])
+    t = np.array(per_iter)
+    a = float(np.sum(t * mn) / np.sum(mn * mn))
+    return {
+        "value": 1.0 / (a * float(n_full) * n_full), "unit": "EM iterations/s", "kind": "reference formulation (numpy / scipy, fp64)",
+        "cores": os.cpu_count(),
+        "sample": "RigidCPD N=M in %s, %d EM iterations each, dense M x N float64 matrix as in probreg cpd.py:71-88; fit t_iter = a*M*N, "
+                  "value = 1/(a*%d^2) (extrapolated: the 100k matrix alone would be 80 GB and the reference holds three of them)"
+                  % (list(sizes), iters, n_full),
+        "fit": {"a_seconds_per_pair": a, "sizes": list(sizes), "s_per_iteration": per_iter,
+                "it_s_measured": [1.0 / x for x in per_iter],
+                "relative_residuals": [float(ti / (a * x) - 1.0) for ti, x in zip(t, mn)]},
+    }
 
 
 def parity_other_workloads():

@@ -106,6 +106,31 @@ def expectation_step(t_source, target, sigma2, w=0.0, chunk=1024):
     return EstepResult(pt1, p1, px, float(np.sum(p1)))
 
 
+def expectation_step_unchunked(t_source, target, sigma2, w=0.0):
+    """cpd.py:71-88 line by line, the reference's OWN formulation: one dense M x N float64 matrix through scipy's
+    ``cdist`` (the reference's ``distance_module``, cpd.py:57), ``exp``, column sums, ``divide``, row / column sums and
+    ``dot`` - at least nine full passes over the matrix.  This is what `cpu_baseline.reference_numpy` times on the bench
+    host (the reference tree itself does not travel to the GPU box); pinned to the reference's outputs at 1e-12 by
+    tests/test_oracle_golden.py beside the chunked form."""
+    from scipy.spatial import distance as scipy_distance
+
+    t_source = np.asarray(t_source, dtype=np.float64)
+    target = np.asarray(target, dtype=np.float64)
+    assert t_source.ndim == 2 and target.ndim == 2, "source and target must have 2 dimensions."
+    pmat = scipy_distance.cdist(t_source, target, "sqeuclidean")          # :74
+    pmat = np.exp(-pmat / (2.0 * sigma2))                                  # :76
+    c = (2.0 * np.pi * sigma2) ** (t_source.shape[1] * 0.5)                # :78
+    c *= w / (1.0 - w) * t_source.shape[0] / target.shape[0]               # :79
+    den = np.sum(pmat, axis=0)                                             # :80
+    den[den == 0] = np.finfo(np.float32).eps                               # :81
+    den += c                                                               # :82
+    pmat = np.divide(pmat, den)                                            # :84
+    pt1 = np.sum(pmat, axis=0)                                             # :85
+    p1 = np.sum(pmat, axis=1)                                              # :86
+    px = np.dot(pmat, target)                                              # :87
+    return EstepResult(pt1, p1, px, float(np.sum(p1)))                     # :88
+
+
 # ----------------------------------------------------------------------------------------------
 # M-steps
 # ----------------------------------------------------------------------------------------------

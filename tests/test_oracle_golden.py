@@ -59,6 +59,18 @@ def test_estep_matches_reference(cpd_golden, chunk):
         assert abs(es.n_p - c["n_p"]) < 1e-9, name
 
 
+def test_unchunked_estep_matches_reference(cpd_golden):
+    """The reference's own dense-matrix formulation restated line by line (what bench.py's cpu_baseline.reference_numpy
+    times): equal to the reference's E-step outputs to 1e-12."""
+    for name in cpd_golden.group("estep"):
+        c = cpd_golden.case("estep/" + name)
+        es = co.expectation_step_unchunked(c["t_source"], c["target"], c["sigma2"], c["w"])
+        assert np.max(np.abs(es.pt1 - c["pt1"])) < 1e-12, name
+        assert rel_err(es.p1, c["p1"]) < 1e-12, name
+        assert rel_err(es.px, c["px"]) < 1e-12, name
+        assert abs(es.n_p - c["n_p"]) < 1e-9, name
+
+
 def test_dead_column_rule(cpd_golden):
     # cpd.py:81: a column whose every fp64 exp() underflowed gets den = eps32 -> P column == 0
     c = cpd_golden.case("estep/bunny_dead_column_w0")

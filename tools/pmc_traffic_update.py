@@ -18,8 +18,8 @@ def table(name):
         return None
     for line in open(path):
         f = line.split()
-        if len(f) == 4 and f[1] in ("FETCH_SIZE", "WRITE_SIZE"):
-            out.setdefault(f[0], {})[f[1]] = (float(f[2]), int(f[3]))
+        if len(f) >= 4 and f[-3] in ("FETCH_SIZE", "WRITE_SIZE"):  # (kernel names may contain spaces: "k_embed<3, true>")
+            out.setdefault(" ".join(f[:-3]), {})[f[-3]] = (float(f[-2]), int(f[-1]))
     return {k: ((2.0 * v.get("FETCH_SIZE", (0, 0))[0] + v.get("WRITE_SIZE", (0, 0))[0]) * 1024.0,
                 max(v.get("FETCH_SIZE", (0, 0))[1], v.get("WRITE_SIZE", (0, 0))[1])) for k, v in out.items()}
 
@@ -50,11 +50,12 @@ if t:
     out["nonrigid_50k"] = sweep_entry(t, how % "nonrigid_50k")
 t = table("filterreg_500k")
 if t:
-    iters = t.get("k_fr_finish", (0, 0))[1]
+    # one launch of the M-step's terms kernel per EM iteration (round 3 folded k_fr_finish into it; round 4 split it out again)
+    iters = max(t.get("k_fr_terms", (0, 0))[1], t.get("k_fr_terms_pt2pl", (0, 0))[1])
     total = sum(b * n for k, (b, n) in t.items() if not k.startswith(("k_sks", "k_sums", "k_fr_values")))
     out["filterreg_500k"] = {"iteration_hbm_bytes": int(round(total / iters)) if iters else None, "iterations_in_profile": iters,
                              "how": "sum over every kernel of an EM iteration of (2*FETCH_SIZE + WRITE_SIZE)*1024 x launches, "
-                                    "divided by the number of iterations (launches of k_fr_finish); " + how % "filterreg_500k",
+                                    "divided by the number of iterations (launches of k_fr_terms); " + how % "filterreg_500k",
                              "round": int(tag[1:])}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "how"} for k, v in out.items()}, indent=1))
