@@ -1222,6 +1222,7 @@ int prg_cpd_set_dense_engine(prg_cpd* h, int mode, double bound) {
     if (bound > 0.0) h->dense_bound = bound;
     h->mfma_off = false;
     h->pred_col = 1;
+    h->pred_fine = 0;
     h->eng_reset = true;
     return PRG_OK;
 }
@@ -1313,6 +1314,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     h->have_colmin = false;  // a new registration starts: its first column pass takes no seed from the previous one
     h->mfma_off = false;     // ... and it starts in the dense regime
     h->pred_col = 1;
+    h->pred_fine = 0;
     h->eng_reset = true;
     return PRG_OK;
 }
@@ -1402,8 +1404,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const bool mfma_possible = use_cull && h->dense_engine > 0 && !h->srcw &&
                                (h->dense_engine >= 2 || (h->M >= 8192 && h->N >= 8192));
     static const int mfma_seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;  // 0: fill the chip once
-    const int PAm = mfma_possible ? prg::mfma_planes(h->N, h->M, mfma_seg) : 0,
-              PBm = mfma_possible ? prg::mfma_planes(h->M, h->N, mfma_seg) : 0;
+    // (buffers are sized for whichever way a matrix-core launch is cut: grid of segments or stream mode)
+    const int PAm = mfma_possible ? std::max(prg::mfma_planes(h->N, h->M, mfma_seg), prg::mfma_stream_planes(h->N, h->M)) : 0,
+              PBm = mfma_possible ? std::max(prg::mfma_planes(h->M, h->N, mfma_seg), prg::mfma_stream_planes(h->M, h->N)) : 0;
     // sparse regime: sweeps over a device-built work queue (cpd_sweeps_queue.hip) - partial results per unit, not per plane
     // ... when both clouds are large: the queue costs a build pass and leaves more partial results than the grid of culled
     // waves, which only pays off while a sweep is long (measured at C1: ahead with the target on 1 or 2 ranks, behind on 4 and 8)
@@ -1517,8 +1520,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         prg::launch_chunk_meta_bbox(h, &ea);
         if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
         const bool pred = h->pred_col != 0;
-        if (pred)
-            prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev);
+        if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
+            prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev, h->pred_fine == 0);
         else if (!use_queue)
             prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev);
         // (pred == vector pipe with the work queue: nothing goes out ahead - inside the dense regime that engine only runs
@@ -1548,8 +1551,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                     pred == use_mfma ? "yes" : "NO", (int)row_mfma, (int)fine_cull);
         col_launched = pred == use_mfma && (pred || !use_queue);
         h->pred_col = use_mfma ? 1 : 0;
+        h->pred_fine = fine_cull ? 1 : 0;
         if (!col_launched && use_mfma) {  // (the guarded launch has returned at once; rare: the engine changes once or twice per registration)
-            prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev);
+            prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev, !fine_cull);
             col_launched = true;
         }
     }
@@ -1569,14 +1573,14 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
     // (lean matrix-core row pass: no residual sums - sum pt1 |x|^2 goes from k_colfinal's partials to k_xpx_columns)
     double* xpart = h->mompart + (int64_t)mom_blocks(h) * kMomComp;
-    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, use_mfma ? PAm : PA, h->Ncap, h->N, h->pt1, h->params, w,
+    k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, use_mfma ? h->mfma_col_planes : PA, h->Ncap, h->N, h->pt1, h->params, w,
                                                       h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal, h->D, h->colmin,
                                                       h->colmin + h->Ncap,
                                                       use_cull ? h->tmeta : nullptr, use_mfma ? (first_mfma ? 2 : 1) : 0, h->motion, slot,
                                                       queue_view(h->qcol, col_queue), row_lean ? xpart : nullptr);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
-        prg::launch_rowpass_mfma(h, mfma_seg, reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)PBm * 5 * h->Mcap), fine_cull, row_lean);
+        prg::launch_rowpass_mfma(h, mfma_seg, fine_cull, row_lean, !fine_cull);
     else if (row_queue)
         PRG_TRY(prg::launch_rowpass_queue(h, h->qrow_live ? 0 : h->q_first_row));
     else if (use_cull)
@@ -1587,9 +1591,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         prg::launch_rowpass_packed(h, RB, SB, segB);
     if (ev) PRG_HIP(hipEventRecord(ev[4], h->stream));
     const int nblk = (int)std::min<int64_t>(prg::ceil_div(h->M, kBlock), 1024);
-    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, row_mfma ? PBm : PB, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
+    const int row_planes = row_mfma ? h->mfma_row_planes : PB;
+    k_row_moments<<<nblk, kBlock, 0, h->stream>>>(h->rowpart, row_planes, h->Mcap, h->M, h->src4, h->z4, h->rowacc,
                                                   h->mompart,
-                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)(row_mfma ? PBm : PB) * 5 * h->Mcap)
+                                                  use_cull ? reinterpret_cast<const unsigned char*>(h->rowpart + (int64_t)row_planes * 5 * h->Mcap)
                                                            : nullptr,
                                                   row_mfma ? h->rorig : nullptr, queue_view(h->qrow, row_queue), row_lean ? 1 : 0);
     // (folding this single-block reduction into the last-finishing workgroup of k_row_moments was measured in round 3:

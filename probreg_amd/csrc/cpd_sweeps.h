@@ -41,11 +41,14 @@ __device__ __forceinline__ float col_seed_offset(float kk, float cm, float mo) {
 // the groups of 32 streamed points of each chunk (pays once sigma2 is small enough for some of them to be skipped)
 // guard (may be null): device copy of the E-step's engine decision - the launch was issued ahead of it and returns at
 // once unless `col` names its engine; the matrix-core kernel also takes `fine` from there
-void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard);  // S segments of the streamed cloud (0 = fill the chip once)
+// stream: cut the launch into equal runs of (block, chunk) units over exactly the workgroups the chip holds (dense regime; see
+// WorkItem in cpd_sweeps_mfma.hip) when mfma_stream_planes allows it; the launchers leave the plane count the merge kernels
+// must read in h->mfma_col_planes / h->mfma_row_planes
+void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard, bool stream);  // S segments of the streamed cloud (0 = fill the chip once)
+int mfma_stream_planes(int64_t owned_points, int64_t streamed_points);  // planes per block in stream mode, 0: not applicable
 // zchunk + bounding box of z4 -> motion[8..13]; eng != null: the last thread also takes the engine decision (EngineArgs)
 void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng);
-void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine, bool lean);  // lean: without the residual sums (plane 4)
-//  // rowflag: 64 bytes per 128-row block (touched planes)
+void launch_rowpass_mfma(prg_cpd* h, int S, bool fine, bool lean, bool stream);  // lean: without the residual sums (plane 4)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  // 256-point chunks one workgroup walks
 

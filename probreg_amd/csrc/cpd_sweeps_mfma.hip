@@ -178,6 +178,33 @@ __device__ __forceinline__ bf16x8 owned_operand(int k, float kk, float dx, float
     return (bf16x8){c.h, c.m, c.l, z, z, z, z, z};
 }
 
+// ---- how a launch is cut into workgroups -------------------------------------------------------------------------
+// grid mode (sk_g == 0): grid = (blocks of 512 owned points, segments of `chunks_per_seg` streamed chunks), one work item per
+// workgroup, plane = segment.  More workgroups than the chip holds at a time (768: 3 per CU) are handed out as slots free up -
+// what a culled sweep wants, whose items differ in length.  In the DENSE regime every (block, chunk) unit costs the same and
+// the grid's granularity is pure loss: rounds x chunks_per_seg is 105 units per slot for the 99.8 there are at C1 (95 %), 14 for
+// 12.5 on a 1/8 shard's row pass (89 %).  stream mode (sk_g > 0): exactly sk_g workgroups, all resident at once, each takes
+// the contiguous run [w U / G, (w + 1) U / G) of the U = blocks x chunks units in (block, chunk) order - at most one unit more
+// than its neighbour (99.7 % / 96 %) - as one work item per block the run touches.  An item of block b writes plane
+// w - (the workgroup that holds b's first unit); the item that ends a block fills the block's unused planes with neutral values.
+struct WorkItem { int blk; int c0; int nc; int plane; bool ends_block; };
+// runs of units: the first `rem` workgroups take base + 1 units, the others base (U = G base + rem; host arithmetic, 32 bit)
+struct StreamCut { int g; int pmax; unsigned base; unsigned rem; };
+__device__ __forceinline__ unsigned sk_start(unsigned w, const StreamCut sc) { return w * sc.base + (w < sc.rem ? w : sc.rem); }
+__device__ __forceinline__ WorkItem sk_item(unsigned u, unsigned u_end, unsigned w, unsigned nchunks, const StreamCut sc) {
+    WorkItem it;
+    const unsigned blk = u / nchunks, c0 = u - blk * nchunks;
+    const unsigned left = nchunks - c0, want = u_end - u;
+    it.blk = (int)blk;
+    it.c0 = (int)c0;
+    it.nc = (int)(want < left ? want : left);
+    it.ends_block = c0 + (unsigned)it.nc == nchunks;
+    const unsigned x = blk * nchunks, big = sc.rem * (sc.base + 1u);  // the block's first unit: which workgroup holds it?
+    const unsigned wf = x < big ? x / (sc.base + 1u) : sc.rem + (x - big) / sc.base;
+    it.plane = (int)(w - wf);
+    return it;
+}
+
 // ---- sweep 1 on the matrix cores: den_n of cpd.py:80 --------------------------------------------------------------
 // grid = (ceil(N / 512), S); plane blockIdx.y receives (min d^2 over the segment, sum of exp2(kk d^2 + L_n)) with
 // L_n = prg::col_seed_offset - the same for every segment of a column.
@@ -193,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          float2* __restrict__ colpart, int64_t ncap,
                                                          unsigned* __restrict__ wgcount, unsigned long long* __restrict__ work,
                                                          int first, int fine,
-                                                         const EngineDecision* __restrict__ guard) {
+                                                         const EngineDecision* __restrict__ guard, const StreamCut sk) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
     if (guard) {  // launched ahead of the engine decision (cpd.hip, estep_impl): run only if it came out this way
@@ -201,9 +228,24 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
         fine = guard->fine;
     }
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t n0wg = (int64_t)blockIdx.x * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const float mo = __uint_as_float(*motion);
+    const int nchunks = (int)((m_total + kChunk - 1) / kChunk), nblocks = (int)((n_total + kWgPoints - 1) / kWgPoints);
+    const int sk_g = sk.g, sk_pmax = sk.pmax;
+    unsigned unit = sk_g ? sk_start(blockIdx.x, sk) : 0u;
+    const unsigned unit_end = sk_g ? sk_start(blockIdx.x + 1u, sk) : 0u;
+    for (;;) {  // work items of this workgroup (grid mode: exactly one)
+    WorkItem item;
+    if (sk_g) {
+        item = sk_item(unit, unit_end, blockIdx.x, (unsigned)nchunks, sk);
+    } else {
+        item.blk = (int)blockIdx.x;
+        item.c0 = (int)blockIdx.y * chunks_per_seg;
+        item.nc = (item.c0 + chunks_per_seg < nchunks ? item.c0 + chunks_per_seg : nchunks) - item.c0;
+        item.plane = blockIdx.y;
+        item.ends_block = false;
+    }
+    const int64_t n0wg = (int64_t)item.blk * kWgPoints, n0 = n0wg + wv * (16 * kOwn);
     // the workgroup's patch: box (for the chunk test) and origin (its centre).  A workgroup that holds pads has no usable
     // box: it evaluates everything and takes its first point as origin.
     float lo[3], hi[3];
@@ -247,13 +289,12 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
         s[t] = 0.f;
         tm[t] = -INFINITY;
     }
-    const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
-    const int64_t nchunks = (m_total + kChunk - 1) / kChunk;
-    const int nc = (int)((c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks) - c0);  // <= 64
+    unsigned tiles_done = 0;
+    const int64_t c0 = item.c0;
+    const int nc = item.nc;  // <= 64: one ballot's worth of chunks (grid mode: chunks_per_seg; stream mode: the run length)
     // which chunks of the segment are needed: one box test per lane, one ballot (identical in all four waves)
     const BoxMeta cm = zchunk[c0 + (lane < nc ? lane : nc - 1)];
     unsigned long long mask = __ballot(lane < nc && !(box_gap2(lo, hi, cm) > thr));
-    unsigned tiles_done = 0;
     if (mask) {
         int cur = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -331,21 +372,33 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned tiles = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
-        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tiles;
+        wgcount[(int64_t)item.plane * nblocks + item.blk] = tiles;
         if (tiles) atomicAdd(work, (unsigned long long)tiles);  // what the next E-step's engine decision goes by
     }
-    float2* __restrict__ out = colpart + (int64_t)blockIdx.y * ncap + n0;
+    float2* __restrict__ out = colpart + (int64_t)item.plane * ncap + n0;
 #pragma unroll
-    for (int u = 0; u < kOwn; ++u) {
-        const float st = xor_sum(s[u]);
-        const float tt = xor_max(tm[u]);
+    for (int u2 = 0; u2 < kOwn; ++u2) {
+        const float st = xor_sum(s[u2]);
+        const float tt = xor_max(tm[u2]);
         if (lane < 16) {
             // t = kk d^2 + L  ->  d^2 = (t - L) / kk; kept slightly high: the next E-step's cull bound wants an upper bound
-            float dmin = fmaxf((tt - off[u]) / kk, 0.f);
+            float dmin = fmaxf((tt - off[u2]) / kk, 0.f);
             dmin = fmaf(dmin, 2.0e-4f, dmin) + 1.0e-12f;
-            out[16 * u + lane] = make_float2(tt == -INFINITY ? INFINITY : dmin, st);
+            out[16 * u2 + lane] = make_float2(tt == -INFINITY ? INFINITY : dmin, st);
         }
     }
+    if (!sk_g) break;
+    if (item.ends_block) {  // the planes this block did not need: neutral partials, no evaluated tiles
+        for (int q = item.plane + 1; q < sk_pmax; ++q) {
+            colpart[(int64_t)q * ncap + n0wg + threadIdx.x] = make_float2(INFINITY, 0.f);
+            colpart[(int64_t)q * ncap + n0wg + kBlock + threadIdx.x] = make_float2(INFINITY, 0.f);
+            if (threadIdx.x == 0) wgcount[(int64_t)q * nblocks + item.blk] = 0u;
+        }
+    }
+    unit += item.nc;
+    if (unit >= unit_end) break;
+    __syncthreads();  // (wave_tiles and the staging buffers are reused by the next item)
+    }  // work items
 }
 
 // ---- sweep 2 on the matrix cores: p1, px and the sigma2 residual of cpd.py:84-87 ----------------------------------
@@ -354,8 +407,13 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
 // four lanes of a row are added up at the end).  Output plane blockIdx.y, relative to the workgroup's origin o (stored
 // in rorig[row block of 512]): p1, u' = sum P (x - o), e' = sum P |x - o|^2 - k_row_moments' residual form with o as
 // the reference point.
-template <bool LEAN>
-__global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
+// STREAM: the launch is cut in stream mode (see WorkItem).  A template parameter, not a run-time one: with the item loop in
+// the code the register allocator needs 170 VGPRs where the single-item kernel takes 152 - one allocation granule above three
+// waves per SIMD - so the stream instantiation is held to three waves per SIMD explicitly (two values computed before the item
+// loop live in scratch, outside the chunk loop) and the grid-mode instantiations compile exactly as before.  Only the LEAN row
+// pass has a stream instantiation: the dense regime, where stream mode applies, is where the row pass runs lean.
+template <bool LEAN, bool STREAM>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, STREAM ? 3 : 10))) void k_rowpass_mfma(const float4* __restrict__ z4, const float4* __restrict__ tgt4,
                                                          const BoxMeta* __restrict__ zmeta,
                                                          const BoxMeta* __restrict__ tmeta,
                                                          const BoxMeta* __restrict__ tchunk, int chunks_per_seg,
@@ -364,12 +422,27 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
                                                          int64_t mcap, float4* __restrict__ rorig,
                                                          unsigned char* __restrict__ rowflag,
                                                          unsigned* __restrict__ wgcount, unsigned long long* __restrict__ work,
-                                                         int fine) {
+                                                         int fine, const StreamCut sk) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t m0wg = (int64_t)blockIdx.x * kWgPoints, m0 = m0wg + wv * (16 * kOwn);
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
+    const int nchunks = (int)((n_total + kChunk - 1) / kChunk), nblocks = (int)((m_total + kWgPoints - 1) / kWgPoints);
+    const int sk_pmax = sk.pmax;
+    unsigned unit = STREAM ? sk_start(blockIdx.x, sk) : 0u;
+    const unsigned unit_end = STREAM ? sk_start(blockIdx.x + 1u, sk) : 0u;
+    for (;;) {  // work items of this workgroup (grid mode: exactly one) - see WorkItem
+    WorkItem item;
+    if (STREAM) {
+        item = sk_item(unit, unit_end, blockIdx.x, (unsigned)nchunks, sk);
+    } else {
+        item.blk = (int)blockIdx.x;
+        item.c0 = (int)blockIdx.y * chunks_per_seg;
+        item.nc = (item.c0 + chunks_per_seg < nchunks ? item.c0 + chunks_per_seg : nchunks) - item.c0;
+        item.plane = blockIdx.y;
+        item.ends_block = false;
+    }
+    const int64_t m0wg = (int64_t)item.blk * kWgPoints, m0 = m0wg + wv * (16 * kOwn);
     float lo[3], hi[3];
     float4 o;
     WaveBox wb;
@@ -398,13 +471,12 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
         uxy[t] = uze[t] = (f32x2){0.f, 0.f};
         if (!LEAN) pp[t] = (f32x2){0.f, 0.f};
     }
-    const int64_t c0 = (int64_t)blockIdx.y * chunks_per_seg;
-    const int64_t nchunks = (n_total + kChunk - 1) / kChunk;
-    const int nc = (int)((c0 + chunks_per_seg < nchunks ? c0 + chunks_per_seg : nchunks) - c0);  // <= 64
-    // a chunk is skipped when every P of the (patch, chunk) block is an exact zero: kk dist^2(boxes) + max b_n < -127
+    unsigned tiles_done = 0;
+    const int64_t c0 = item.c0;
+    const int nc = item.nc;  // <= 64: one ballot's worth of chunks (grid mode: chunks_per_seg; stream mode: the run length)
+    // a chunk is skipped when every P of the (patch, chunk) block is below the cull bound: kk dist^2(boxes) + max b_n < -kCullExp
     const BoxMeta cm = tchunk[c0 + (lane < nc ? lane : nc - 1)];
     unsigned long long mask = __ballot(lane < nc && !(fmaf(box_gap2(lo, hi, cm), kk, cm.aux) < -prg::kCullExp));
-    unsigned tiles_done = 0;
     if (mask) {
         int cur = __builtin_ctzll(mask);
         mask &= mask - 1;
@@ -491,14 +563,14 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned tiles = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
-        wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = tiles;
+        wgcount[(int64_t)item.plane * nblocks + item.blk] = tiles;
         if (tiles) atomicAdd(work, (unsigned long long)tiles);  // what the next E-step's engine decision goes by
     }
     // k_row_moments skips (128-row block, plane) partials that were never touched: neither written nor read
     const bool touched = tiles_done != 0;  // (wave-uniform: this wave's 128 rows)
-    if (lane == 0) rowflag[((int64_t)blockIdx.x * 4 + wv) * 64 + blockIdx.y] = touched ? 1 : 0;
+    if (lane == 0) rowflag[((int64_t)item.blk * 4 + wv) * 64 + item.plane] = touched ? 1 : 0;
     if (touched) {
-        float* __restrict__ out = rowpart + (int64_t)blockIdx.y * 5 * mcap + m0;
+        float* __restrict__ out = rowpart + (int64_t)item.plane * 5 * mcap + m0;
 #pragma unroll
         for (int u = 0; u < kOwn; ++u) {
             const float a0 = xor_sum(LEAN ? uze[u][1] : pp[LEAN ? 0 : u][0] + pp[LEAN ? 0 : u][1]), a1s = xor_sum(uxy[u][0]),
@@ -515,7 +587,17 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_mfma(const float4* __restric
             }
         }
     }
-    if (blockIdx.y == 0 && threadIdx.x == 0) rorig[blockIdx.x] = o;
+    if (item.c0 == 0 && threadIdx.x == 0) rorig[item.blk] = o;
+    if (!STREAM) break;
+    if (item.ends_block) {  // the planes this block did not need: untouched, no evaluated tiles
+        for (int q = item.plane + 1 + lane; q < sk_pmax; q += 64) rowflag[((int64_t)item.blk * 4 + wv) * 64 + q] = 0;
+        if (threadIdx.x == 0)
+            for (int q = item.plane + 1; q < sk_pmax; ++q) wgcount[(int64_t)q * nblocks + item.blk] = 0u;
+    }
+    unit += item.nc;
+    if (unit >= unit_end) break;
+    __syncthreads();  // (wave_tiles and the staging buffers are reused by the next item)
+    }  // work items
 }
 
 // one box per chunk of 256 points = union of its 8 group boxes (+ the largest aux of the groups)
@@ -707,30 +789,83 @@ void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng) {
                                                   eng ? *eng : none);
 }
 
-void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard) {
+// Stream mode (see WorkItem): planes a block's items can occupy, 0 when the mode does not apply - fewer than four units per
+// workgroup (nothing to balance) or so few blocks that a block would spread over more planes than the merge kernels take.
+constexpr int kStreamSlots = 768;  // what the chip holds of these kernels at a time: 3 per CU (43 KB of LDS each)
+// workgroups of a stream-mode launch: whole rounds of the chip's slots (equal runs: r rounds take r run lengths), as many as
+// keep a run within the 64 chunks one ballot covers
+static int64_t stream_workgroups(int64_t blocks, int64_t chunks) {
+    const int64_t units = blocks * chunks;
+    return kStreamSlots * ceil_div(units, (int64_t)kStreamSlots * 64);
+}
+int mfma_stream_planes(int64_t owned_points, int64_t streamed_points) {
+    static const bool off = getenv("PRG_MFMA_STREAM") && atoi(getenv("PRG_MFMA_STREAM")) == 0;
+    const int64_t blocks = ceil_div(owned_points, kWgPoints), chunks = ceil_div(streamed_points, kChunk);
+    if (off || blocks * chunks < 4 * (int64_t)kStreamSlots || blocks * chunks >= (int64_t)1 << 31) return 0;
+    // most planes a block's items occupy = most workgroups whose runs touch one block (exact: walked once per shape)
+    static thread_local int64_t last_blocks = -1, last_chunks = -1;
+    static thread_local int last_planes = 0;
+    if (blocks != last_blocks || chunks != last_chunks) {
+        const int64_t units = blocks * chunks, g = stream_workgroups(blocks, chunks), base = units / g, rem = units % g;
+        auto holder = [&](int64_t x) { return x < rem * (base + 1) ? x / (base + 1) : rem + (x - rem * (base + 1)) / base; };
+        int64_t most = 0;
+        for (int64_t b = 0; b < blocks; ++b) most = std::max(most, holder((b + 1) * chunks - 1) - holder(b * chunks) + 1);
+        last_blocks = blocks;
+        last_chunks = chunks;
+        last_planes = (int)most;
+    }
+    return last_planes <= 48 ? last_planes : 0;
+}
+
+static StreamCut stream_cut(int planes, int64_t blocks, int64_t chunks) {
+    StreamCut c = {0, 0, 0u, 0u};
+    if (planes > 0) {
+        const int64_t units = blocks * chunks, g = stream_workgroups(blocks, chunks);
+        c.g = (int)g;
+        c.pmax = planes;
+        c.base = (unsigned)(units / g);
+        c.rem = (unsigned)(units % g);
+    }
+    return c;
+}
+
+void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard, bool stream) {
     const int cps = mfma_chunks_per_seg(h->N, h->M, S);
-    dim3 grid((unsigned)ceil_div(h->N, kWgPoints), (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
+    const int sp = stream ? mfma_stream_planes(h->N, h->M) : 0;
+    const int64_t nblocks = ceil_div(h->N, kWgPoints);
+    dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
+    h->mfma_col_planes = sp ? sp : (int)grid.y;
+    const StreamCut cut = stream_cut(sp, nblocks, ceil_div(h->M, kChunk));
+    if (sp) grid = dim3((unsigned)cut.g, 1);
     // (zchunk: boxes of this E-step's transformed source, written by launch_chunk_meta_bbox before the engine decision)
     k_colpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
                                                    h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
-                                                   h->colpart, h->Ncap, h->wgcount, h->eng_work, first ? 1 : 0, fine ? 1 : 0, guard);
-    h->wg_col = (int64_t)grid.x * grid.y;
+                                                   h->colpart, h->Ncap, h->wgcount, h->eng_work, first ? 1 : 0, fine ? 1 : 0, guard,
+                                                   cut);
+    h->wg_col = nblocks * h->mfma_col_planes;  // (evaluated-tile counters: one per (plane, block))
     h->wg_col_pairs = 128.0 * 16.0;  // counted unit: one wave's 128 points x one 16-point tile
     h->dense_pairs_col = 0.0;
 }
 
-void launch_rowpass_mfma(prg_cpd* h, int S, unsigned char* rowflag, bool fine, bool lean) {
+void launch_rowpass_mfma(prg_cpd* h, int S, bool fine, bool lean, bool stream) {
     const int cps = mfma_chunks_per_seg(h->M, h->N, S);
-    dim3 grid((unsigned)ceil_div(h->M, kWgPoints), (unsigned)ceil_div(ceil_div(h->N, kChunk), cps));
+    const int sp = stream && lean ? mfma_stream_planes(h->M, h->N) : 0;  // (stream mode: the lean instantiation only)
+    const int64_t nblocks = ceil_div(h->M, kWgPoints);
+    dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ceil_div(h->N, kChunk), cps));
+    h->mfma_row_planes = sp ? sp : (int)grid.y;
+    const StreamCut cut = stream_cut(sp, nblocks, ceil_div(h->N, kChunk));
+    if (sp) grid = dim3((unsigned)cut.g, 1);
+    // touched flags: 64 bytes per 128-row block, behind the planes this launch writes (k_row_moments is told the same count)
+    unsigned char* rowflag = reinterpret_cast<unsigned char*>(h->rowpart + (int64_t)h->mfma_row_planes * 5 * h->Mcap);
     launch_chunk_meta(h, h->tmeta, h->Ncap, h->tchunk);  // target boxes with this E-step's b_n ranges (after k_colfinal)
-    auto kernel = lean ? k_rowpass_mfma<true> : k_rowpass_mfma<false>;
+    auto kernel = sp ? k_rowpass_mfma<true, true> : lean ? k_rowpass_mfma<true, false> : k_rowpass_mfma<false, false>;
     kernel<<<grid, kBlock, 0, h->stream>>>(h->z4, h->tgt4, reinterpret_cast<const BoxMeta*>(h->zmeta),
                                            reinterpret_cast<const BoxMeta*>(h->tmeta), reinterpret_cast<const BoxMeta*>(h->tchunk), cps,
                                            h->N, h->M, h->params, h->rowpart, h->Mcap, h->rorig, rowflag, h->wgcount + h->wg_cap,
-                                           h->eng_work + 1, fine ? 1 : 0);
-    h->wg_row = (int64_t)grid.x * grid.y;
+                                           h->eng_work + 1, fine ? 1 : 0, cut);
+    h->wg_row = nblocks * h->mfma_row_planes;
     h->wg_row_pairs = 128.0 * 16.0;
     h->dense_pairs_row = 0.0;
 }

@@ -79,6 +79,8 @@ struct Lattice {
     int d = 0;
     int with_blur = 1;
     int size = 0;    // number of lattice vertices (host copy)
+    const float* pend_vals = nullptr;   // lat_filter(defer_slice): the final value plane, waiting to be sliced
+    float pend_alpha = 0.f;
     // device
     float* feat = nullptr;              // [n][d]
     unsigned long long* tkeys = nullptr;  // hash table [cap]
@@ -1388,7 +1390,17 @@ int lat_segments(Lattice* L, int64_t first) {
 
 // Filter `ch` channels: in [n][ch] (device) -> out [n_out][ch] (device); only points >= first are splatted
 // (callers pass first > 0 only when the skipped rows are known to be zero).
-int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out, unsigned seq_mask, float* out) {
+// defer_slice: stop before the slice step and leave (final value plane, alpha) in L->pend_vals / L->pend_alpha - FilterReg's
+// point-to-point M-step slices inside its own terms kernel (k_fr_terms<true>); whoever else needs `out` runs k_slice then.
+int lat_slice(Lattice* L, const float* vals, float alpha, int ch, int64_t n_out, unsigned seq_mask, float* out) {
+    k_slice<<<(unsigned)prg::ceil_div(n_out * ch, kBlock), kBlock, 0, L->stream>>>(L->pslot, L->bary, vals, n_out, L->d + 1, ch,
+                                                                                  alpha, seq_mask, out);
+    PRG_HIP(hipGetLastError());
+    return PRG_OK;
+}
+
+int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out, unsigned seq_mask, float* out,
+               bool defer_slice = false) {
     const int d1 = L->d + 1;
     hipStream_t st = L->stream;
     const int64_t plane = (int64_t)(L->size + 1) * ch;
@@ -1475,10 +1487,13 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
         }
     }
     const float alpha = 1.0f / (1.0f + powf(2.0f, (float)-L->d));
-    k_slice<<<(unsigned)prg::ceil_div(n_out * ch, kBlock), kBlock, 0, st>>>(L->pslot, L->bary, a, n_out, d1, ch,
-                                                                           alpha, seq_mask, out);
     PRG_HIP(hipGetLastError());
-    return PRG_OK;
+    if (defer_slice) {
+        L->pend_vals = a;
+        L->pend_alpha = alpha;
+        return PRG_OK;
+    }
+    return lat_slice(L, a, alpha, ch, n_out, seq_mask, out);
 }
 
 }  // namespace
@@ -1504,6 +1519,7 @@ struct prg_filterreg {
     double* state = nullptr; // [64]: 0..8 rot, 9..11 t, 12 sigma2, 13 q, 14 nonzero count, 15 sigma2_new
     double* part = nullptr;  // block partials
     int64_t part_blocks = 0;
+    bool slice_pending = false;  // the last E-step stopped before its slice step (lat_filter defer_slice); see fr_flush_slice
     std::vector<int> tgt_order;  // Morton order of the target (kernel position -> caller's index); see prg_fr_set_target
     int* ref_pos = nullptr;      // [N] device: caller's index -> kernel position (the ordered splat walks the caller's order)
     int* src_perm = nullptr;     // [M] device: kernel position -> caller's index of the (Morton-sorted) source; null: caller's order
@@ -1547,12 +1563,18 @@ __device__ __forceinline__ double fr_uniform_c(double wfac, int dim, double sigm
 __device__ void fr_finish_body(const double* __restrict__ part, int nblk, int dim, int update_sigma2, double min_sigma2,
                                double* __restrict__ state);
 
-// done != null: the workgroup that finishes last goes on with the weighted Kabsch / composition / sigma2 update itself
-// (fr_finish_body: what k_fr_finish does) - one launch and one dependent-launch gap less per EM iteration.
-__global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout, int ch,
+// SLICE: the lattice's slice step (permutohedral.cpp:521-528 / :586-592: barycentric interpolation of the D + 1 enclosing
+// vertices, the reference's two arithmetic flavours per channel) is done HERE, per source point, instead of in a k_slice launch
+// of its own: the five filtered values of a point go to `vout` (prg_fr_get_estep) and straight into the point's M-step terms -
+// one launch, one dependent-launch gap and one 22 MB re-read less per EM iteration.  The Kabsch finish is a launch of its own
+// again (k_fr_finish): folded into the last workgroup of this kernel (round 3) it doubled the kernel's registers (200 VGPRs:
+// 2 waves per SIMD for the 512 workgroups that never run it) and cost 57 us where the two launches take 16 + 12.
+template <bool SLICE>
+__global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ vout_in, float* __restrict__ vout_w, int ch,
+                                                     const int* __restrict__ offset, const float* __restrict__ bary,
+                                                     const float* __restrict__ vals, float alpha,
                                                      const double* __restrict__ ts, int64_t m, int dim, double wfac,
-                                                     double* __restrict__ state, double* __restrict__ part,
-                                                     unsigned* __restrict__ done, int update_sigma2, double min_sigma2) {
+                                                     const double* __restrict__ state, double* __restrict__ part) {
     __shared__ double sh[4][kFrComp];
     double a[kFrComp];
 #pragma unroll
@@ -1561,11 +1583,33 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
     const double c = fr_uniform_c(wfac, dim, sigma2);
     // grid-stride: a few hundred workgroups, each thread sums several points before the (32-component) reduction
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
-        const float m0 = vout[i * ch];
+        float f[5];
+        if (SLICE) {  // (ch == 5, seq_mask 0x11: channels 0 and 4 follow seqCompute, 1..3 sseCompute - see k_slice)
+            const int d1 = dim + 1;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) f[k] = 0.f;
+            for (int r = 0; r < d1; ++r) {
+                const int o = offset[i * d1 + r] + 1;
+                const float w = bary[i * d1 + r];
+                const float* __restrict__ v = vals + (int64_t)o * 5;
+                const float wa = __fmul_rn(w, alpha);
+                f[0] = __fadd_rn(f[0], __fmul_rn(__fmul_rn(w, v[0]), alpha));
+                f[1] = __fadd_rn(f[1], __fmul_rn(wa, v[1]));
+                f[2] = __fadd_rn(f[2], __fmul_rn(wa, v[2]));
+                f[3] = __fadd_rn(f[3], __fmul_rn(wa, v[3]));
+                f[4] = __fadd_rn(f[4], __fmul_rn(__fmul_rn(w, v[4]), alpha));
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) vout_w[i * 5 + k] = f[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) f[k] = vout_in[i * ch + k];
+        }
+        const float m0 = f[0];
         if (m0 != 0.f) {
             const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
-            const float m1[3] = {vout[i * ch + 1], vout[i * ch + 2], vout[i * ch + 3]};
-            const float m2 = vout[i * ch + 4];
+            const float m1[3] = {f[1], f[2], f[3]};
+            const float m2 = f[4];
             float tg[3];  // m1m0 = m1 / m0 in float32 (:172)
             for (int k = 0; k < 3; ++k) tg[k] = k < dim ? __fdiv_rn(m1[k], m0) : 0.f;
             const double m0m0 = (double)m0 / ((double)m0 + c);       // :173
@@ -1606,18 +1650,6 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
     if (threadIdx.x < kFrComp)
         part[(int64_t)blockIdx.x * kFrComp + threadIdx.x] =
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-    if (!done) return;
-    __shared__ bool is_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        is_last = atomicAdd(done, 1u) == gridDim.x - 1;
-        if (is_last) *done = 0u;
-    }
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    fr_finish_body(part, (int)gridDim.x, dim, update_sigma2, min_sigma2, state);
 }
 
 // point-to-plane M-step terms (filterreg.py:183-186 -> cc/point_to_plane.cc:6-32): per point with m0 != 0
@@ -2254,16 +2286,26 @@ int prg_fr_estep(prg_filterreg* h, double alpha, int* lattice_size, int* with_bl
     h->last_blur = blur;
     // one fused 5-channel pass: channels 0 (m0) and 4 (m2) are single-channel filters in the reference
     // (seqCompute arithmetic), channels 1..3 (m1) its 3-channel filter (sseCompute arithmetic)
-    PRG_TRY(lat_filter(&h->L, h->vin, h->ch, h->M, h->M, 0x11u, h->vout));  // normals (ch 5..7): 3-channel filter
+    // (point-to-point plans, ch == 5: the slice step waits for its consumer - the M-step slices inside its terms kernel)
+    h->slice_pending = h->ch == 5;
+    PRG_TRY(lat_filter(&h->L, h->vin, h->ch, h->M, h->M, 0x11u, h->vout, h->slice_pending));  // normals (ch 5..7): 3-channel filter
     if (lattice_size) *lattice_size = h->L.size;
     if (with_blur) *with_blur = blur;
     h->have_estep = true;
     return PRG_OK;
 }
 
+// the E-step's deferred slice, for every consumer of `vout` other than the point-to-point M-step
+static int fr_flush_slice(prg_filterreg* h) {
+    if (!h->slice_pending) return PRG_OK;
+    h->slice_pending = false;
+    return lat_slice(&h->L, h->L.pend_vals, h->L.pend_alpha, h->ch, h->M, 0x11u, h->vout);
+}
+
 // columns [col0, col0 + ncols) of the filtered values, one row per source point in the CALLER's order -> out_hd
 static int fr_fetch_columns(prg_filterreg* h, int col0, int ncols, float* out_hd) {
     hipStream_t st = h->L.stream;
+    PRG_TRY(fr_flush_slice(h));
     PRG_TRY(lat_ensure_io(&h->L, (size_t)h->M * ncols * sizeof(float)));
     k_fr_columns<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, st>>>(h->vout, h->ch, col0, ncols, h->src_perm, h->M, h->L.io);
     PRG_HIP(hipGetLastError());
@@ -2303,8 +2345,15 @@ int prg_fr_mstep(prg_filterreg* h, double w, int update_sigma2, double min_sigma
     hipStream_t st = h->L.stream;
     const double wfac = w / (1.0 - w) * (double)h->N / (double)h->M;
     const int nblk = (int)h->part_blocks;
-    k_fr_terms<<<nblk, kBlock, 0, st>>>(h->vout, h->ch, h->ts, h->M, h->D, wfac, h->state, h->part,
-                                        reinterpret_cast<unsigned*>(h->state + 60), update_sigma2, min_sigma2);
+    if (h->slice_pending) {  // slice + terms in one launch (the values still go to vout for prg_fr_get_estep)
+        h->slice_pending = false;
+        k_fr_terms<true><<<nblk, kBlock, 0, st>>>(nullptr, h->vout, 5, h->L.pslot, h->L.bary, h->L.pend_vals, h->L.pend_alpha, h->ts,
+                                                  h->M, h->D, wfac, h->state, h->part);
+    } else {
+        k_fr_terms<false><<<nblk, kBlock, 0, st>>>(h->vout, nullptr, h->ch, nullptr, nullptr, nullptr, 0.f, h->ts, h->M, h->D, wfac,
+                                                   h->state, h->part);
+    }
+    k_fr_finish<<<1, kBlock, 0, st>>>(h->part, nblk, h->D, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
     return out_host ? fr_read_state(h, out_host, 18) : PRG_OK;  // NULL: nothing is read back, the stream keeps running
 }
@@ -2346,6 +2395,7 @@ int prg_fr_mstep_pt2pl(prg_filterreg* h, double w, int update_sigma2, double min
     hipStream_t st = h->L.stream;
     const double wfac = w / (1.0 - w) * (double)h->N / (double)h->M;
     const int nblk = (int)h->part_blocks;
+    PRG_TRY(fr_flush_slice(h));
     k_fr_terms_pt2pl<<<nblk, kBlock, 0, st>>>(h->vout, h->ts, h->M, wfac, h->state, h->part);
     k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>(h->part, nblk, update_sigma2, min_sigma2, h->state);
     PRG_HIP(hipGetLastError());
@@ -2405,8 +2455,8 @@ int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_sourc
                                                   (const double*)b_state.p, (double*)b_part.p);
         k_fr_finish_pt2pl<<<1, kBlock, 0, st>>>((const double*)b_part.p, nblk, update_sigma2, -1.0, (double*)b_state.p);
     } else {
-        k_fr_terms<<<nblk, kBlock, 0, st>>>((const float*)b_v.p, ch, (const double*)b_ts.p, m, dim, wfac,
-                                            (double*)b_state.p, (double*)b_part.p, nullptr, 0, 0.0);
+        k_fr_terms<false><<<nblk, kBlock, 0, st>>>((const float*)b_v.p, nullptr, ch, nullptr, nullptr, nullptr, 0.f,
+                                                   (const double*)b_ts.p, m, dim, wfac, (const double*)b_state.p, (double*)b_part.p);
         k_fr_finish<<<1, kBlock, 0, st>>>((const double*)b_part.p, nblk, dim, update_sigma2, -1.0, (double*)b_state.p);
     }
     PRG_HIP(hipGetLastError());
