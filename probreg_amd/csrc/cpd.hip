@@ -1139,6 +1139,7 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     PRG_HIP(hipStreamSynchronize(h->stream));
     // (the sums of the previous target no longer describe this one: no lean row pass until prg_cpd_init_sums has run)
     if (h->tsum_local) PRG_HIP(hipMemsetAsync(h->tsum_local, 0, 4 * sizeof(double), h->stream));
+    h->have_tsum = false;
     const int64_t cap = cap_for(n_local);
     if (cap != h->Ncap) {
         if (h->tgt4) (void)hipFree(h->tgt4);
@@ -1282,6 +1283,7 @@ int prg_cpd_init_sums(prg_cpd* h) {
     PRG_HIP(hipGetLastError());
     PRG_TRY(ensure_engine_state(h));
     PRG_HIP(hipMemcpyAsync(h->tsum_local, h->moments + 24, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    h->have_tsum = true;
     if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));  // (after the LOCAL sums were kept)
     return PRG_OK;
 }
@@ -1330,7 +1332,15 @@ static double engine_leave_below(int64_t owned, int64_t streamed, double tau, do
     return std::max(0.0, cps * tau + delta) / (c_v - late) / (double)owned;  // pairs per owned point
 }
 static double engine_col_bound(int64_t m, int64_t n_local) { return engine_leave_below(n_local, m, 12.0e-6, -15.0e-6, 0.200e-12); }
-static double engine_row_bound(int64_t m, int64_t n_local) { return engine_leave_below(m, n_local, 19.2e-6, 8.0e-6, 0.233e-12); }
+// Row pass, round 4: what competes near the crossover is the LEAN matrix-core row pass (no residual sums: 14.5 us per chunk
+// instead of 19.2) against vector-pipe sweeps that skip at 2^-48 - re-measured from identical states on the surface at
+// 30k / 50k / 100k / 250k points and on rank 0 of 2 / 4 / 8 at 100k (profiles/r4_engine_switch_*.log): the two cross at
+// 18.6k / 13.4k / 18k / 37.5k and 12.4k / 6.3k / 5.3k evaluated targets per source point; tau 14.5 us, c_v 0.25 ps, delta -20 us
+// put the bound within x1.24 of every one of them (round 3's constants left 2-2.5x too early after those two changes).  A plan
+// whose row pass cannot run lean (prg_cpd_set_lean_factor(0), or no prg_cpd_init_sums) keeps round 3's constants.
+static double engine_row_bound(int64_t m, int64_t n_local, bool lean = true) {
+    return lean ? engine_leave_below(m, n_local, 14.5e-6, -20.0e-6, 0.250e-12) : engine_leave_below(m, n_local, 19.2e-6, 8.0e-6, 0.233e-12);
+}
 
 int prg_cpd_engine_bounds(int64_t m, int64_t n_local, double* col_bound, double* row_bound) {
     PRG_REQUIRE(m > 0 && n_local > 0 && col_bound && row_bound, PRG_ERR_INVALID, "prg_cpd_engine_bounds: need m, n_local > 0 and two outputs");
@@ -1483,7 +1493,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         static const double r_col_env = getenv("PRG_ENGINE_RCOL") ? atof(getenv("PRG_ENGINE_RCOL")) : 0.0;
         static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
         ea.r_col_bound = r_col_env > 0.0 ? r_col_env : h->dense_bound > 0.0 ? h->dense_bound : engine_col_bound(h->M, h->N);
-        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N);
+        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, h->lean_factor != 0.0 && h->have_tsum);
         ea.streamed_col = (double)h->M;
         ea.streamed_row = (double)h->N;
         // the first sweep over the work queue after the matrix cores has no previous build to size its units from: about

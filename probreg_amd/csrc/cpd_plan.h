@@ -118,6 +118,7 @@ struct prg_cpd {
                                 // 2: both sweeps on the matrix cores, always (tests)
     double dense_bound = 0.0;    // > 0: matrix-core column pass while it evaluates at least this many source points per target (0: estep_impl's model)
     double* tsum_local = nullptr;            // (sum x, sum y, sum z, sum |x|^2) of the local target, beside the decision
+    bool have_tsum = false;                  // ... filled in by prg_cpd_init_sums for the current target (the lean row pass needs it)
     unsigned long long* eng_work = nullptr;  // [2] tiles evaluated by the matrix-core column / row pass (read + cleared by the decision)
     int q_first_col = 32, q_first_row = 32;  // groups per unit of the first queue sweep after a matrix-core one
     bool eng_reset = true;       // the switch's memory is void (new registration, engine mode changed)
