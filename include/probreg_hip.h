@@ -109,6 +109,11 @@ int prg_cpd_last_estep_lean(prg_cpd* h, int* lean);
  * (default 64; 0 = never; a huge value = wherever the matrix-core row pass runs - tests and tools/lean_error.py measure the
  * sigma2 error of the lean pass far beyond where the default allows it); negative restores the default. */
 int prg_cpd_set_lean_factor(prg_cpd* h, double factor);
+/* How a DENSE-regime launch of the matrix-core sweeps (nothing to skip yet) is cut into workgroups: 1 (default) - equal runs
+ * of (512-point block, 256-point chunk) units over whole rounds of the workgroups the chip holds, at most one unit of
+ * difference between any two; 0 - the grid of (block, segment) workgroups every other regime uses.  Same pairs, same
+ * arithmetic; the partial sums are merged in a different order (tests, measurements). */
+int prg_cpd_set_stream_mode(prg_cpd* h, int on);
 
 /* Upload the (already centred) source cloud, replicated on every device.
  * Replaces: CoherentPointDrift.set_source, cpd.py:61-62. */

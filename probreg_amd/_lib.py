@@ -70,6 +70,7 @@ SIGNATURES = {
     "prg_cpd_engine_bounds": [_i64, _i64, _c.POINTER(_d), _c.POINTER(_d)],
     "prg_cpd_last_estep_lean": [_vp, _c.POINTER(_i)],
     "prg_cpd_set_lean_factor": [_vp, _d],
+    "prg_cpd_set_stream_mode": [_vp, _i],
     "prg_cpd_last_estep_engines": [_vp, _c.POINTER(_i), _c.POINTER(_i)],
     "prg_cpd_set_source": [_vp, _vp, _i64, _i],
     "prg_cpd_set_target": [_vp, _vp, _i64, _i, _i64],

@@ -1254,6 +1254,12 @@ int prg_cpd_last_estep_lean(prg_cpd* h, int* lean) {
     return PRG_OK;
 }
 
+int prg_cpd_set_stream_mode(prg_cpd* h, int on) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_stream_mode: NULL handle");
+    h->mfma_stream = on != 0;
+    return PRG_OK;
+}
+
 int prg_cpd_set_lean_factor(prg_cpd* h, double factor) {
     PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_lean_factor: NULL handle");
     h->lean_factor = factor;
@@ -1531,7 +1537,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
         const bool pred = h->pred_col != 0;
         if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
-            prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev, h->pred_fine == 0);
+            prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev, h->mfma_stream && h->pred_fine == 0);
         else if (!use_queue)
             prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev);
         // (pred == vector pipe with the work queue: nothing goes out ahead - inside the dense regime that engine only runs
@@ -1563,7 +1569,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         h->pred_col = use_mfma ? 1 : 0;
         h->pred_fine = fine_cull ? 1 : 0;
         if (!col_launched && use_mfma) {  // (the guarded launch has returned at once; rare: the engine changes once or twice per registration)
-            prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev, !fine_cull);
+            prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev, h->mfma_stream && !fine_cull);
             col_launched = true;
         }
     }
@@ -1590,7 +1596,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                       queue_view(h->qcol, col_queue), row_lean ? xpart : nullptr);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
-        prg::launch_rowpass_mfma(h, mfma_seg, fine_cull, row_lean, !fine_cull);
+        prg::launch_rowpass_mfma(h, mfma_seg, fine_cull, row_lean, h->mfma_stream && !fine_cull);
     else if (row_queue)
         PRG_TRY(prg::launch_rowpass_queue(h, h->qrow_live ? 0 : h->q_first_row));
     else if (use_cull)

@@ -104,6 +104,11 @@ class CpdPlan(object):
         check(lib.prg_cpd_last_estep_lean(self._h, ctypes.byref(v)))
         return int(v.value)
 
+    def set_stream_mode(self, on=True):
+        """Dense-regime matrix-core launches cut into equal runs of units over the chip's workgroup slots (default) or into the
+        grid of (block, segment) workgroups (prg_cpd_set_stream_mode)."""
+        check(lib.prg_cpd_set_stream_mode(self._h, 1 if on else 0))
+
     def set_lean_factor(self, factor=-1.0):
         """Lean matrix-core row pass while mean |x|^2 / (sigma2 D) <= factor (default 64; 0 never; < 0 restores the default)."""
         check(lib.prg_cpd_set_lean_factor(self._h, float(factor)))

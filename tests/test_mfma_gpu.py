@@ -163,3 +163,42 @@ def test_engine_switch_goes_by_pair_counts_on_a_non_surface_cloud():
     assert np.max(np.abs(res.transformation.t - params["t"])) < TOL_TF
     assert abs(res.transformation.scale - params["scale"]) < TOL_TF * params["scale"]
     assert abs(res.sigma2 - sigma2) <= TOL_SIGMA2 * sigma2
+
+
+@pytest.mark.parametrize("n,m,w", [(40000, 40000, 0.0), (30011, 45007, 0.1)])
+def test_stream_mode_equals_grid_mode_and_the_oracle(n, m, w):
+    """Dense regime: the matrix-core sweeps cut in stream mode (equal runs of (block, chunk) units, several work items per
+    workgroup, a block's partial sums spread over the planes of the workgroups that touched it) against the
+    grid of (block, segment) workgroups from the SAME state, and both against the fp64 oracle (cpd.py:71-88).  Both cuts
+    evaluate every pair."""
+    from oracle import cpd_c, cpd_numpy as co
+    from probreg_amd import synthetic
+
+    src, tgt, _ = synthetic.rigid_pair(n, m=m, seed=29)
+    reg, plan = _plan_with_state(src, tgt, 1, 1)
+    state = plan.get_params()
+    out = {}
+    for stream in (True, False):
+        plan.set_stream_mode(stream)
+        plan.set_dense_engine(1)       # (resets the switch's memory: the next E-steps start in the dense regime)
+        plan.set_params(state)
+        plan.estep(w)                  # first E-step after the reset takes the matrix cores and counts
+        plan.set_params(state)
+        plan.estep(w)
+        assert plan.last_estep_engines() == (1, 1) and plan.last_estep_lean() == 1
+        assert plan.pair_counts() == (float(n) * m, float(n) * m)
+        out[stream] = (plan.get_moments(), plan.get_estep())
+    res = reg._result_from_params(state)
+    ts = co.transform("rigid", dict(rot=res.transformation.rot, t=res.transformation.t, scale=res.transformation.scale), src)
+    pt1, p1, px, n_p = cpd_c.expectation_step(ts, tgt, res.sigma2, w)
+    for stream in (True, False):
+        mom, (g_pt1, g_p1, g_px) = out[stream]
+        g_px = g_px + np.outer(g_p1, reg._cx)
+        assert abs(mom[0] - n_p) < 2e-6 * n_p, stream
+        assert np.max(np.abs(g_pt1 - pt1)) < 2e-5, stream
+        assert np.max(np.abs(g_p1 - p1)) < 2e-5 * max(1.0, p1.max()), stream
+        assert np.max(np.abs(g_px - px)) < 2e-5 * max(1.0, np.abs(px).max()), stream
+    a, b = out[True][0][:23], out[False][0][:23]
+    assert np.max(np.abs(a - b)) < 1e-6 * n_p
+    # the column side does not depend on how the launch is cut beyond the order fp32 partials are added in
+    assert np.max(np.abs(out[True][1][0] - out[False][1][0])) < 1e-6
