@@ -60,8 +60,8 @@ def test_forced_lean_pass_along_a_100k_rigid_registration(w):
 
 
 def test_default_lean_window_and_switch_off():
-    """Default factor (64): every matrix-core row pass of C1 runs lean, and the flag is off once the row pass has gone to the
-    vector pipe; a smaller factor (16, round 3's default) can only turn it off earlier; factor 0 never runs it; all give the
+    """Default factor (64): the matrix-core row passes of C1 run lean up to that amplification, and the flag is off once the row
+    pass has gone to the vector pipe; a smaller factor (16, round 3's default) can only turn it off earlier; factor 0 never runs it; all give the
     oracle's sigma2 (checked on the last iteration whose row pass runs on the matrix cores under every setting)."""
     from probreg_amd import cpd, synthetic
 
@@ -87,7 +87,8 @@ def test_default_lean_window_and_switch_off():
     flags, rows = seen[-1.0]
     assert flags[:7] == [1] * 7 and flags[-1] == 0 and rows[-1] == 0, (flags, rows)
     assert flags == sorted(flags, reverse=True)                      # ... never back on
-    assert all(f == r for f, r in zip(flags, rows)), (flags, rows)   # lean exactly where the matrix-core row pass ran
+    # lean only where the matrix-core row pass ran (the row pass may stay on the matrix cores past amplification 64: not lean there)
+    assert all(f <= r for f, r in zip(flags, rows)), (flags, rows)
     f16, r16 = seen[16.0]
     assert f16[:6] == [1] * 6 and all(a <= b for a, b in zip(f16, flags)) and all(f <= r for f, r in zip(f16, r16)), (f16, r16)
     assert seen[0.0][0] == [0] * 15 and seen[0.0][1][:7] == [1] * 7
