@@ -1139,7 +1139,6 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     PRG_HIP(hipStreamSynchronize(h->stream));
     // (the sums of the previous target no longer describe this one: no lean row pass until prg_cpd_init_sums has run)
     if (h->tsum_local) PRG_HIP(hipMemsetAsync(h->tsum_local, 0, 4 * sizeof(double), h->stream));
-    h->have_tsum = false;
     const int64_t cap = cap_for(n_local);
     if (cap != h->Ncap) {
         if (h->tgt4) (void)hipFree(h->tgt4);
@@ -1289,7 +1288,6 @@ int prg_cpd_init_sums(prg_cpd* h) {
     PRG_HIP(hipGetLastError());
     PRG_TRY(ensure_engine_state(h));
     PRG_HIP(hipMemcpyAsync(h->tsum_local, h->moments + 24, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    h->have_tsum = true;
     if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));  // (after the LOCAL sums were kept)
     return PRG_OK;
 }
@@ -1342,8 +1340,9 @@ static double engine_col_bound(int64_t m, int64_t n_local) { return engine_leave
 // instead of 19.2) against vector-pipe sweeps that skip at 2^-48 - re-measured from identical states on the surface at
 // 30k / 50k / 100k / 250k points and on rank 0 of 2 / 4 / 8 at 100k (profiles/r4_engine_switch_*.log): the two cross at
 // 18.6k / 13.4k / 18k / 37.5k and 12.4k / 6.3k / 5.3k evaluated targets per source point; tau 14.5 us, c_v 0.25 ps, delta -20 us
-// put the bound within x1.24 of every one of them (round 3's constants left 2-2.5x too early after those two changes).  A plan
-// whose row pass cannot run lean (prg_cpd_set_lean_factor(0), or no prg_cpd_init_sums) keeps round 3's constants.
+// put the bound within x1.24 of every one of them (round 3's constants left 2-2.5x too early after those two changes).  Where the
+// row pass cannot run lean (amplification above the lean factor, prg_cpd_set_lean_factor(0), no prg_cpd_init_sums) round 3's
+// constants apply: the decision kernel, which knows, picks between the two bounds (EngineArgs::r_row_bound / r_row_bound_full).
 static double engine_row_bound(int64_t m, int64_t n_local, bool lean = true) {
     return lean ? engine_leave_below(m, n_local, 14.5e-6, -20.0e-6, 0.250e-12) : engine_leave_below(m, n_local, 19.2e-6, 8.0e-6, 0.233e-12);
 }
@@ -1499,7 +1498,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         static const double r_col_env = getenv("PRG_ENGINE_RCOL") ? atof(getenv("PRG_ENGINE_RCOL")) : 0.0;
         static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
         ea.r_col_bound = r_col_env > 0.0 ? r_col_env : h->dense_bound > 0.0 ? h->dense_bound : engine_col_bound(h->M, h->N);
-        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, h->lean_factor != 0.0 && h->have_tsum);
+        ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, true);
+        ea.r_row_bound_full = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, false);  // (the device knows which applies)
         ea.streamed_col = (double)h->M;
         ea.streamed_row = (double)h->N;
         // the first sweep over the work queue after the matrix cores has no previous build to size its units from: about

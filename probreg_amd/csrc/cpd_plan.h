@@ -26,7 +26,8 @@ struct EngineDecision {
 struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double ext2;
     // matrix-core sweeps while they evaluate at least this many pairs per owned point (see estep_impl)
-    double r_col_bound, r_row_bound;
+    double r_col_bound, r_row_bound;  // (r_row_bound: for the lean row pass)
+    double r_row_bound_full;          // ... for the row pass with its residual sums (amplification above the lean factor)
     double owned_col, owned_row;  // N_local, M
     double streamed_col, streamed_row;  // M, N_local: what the count is when nothing is culled (the switch's initial memory)
     const double* tsum;           // (sum x, sum y, sum z, sum |x|^2) of the local target
@@ -118,7 +119,6 @@ struct prg_cpd {
                                 // 2: both sweeps on the matrix cores, always (tests)
     double dense_bound = 0.0;    // > 0: matrix-core column pass while it evaluates at least this many source points per target (0: estep_impl's model)
     double* tsum_local = nullptr;            // (sum x, sum y, sum z, sum |x|^2) of the local target, beside the decision
-    bool have_tsum = false;                  // ... filled in by prg_cpd_init_sums for the current target (the lean row pass needs it)
     unsigned long long* eng_work = nullptr;  // [2] tiles evaluated by the matrix-core column / row pass (read + cleared by the decision)
     int q_first_col = 32, q_first_row = 32;  // groups per unit of the first queue sweep after a matrix-core one
     bool eng_reset = true;       // the switch's memory is void (new registration, engine mode changed)

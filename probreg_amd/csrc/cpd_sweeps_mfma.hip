@@ -702,7 +702,9 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     if (tc && !eng.reset) r_col = (float)((double)tc * 2048.0 / eng.owned_col);
     if (tr && !eng.reset) r_row = (float)((double)tr * 2048.0 / eng.owned_row);
     const bool dense = ok && (eng.forced || r_col >= eng.r_col_bound);
-    if (!(r_row >= eng.r_row_bound)) row_off = 1;
+    // (the row pass' bound depends on which row pass it would be: lean - cheaper per chunk, competitive for longer - or full)
+    const bool lean_ok = eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.lean_factor * eng.owned_col >= eng.tsum[3];
+    if (!(r_row >= (lean_ok ? eng.r_row_bound : eng.r_row_bound_full))) row_off = 1;
     // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
     // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold
     // (farthest corners of the two bounding boxes: every term of every column is >= 2^-110)
@@ -719,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     // The matrix-core row pass may drop its residual sums (k_rowpass_mfma<LEAN>) while the M-step's
     // sigma2 = (sum pt1 |x|^2 - ...) / (Np D) does not cancel much: the column-side sum differs from what the row sums imply
     // by ~1e-6 relative (fp32 tails), amplified by mean |x|^2 / (sigma2 D) - at most eng.lean_factor here.
-    const bool lean = row && eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.lean_factor * eng.owned_col >= eng.tsum[3];
+    const bool lean = row && lean_ok;
     EngineDecision d;
     d.seq = eng.seq;
     d.col = col ? 1 : 0;

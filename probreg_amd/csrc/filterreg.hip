@@ -1041,11 +1041,6 @@ static int next_generation(unsigned long long* table, int64_t cap, unsigned* gen
     return PRG_OK;
 }
 
-// Above this many vertices (in the previous lattice of the same kind) the table is filled in ONE launch: the two-stage fill
-// exists because, while the lattice is small, thousands of waves compare-and-swap the same few hundred empty slots at once;
-// with tens of thousands of vertices a wave's points spread over many slots and the stage-1 launch is pure overhead.
-static const int kSingleLaunchAbove = getenv("PRG_EMBED_SINGLE_ABOVE") ? atoi(getenv("PRG_EMBED_SINGLE_ABOVE")) : 0x7fffffff;
-
 int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above = -1) {
     PRG_REQUIRE(d >= 1 && d <= kMaxDG, PRG_ERR_INVALID, "permutohedral lattice: feature dimension %d not in [1, %d]", d,
                 kMaxDG);
@@ -1129,11 +1124,13 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                             (long long)done, (long long)n, host[0], (long long)decide_above, with_blur);
                 return PRG_OK;  // prev_size[mode] keeps the last full count
             }
-        } else if (n >= 4096 && (L->prev_size[mode] <= 0 || L->prev_size[mode] < kSingleLaunchAbove || L->side_fuse)) {
+        } else if (n >= 4096) {
             // no decision to take, but the table is still filled in two launches: the first sixteenth of the points
             // creates most vertices almost uncontended, the rest then find them with plain reads - one launch over
             // all points has every wave compare-and-swap the same few hundred empty slots at once (3x slower while
-            // the lattice is small)
+            // the lattice is small; [r4] once it has tens of thousands of vertices a single launch is neither faster nor
+            // slower - measured at C4 with the switch at 8k / 32k / 128k vertices: 4855 / 4864 / 4871 / 4885 it/s - so the
+            // two stages stay unconditional)
             done = n / 16;
             if (L->side_fuse) {  // the prepared side stage (lat_side_stage) covers exactly these points: one launch for both
                 float bsc[3];
