@@ -46,6 +46,9 @@ F64_MFMA_PEAK_TFLOPS = 78.6    # v_mfma_f64_16x16x4_f64
 # The same count is charged to the dense-regime iterations that take the exponent (8 of the 21 / 14 flop) from the bf16
 # matrix pipe instead (csrc/cpd_sweeps_mfma.hip): `frac` is useful pair-flops per second over the fp32 vector peak.
 FLOP_ROW, FLOP_COL = 21.0, 14.0
+# the fused single sweep of a rigid iteration in the dense regime (prg_cpd_set_moments_only): the column pass'
+# exponent, minimum and sum (14) + the contraction of 4 more channels on the source side (4 fma = 8): ONE sweep per E-step
+FLOP_FUSED = 22.0
 # the matrix-core row pass without its residual sums (prg_cpd_last_estep_lean): one fma per pair less
 FLOP_ROW_LEAN = 19.0
 # SURVEY.md 8(d)'s own count for the two-sweep fused form (scale as a separate multiplication, no min tracking): 20 / 11
@@ -255,6 +258,10 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     plan = reg._plan
     if tuning:
         plan.set_tuning(*[int(v) for v in tuning.split(",")])
+    if kind == "rigid" and os.environ.get("PROBREG_BENCH_TWO_SWEEPS") != "1":
+        # what the registration's own loop does (prg_cpd_iterate): a rigid E-step feeds nothing but the rigid M-step, so the
+        # dense regime may run as ONE sweep over the pairs; the step below stays E-step [+ all-reduce] + M-step
+        plan.set_moments_only(1)
 
     def step():
         plan.estep(0.0)
@@ -305,7 +312,11 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         ms = plan.estep_timed(0.0)
         pc, pr = plan.pair_counts()
         ce, re_ = plan.last_estep_engines()
+        fused = bool(plan.last_estep_fused())
         fr = FLOP_ROW_LEAN if plan.last_estep_lean() else FLOP_ROW
+        if fused:  # one sweep did the whole E-step: it is reported in the row-pass slot (the dominant kernel), the column slot is empty
+            ms = dict(ms, rowpass=ms["colpass"], colpass=0.0)
+            pr, pc, fr, re_ = pc, 0.0, FLOP_FUSED, 2
         flop_row += pr * fr
         per_iteration.append((it, s2_it, ce, re_, pc, pr, ms["colpass"], ms["rowpass"], ms["total"], fr))
         reg._all_reduce_moments(plan)
@@ -323,6 +334,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         with open(pairs_log, "w") as f:
             f.write("# %s: E-step sweeps of the timed window, HIP events on the plan's stream (prg_cpd_estep_timed) and the device's "
                     "counters of evaluated pairs (prg_cpd_pair_counts)\n" % desc)
+            f.write("# row = 2: the FUSED single sweep of a rigid iteration (one sweep per E-step, %g flop per pair, reported in the row columns; the column slot is empty)\n" % FLOP_FUSED)
             f.write("# engine 1 = matrix cores (bf16x3 exponent, csrc/cpd_sweeps_mfma.hip), 0 = culled vector-pipe sweeps; "
                     "frac = pairs x flop/pair / ms / %.1f TFLOP/s (flop/pair: row %g - %g where the matrix-core row pass ran "
                     "without its residual sums, column `fr` - column %g)\n"
@@ -331,7 +343,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
                                                                            "ms_col", "ms_row", "ms_estep", "frac_col", "frac_row"))
             for (it, s2_it, ce, re_, pc, pr, mc, mr, mt, fr) in per_iteration:
                 f.write("%3d %12.5e %4d %4d %3.0f %14.0f %14.0f %9.4f %9.4f %9.4f %8.3f %8.3f\n" % (
-                    it, s2_it, ce, re_, fr, pc, pr, mc, mr, mt, pc * FLOP_COL / (mc * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS,
+                    it, s2_it, ce, re_, fr, pc, pr, mc, mr, mt, (pc * FLOP_COL / (mc * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS) if mc > 0 else 0.0,
                     pr * fr / (mr * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS))
             tot_r = sum(r[5] for r in per_iteration)
             tot_fl = sum(r[5] * r[9] for r in per_iteration)
@@ -342,9 +354,9 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     m_pts, n_loc = plan.m, plan.n
     row_s_total, col_s_total = acc["rowpass"] * 1e-3 * steps, acc["colpass"] * 1e-3 * steps
     row_tf = flop_row / row_s_total / 1e12
-    col_tf = pairs_col * FLOP_COL / col_s_total / 1e12
+    col_tf = pairs_col * FLOP_COL / col_s_total / 1e12 if col_s_total > 0 else 0.0
     dense_row_tf = first_pairs[1] * first_fr / (first["rowpass"] * 1e-3) / 1e12
-    dense_col_tf = first_pairs[0] * FLOP_COL / (first["colpass"] * 1e-3) / 1e12
+    dense_col_tf = first_pairs[0] * FLOP_COL / (first["colpass"] * 1e-3) / 1e12 if first["colpass"] > 0 else 0.0
     # SURVEY.md 8(d) figure kept beside it: algorithmic bytes of the reference's formulation at fp32 (P written once
     # by the column pass, read once by the row pass) over the measured time - an EFFECTIVE rate, not a roofline
     alg_row = 4.0 * m_pts * n_loc + 4.0 * (m_pts + n_loc) * 5
@@ -367,8 +379,9 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     out["late_it_s"] = 1.0 / t_late
     out["roofline"] = {
         "bound": "valu",
-        "kernel": "row pass (E-step sweep 2: P1, PX, sigma2 residual): k_rowpass_mfma while sigma2 is large, "
-                  "k_rowpass_cull afterwards",
+        "kernel": "the E-step's dominant pair sweep: the fused single sweep k_colpass_mfma<FUSED> (den, P1, PX sums from the column "
+                  "side, one exponential per pair and iteration) while sigma2 is large, the row pass (k_rowpass_mfma / "
+                  "k_rowpass_queue) afterwards",
         "achieved": row_tf,
         "peak": VALU_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -377,9 +390,10 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         "traffic_source": "profiles/pmc_traffic.json - STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                           "tools/profile_round.sh, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; not measured in this run",
         "how": "flop = pairs the kernel evaluated (per-workgroup device counters, prg_cpd_pair_counts) x %g flop/pair (%g in the "
-               "iterations whose matrix-core row pass ran without its residual sums, prg_cpd_last_estep_lean); "
-               "time = HIP events on the plan's stream; both summed over the %d timed-window iterations" % (FLOP_ROW, FLOP_ROW_LEAN, steps),
-        "flop_per_pair": {"isa_count": {"row": FLOP_ROW, "row_lean": FLOP_ROW_LEAN, "col": FLOP_COL,
+               "iterations whose matrix-core row pass ran without its residual sums, prg_cpd_last_estep_lean; %g in the iterations "
+               "that ran as the fused single sweep, prg_cpd_last_estep_fused - there the sweep is the whole E-step); "
+               "time = HIP events on the plan's stream; both summed over the %d timed-window iterations" % (FLOP_ROW, FLOP_ROW_LEAN, FLOP_FUSED, steps),
+        "flop_per_pair": {"isa_count": {"row": FLOP_ROW, "row_lean": FLOP_ROW_LEAN, "col": FLOP_COL, "fused": FLOP_FUSED,
                                         "row_window_average": flop_row / max(pairs_row, 1.0)},
                           "survey_8d": {"row": FLOP_ROW_SURVEY, "col": FLOP_COL_SURVEY},
                           "note": "the matrix-core engine takes 8 of these flop per pair (the exponent) from the bf16 matrix "
@@ -388,7 +402,8 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         "matrix_core_share": {"column_pass_iterations": sum(1 for r in per_iteration if r[2]) / float(steps),
                               "row_pass_iterations": sum(1 for r in per_iteration if r[3]) / float(steps),
                               "row_pass_pairs": sum(r[5] for r in per_iteration if r[3]) / max(pairs_row, 1.0),
-                              "row_pass_lean_iterations": sum(1 for r in per_iteration if r[9] == FLOP_ROW_LEAN) / float(steps)},
+                              "row_pass_lean_iterations": sum(1 for r in per_iteration if r[9] == FLOP_ROW_LEAN) / float(steps),
+                              "fused_single_sweep_iterations": sum(1 for r in per_iteration if r[3] == 2) / float(steps)},
         "avg_launch_ms": acc["rowpass"],
         "pairs_evaluated_per_launch": pairs_row / steps,
         "pairs_total_per_launch": float(m_pts) * n_loc,

@@ -158,6 +158,15 @@ int prg_cpd_set_comm(prg_cpd* h, prg_comm* comm);
  * + M-step, the loop body of CoherentPointDrift.registration (cpd.py:110-113) without its host-side convergence test
  * (tol < 0, no callbacks).  Nothing is read back; prg_cpd_get_params afterwards synchronises. */
 int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter);
+/* What a RIGID EM iteration needs of its E-step (cpd.py:160-192) are 23 sums, not the per-point arrays p1 / px.  mode 1: every
+ * prg_cpd_estep of this plan may therefore run, while sigma2 is large (dense regime, sigma2's amplification within the lean
+ * factor), as ONE sweep over the pairs - the column pass with the row pass' contraction on the source side, the moments taken
+ * from per-column sums - instead of two: MOMENTS, pt1 and the parameter block come out as always,
+ * prg_cpd_get_estep has no p1 / px to return after such an E-step (it says so), and the caller must follow it with
+ * prg_cpd_mstep(PRG_TF_RIGID).  mode 0 (default): only prg_cpd_iterate(PRG_TF_RIGID) does this, for its own E-steps.
+ * mode 2: nobody does (two sweeps always: tests, measurements).  prg_cpd_last_estep_fused reports what the last E-step did. */
+int prg_cpd_set_moments_only(prg_cpd* h, int mode);
+int prg_cpd_last_estep_fused(prg_cpd* h, int* fused);
 
 /* sigma2 initialiser, step 1: local target sums -> MOMENTS[24..27] (others zeroed).
  * Replaces: mu.squared_kernel_sum, math_utils.py:28-29 -> cc/math_utils.cc:5-15

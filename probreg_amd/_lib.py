@@ -86,6 +86,8 @@ SIGNATURES = {
     "prg_comm_all_reduce_f64": [_vp, _vp, _i64, _vp],
     "prg_cpd_set_comm": [_vp, _vp],
     "prg_cpd_iterate": [_vp, _i, _i, _d, _i],
+    "prg_cpd_set_moments_only": [_vp, _i],
+    "prg_cpd_last_estep_fused": [_vp, _c.POINTER(_i)],
     "prg_cpd_init_sums": [_vp],
     "prg_cpd_init_params": [_vp, _vp],
     "prg_cpd_estep": [_vp, _d],

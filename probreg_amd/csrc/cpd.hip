@@ -448,6 +448,159 @@ __device__ __forceinline__ void block_reduce_store(double (&a)[kMomComp], double
             sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused single sweep of a rigid EM iteration (cpd_sweeps_mfma.hip, k_colpass_mfma<FUSED>): per column n the planes hold
+// (min d^2, A, Bx, By, Bz, E) with A = sum_m K, B = sum_m K (z_m - o), E = sum_m K |z_m - o|^2, K = exp2(kk d^2 + L_n), o the
+// origin of the column's 512-block.  This kernel is k_colfinal (den_n, pt1_n, b_n, the seeds of the next column pass) AND the
+// moment kernel: with q_n = pt1_n / A_n the column contributes
+//   [0] pt1   [1..3] pt1 x   [4..6] pz = q B + pt1 o   [7..15] x pz^T   [16] q (E + 2 o.B) + pt1 |o|^2   [22] pt1 |x|^2
+// (block partials in mompart; k_fused_final sums them and maps the z-side sums back to the source's own frame).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_colfinal_fused(float4* __restrict__ tgt4, const float* __restrict__ fpart, int nseg,
+                                                           int64_t ncap, int64_t n, float* __restrict__ pt1,
+                                                           const double* __restrict__ params, double w, double m_over_n, int dim,
+                                                           float* __restrict__ colmin, float* __restrict__ colmin_g,
+                                                           float* __restrict__ gmeta, int seed_mode, unsigned* __restrict__ stat,
+                                                           int slot, const float4* __restrict__ corig,
+                                                           double* __restrict__ mompart) {
+    const int64_t i_own = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool valid = i_own < n;
+    const int64_t i = valid ? i_own : n - 1;
+    const double sigma2 = params[13];
+    const float kkf = (float)(-kLog2e / (2.0 * sigma2));
+    // every plane's sums are relative to the SAME exponent offset, known before the sweep (as in k_colfinal's seed mode)
+    const float goff = seed_mode == 2 ? 0.f : prg::col_seed_offset(kkf, colmin[i], __uint_as_float(stat[slot]));
+    float gmin = INFINITY;
+    double A = 0.0, B[3] = {0.0, 0.0, 0.0}, E = 0.0;
+    for (int s0 = 0; s0 < nseg; ++s0) {
+        const float* __restrict__ q = fpart + (int64_t)s0 * 6 * ncap + i;
+        gmin = fminf(gmin, q[0]);
+        A += (double)q[ncap];
+        B[0] += (double)q[2 * ncap];
+        B[1] += (double)q[3 * ncap];
+        B[2] += (double)q[4 * ncap];
+        E += (double)q[5 * ncap];
+    }
+    const double den = A * exp2(-(double)goff);  // underflows to 0 exactly where fp64 exp() does
+    double c = 0.0;
+    if (w > 0.0) c = pow(2.0 * M_PI * sigma2, dim * 0.5) * (w / (1.0 - w) * m_over_n);
+    float b, p;
+    double pd = 0.0, qn = 0.0;
+    if (den == 0.0) {  // cpd.py:81: den = eps32, the column of P is all zero
+        b = -INFINITY;
+        p = 0.f;
+    } else {
+        const double tot = den + c;
+        b = (float)(-log2(tot));
+        pd = den / tot;
+        p = (float)pd;
+        qn = pd / A;
+    }
+    float cmin = 0.f;
+    double a[kMomComp];
+#pragma unroll
+    for (int k = 0; k < kMomComp; ++k) a[k] = 0.0;
+    if (valid) {
+        reinterpret_cast<float*>(tgt4 + i)[3] = b;
+        pt1[i] = p;
+        colmin[i] = gmin;
+        cmin = gmin;
+        const float4 xf = tgt4[i], of = corig[i / prg::kMfmaWgPoints];
+        const double x[3] = {xf.x, xf.y, xf.z}, o[3] = {of.x, of.y, of.z};
+        double pz[3], ob = 0.0, oo = 0.0, xx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pz[k] = qn * B[k] + pd * o[k];
+            ob += o[k] * B[k];
+            oo += o[k] * o[k];
+            xx += x[k] * x[k];
+        }
+        a[0] = pd;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            a[1 + r] = pd * x[r];
+            a[4 + r] = pz[r];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[7 + 3 * r + k] = x[r] * pz[k];
+        }
+        a[16] = qn * (E + 2.0 * ob) + pd * oo;
+        a[22] = pd * xx;
+    } else {
+        b = 0.f;
+    }
+    block_reduce_store(a, mompart);
+    {  // per group of 32 columns the largest of the minima, and the shard's largest (exactly as k_colfinal)
+        const float gm = half_max(cmin);
+        if ((threadIdx.x & 31) == 0) colmin_g[(int64_t)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5)] = gm;
+        __shared__ float wg_max[kBlock / 32];
+        if ((threadIdx.x & 31) == 0) wg_max[threadIdx.x >> 5] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = wg_max[0];
+#pragma unroll
+            for (int k = 1; k < kBlock / 32; ++k) mx = fmaxf(mx, wg_max[k]);
+            if (mx > 0.f) atomicMax(stat + 4 + slot, __float_as_uint(mx));
+        }
+    }
+    if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta);
+}
+
+// block partials of k_colfinal_fused -> MOMENTS in the layout k_mstep reads.  The sweep saw the TRANSFORMED source
+// z = s R y + t; the rigid M-step wants sums over y: y = R^T (z - t) / s, so
+//   Sy = R^T (Sz - S0 t) / s,   Sxy = (Sxz - Sx t^T) R / s,   tr Syy = (tr Szz - 2 t.Sz + S0 |t|^2) / s^2
+// (R orthonormal: a rotation - checked on the host for the initial one, true by construction afterwards; the M-step only
+// takes the trace of Syy for a rigid fit, cpd.py:179-182, so it goes to [16] and the other five entries stay 0).
+__global__ __launch_bounds__(kRedBlock) void k_fused_final(const double* __restrict__ part, int nblk,
+                                                           const double* __restrict__ params, double* __restrict__ moments) {
+    __shared__ double sh[32][33];
+    __shared__ double m[32];
+    const int c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double sum = 0.0;
+    if (c < kMomComp)
+        for (int b = slice; b < nblk; b += 32) sum += part[(int64_t)b * kMomComp + c];
+    sh[slice][c] = sum;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) t += sh[k][threadIdx.x];
+        m[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double S0 = m[0], s = params[12];
+    const double t[3] = {params[9], params[10], params[11]};
+    double tsz = 0.0, tt = 0.0;
+    moments[0] = S0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        moments[1 + i] = m[1 + i];
+        tsz += t[i] * m[4 + i];
+        tt += t[i] * t[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double sy = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sy += params[3 * k + j] * (m[4 + k] - S0 * t[k]);  // (R^T)[j][k] = R[k][j]
+        moments[4 + j] = sy / s;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v += (m[7 + 3 * i + k] - m[1 + i] * t[k]) * params[3 * k + j];
+            moments[7 + 3 * i + j] = v / s;
+        }
+    moments[16] = (m[16] - 2.0 * tsz + S0 * tt) / (s * s);
+#pragma unroll
+    for (int k = 17; k < 22; ++k) moments[k] = 0.0;
+    moments[22] = m[22];
+    moments[23] = 0.0;
+}
+
 __device__ __forceinline__ void row_moment_terms(double (&a)[kMomComp], double p1, const double (&px)[3],
                                                  const double (&y)[3]) {
     a[0] = p1;
@@ -895,9 +1048,10 @@ int free_plan_buffers(prg_cpd* h) {
     if (h->mompart) (void)hipFree(h->mompart);
     if (h->stage) (void)hipFree(h->stage);
     for (void* q : {(void*)h->perm_src, (void*)h->perm_tgt, (void*)h->zmeta, (void*)h->tmeta, (void*)h->colmin,
-                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount, (void*)h->rorig, (void*)h->zchunk, (void*)h->tchunk})
+                    (void*)h->motion, (void*)h->srcw, (void*)h->wgcount, (void*)h->rorig, (void*)h->corig, (void*)h->zchunk, (void*)h->tchunk})
         if (q) (void)hipFree(q);
     h->rorig = nullptr;
+    h->corig = nullptr;
     h->zchunk = h->tchunk = nullptr;
     h->wgcount = nullptr;
     h->wg_cap = 0;
@@ -1151,6 +1305,7 @@ int prg_cpd_set_target(prg_cpd* h, const float* target_hd, int64_t n_local, int 
     if (cap != h->Ncap || !h->tmeta) {
         PRG_TRY(ensure_exact(&h->tmeta, (size_t)(cap / prg::kGroup) * 8));
         PRG_TRY(ensure_exact(&h->tchunk, (size_t)(cap / prg::kSuper) * 8));
+        PRG_TRY(ensure_exact(&h->corig, (size_t)(cap / prg::kMfmaWgPoints) + 4));
         PRG_TRY(ensure_exact(&h->colmin, (size_t)cap + (size_t)cap / prg::kGroup));  // + per-group maxima
         PRG_HIP(hipMemsetAsync(h->colmin, 0, ((size_t)cap + (size_t)cap / prg::kGroup) * sizeof(float), h->stream));
     }
@@ -1253,6 +1408,20 @@ int prg_cpd_last_estep_lean(prg_cpd* h, int* lean) {
     return PRG_OK;
 }
 
+int prg_cpd_set_moments_only(prg_cpd* h, int mode) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_moments_only: NULL handle");
+    PRG_REQUIRE(mode >= 0 && mode <= 2, PRG_ERR_INVALID, "prg_cpd_set_moments_only: mode must be 0, 1 or 2");
+    h->moments_only = mode == 1;
+    h->fused_in_iterate = mode != 2;
+    return PRG_OK;
+}
+
+int prg_cpd_last_estep_fused(prg_cpd* h, int* fused) {
+    PRG_REQUIRE(h && fused, PRG_ERR_INVALID, "prg_cpd_last_estep_fused: NULL argument");
+    *fused = h->last_estep_fused ? 1 : 0;
+    return PRG_OK;
+}
+
 int prg_cpd_set_stream_mode(prg_cpd* h, int on) {
     PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_stream_mode: NULL handle");
     h->mfma_stream = on != 0;
@@ -1321,7 +1490,18 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     h->mfma_off = false;     // ... and it starts in the dense regime
     h->pred_col = 1;
     h->pred_fine = 0;
+    h->pred_fused = 0;
     h->eng_reset = true;
+    // the fused single sweep maps its column-side sums back through s R: R has to be a rotation (the M-step's own results are)
+    h->init_rot_orthonormal = true;
+    if (init_params_host) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double d = 0.0;
+                for (int k = 0; k < 3; ++k) d += init_params_host[3 * k + i] * init_params_host[3 * k + j];
+                if (fabs(d - (i == j ? 1.0 : 0.0)) > 1.0e-12) h->init_rot_orthonormal = false;
+            }
+    }
     return PRG_OK;
 }
 
@@ -1418,6 +1598,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // engine, and a 512-point patch of a small cloud spans most of it (the patch-local origin buys no precision)
     const bool mfma_possible = use_cull && h->dense_engine > 0 && !h->srcw &&
                                (h->dense_engine >= 2 || (h->M >= 8192 && h->N >= 8192));
+    // the fused single sweep needs: a caller that wants nothing but a rigid M-step's moments, unweighted sources, a rotation to map
+    // the column-side sums back through
+    const bool allow_fused = mfma_possible && h->moments_only && !h->nonrigid && !h->bcpd && h->init_rot_orthonormal;
     static const int mfma_seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;  // 0: fill the chip once
     // (buffers are sized for whichever way a matrix-core launch is cut: grid of segments or stream mode)
     const int PAm = mfma_possible ? std::max(prg::mfma_planes(h->N, h->M, mfma_seg), prg::mfma_stream_planes(h->N, h->M)) : 0,
@@ -1428,7 +1611,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const bool use_queue = use_cull && (h->sparse_engine == 2 || (h->sparse_engine == 1 && h->M >= 32768 && h->N >= 32768));
     const int64_t qcol_elems = use_queue ? prg::queue_max_units(h->N, h->M) * 128 : 0,
                   qrow_elems = use_queue ? prg::queue_max_units(h->M, h->N) * 640 : 0;
-    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems, std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems)));
+    const int64_t fused_elems = allow_fused ? (int64_t)3 * prg::mfma_planes(h->N, h->M, mfma_seg) * h->Ncap : 0;  // 6 floats per (plane, column)
+    PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems,
+                          std::max<int64_t>(std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems), fused_elems)));
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems,
                           std::max<int64_t>((int64_t)std::max(PB, PBm) * 5 * h->Mcap + (h->Mcap >> 7) * 16, qrow_elems)));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
@@ -1470,6 +1655,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     bool fine_cull = false;                   // ... with the per-wave group tests (some groups can be skipped by now)
     bool row_lean = false;                    // ... row pass without its residual sums (k_rowpass_mfma<LEAN>)
     bool col_launched = false;
+    bool fused = false;                       // ... ONE sweep for the whole E-step (rigid M-step moments from the column side)
     const bool cull_seed = h->have_colmin && !h->srcw;  // the seed bound assumes unweighted distances
     const bool ask = mfma_possible && !h->mfma_off;
     if (ev && !ask) PRG_HIP(hipEventRecord(ev[1], h->stream));
@@ -1522,6 +1708,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // within 2.7e-6 of the oracle's up to an amplification of 190 - 1.5e-6 at 56, 2.0e-6 at 85; tests/test_lean_gpu.py holds
         // the forced pass to 1e-5 up to 128 with w = 0 / 0.1 and on a 2-rank shard.  64 makes every matrix-core row pass of C1 lean.)
         ea.lean_factor = h->lean_factor >= 0.0 ? h->lean_factor : lean_env >= 0.0 ? lean_env : 64.0;
+        ea.fused_allowed = allow_fused ? 1 : 0;
         ea.reset = h->eng_reset ? 1 : 0;
         h->eng_reset = false;
         for (int k = 0; k < 6; ++k) ea.tbox[k] = h->tbox[k];
@@ -1535,8 +1722,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // the decision
         prg::launch_chunk_meta_bbox(h, &ea);
         if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
-        const bool pred = h->pred_col != 0;
-        if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
+        const bool pred = h->pred_col != 0, pred_fused = allow_fused && h->pred_fused != 0;
+        if (pred_fused)  // (the single sweep of a rigid iteration, if the previous E-step ran it)
+            prg::launch_fused_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev);
+        else if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
             prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev, h->mfma_stream && h->pred_fine == 0);
         else if (!use_queue)
             prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev);
@@ -1556,6 +1745,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         row_mfma = mb->row != 0;
         fine_cull = mb->fine != 0;
         row_lean = row_mfma && mb->lean != 0;
+        fused = allow_fused && mb->fused != 0;
         if (!mb->dense) h->mfma_off = true;
         static const bool debug_engine = getenv("PRG_DEBUG_ENGINE") != nullptr;
         if (debug_engine)
@@ -1565,10 +1755,21 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                     (double)mb->motion, (double)mb->cmax,
                     (double)mb->nk_width, (double)mb->nk_far2, (int)h->have_colmin, (int)use_mfma, (int)first_mfma,
                     pred == use_mfma ? "yes" : "NO", (int)row_mfma, (int)fine_cull);
-        col_launched = pred == use_mfma && (pred || !use_queue);
+        // which of the three guarded launches (fused sweep / matrix-core column pass / culled column pass) went out ahead, and
+        // was it the one the decision names?
+        if (pred_fused)
+            col_launched = fused;
+        else if (pred)
+            col_launched = use_mfma && !fused;
+        else
+            col_launched = !use_mfma && !use_queue;
         h->pred_col = use_mfma ? 1 : 0;
         h->pred_fine = fine_cull ? 1 : 0;
-        if (!col_launched && use_mfma) {  // (the guarded launch has returned at once; rare: the engine changes once or twice per registration)
+        h->pred_fused = fused ? 1 : 0;
+        if (!col_launched && fused) {  // (the guarded launch has returned at once; rare: the engine changes a few times per registration)
+            prg::launch_fused_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev);
+            col_launched = true;
+        } else if (!col_launched && use_mfma) {
             prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev, h->mfma_stream && !fine_cull);
             col_launched = true;
         }
@@ -1587,6 +1788,33 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     else
         prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
+    h->last_estep_fused = fused;
+    if (fused) {
+        // the single sweep has left per-column (A, B, E): den_n / pt1_n / the next E-step's seeds AND the moments come out of
+        // one merge kernel; no row pass, no per-point block
+        const int nblk_f = (int)prg::ceil_div(h->N, kBlock);
+        k_colfinal_fused<<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), h->mfma_col_planes, h->Ncap,
+                                                           h->N, h->pt1, h->params, w,
+                                                           h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal,
+                                                           h->D, h->colmin, h->colmin + h->Ncap, h->tmeta, first_mfma ? 2 : 1, h->motion,
+                                                           slot, h->corig, h->mompart);
+        if (ev) {
+            PRG_HIP(hipEventRecord(ev[3], h->stream));
+            PRG_HIP(hipEventRecord(ev[4], h->stream));
+        }
+        k_fused_final<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk_f, h->params, h->moments);
+        if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
+        PRG_HIP(hipGetLastError());
+        if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));
+        h->wg_row = 0;
+        h->dense_pairs_row = 0.0;
+        h->qcol_live = h->qrow_live = false;
+        h->have_estep = true;
+        h->rowacc_valid = false;
+        h->have_colmin = true;
+        h->last_w = w;
+        return PRG_OK;
+    }
     // (lean matrix-core row pass: no residual sums - sum pt1 |x|^2 goes from k_colfinal's partials to k_xpx_columns)
     double* xpart = h->mompart + (int64_t)mom_blocks(h) * kMomComp;
     k_colfinal<<<grid1(h->N), kBlock, 0, h->stream>>>(h->tgt4, h->colpart, use_mfma ? h->mfma_col_planes : PA, h->Ncap, h->N, h->pt1, h->params, w,
@@ -1628,6 +1856,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     h->qcol_live = col_queue;
     h->qrow_live = row_queue;
     h->have_estep = true;
+    h->rowacc_valid = true;
     h->have_colmin = true;  // colmin now describes the z4 of this E-step (motion is measured against it)
     h->last_w = w;
     return PRG_OK;
@@ -1718,10 +1947,16 @@ int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter
                 "prg_cpd_iterate: kind must be PRG_TF_RIGID or PRG_TF_AFFINE");
     PRG_REQUIRE(n_iter >= 0, PRG_ERR_INVALID, "prg_cpd_iterate: n_iter must be >= 0");
     prg::DeviceGuard g(h->device);
-    for (int it = 0; it < n_iter; ++it) {
-        PRG_TRY(estep_impl(h, w, nullptr));  // (ends with the all-reduce when a communicator is attached)
-        k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
+    // a rigid iteration wants nothing of its E-step but the moments: the dense regime may run the fused single sweep
+    const bool keep = h->moments_only;
+    if (kind == PRG_TF_RIGID && h->fused_in_iterate) h->moments_only = true;
+    int st = PRG_OK;
+    for (int it = 0; it < n_iter && st == PRG_OK; ++it) {
+        st = estep_impl(h, w, nullptr);  // (ends with the all-reduce when a communicator is attached)
+        if (st == PRG_OK) k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
     }
+    h->moments_only = keep;
+    PRG_TRY(st);
     PRG_HIP(hipGetLastError());
     return PRG_OK;
 }
@@ -1766,6 +2001,9 @@ int prg_cpd_get_moments(prg_cpd* h, double* moments_host) {
 
 int prg_cpd_get_estep(prg_cpd* h, double* pt1_hd, double* p1_hd, double* px_hd) {
     PRG_REQUIRE(h && h->have_estep, PRG_ERR_STATE, "prg_cpd_get_estep: no E-step has been run");
+    PRG_REQUIRE(h->rowacc_valid || (!p1_hd && !px_hd), PRG_ERR_STATE,
+                "prg_cpd_get_estep: the last E-step ran as the fused single sweep of a rigid iteration (prg_cpd_iterate / "
+                "prg_cpd_set_moments_only): it leaves MOMENTS and pt1, no per-point p1 / px");
     prg::DeviceGuard g(h->device);
     const size_t need = (size_t)(h->N > h->M * h->D ? h->N : h->M * h->D) * sizeof(double);
     PRG_TRY(prg::ensure_stage(h, need));

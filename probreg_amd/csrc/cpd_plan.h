@@ -22,6 +22,7 @@ struct EngineDecision {
     float r_col, r_row;
     int row_off;
     int lean;      // 1: the matrix-core row pass runs without its residual sums (sigma2 large enough, see k_chunk_meta_bbox)
+    int fused;     // 1: ONE sweep for this E-step (k_colpass_mfma<FUSED>: rigid M-step moments from the column side, no row pass)
 };
 struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double ext2;
@@ -36,6 +37,7 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     unsigned long long* work;     // [2] (128 x 16) tiles the matrix-core column / row pass of the PREVIOUS E-step evaluated
     float tbox[6];
     int slot, have_colmin, forced, reset;
+    int fused_allowed;            // this E-step feeds a rigid M-step and nothing else (prg_cpd_iterate / prg_cpd_set_moments_only)
     unsigned seq;
     EngineDecision* dev;
     EngineDecision* host;
@@ -113,6 +115,14 @@ struct prg_cpd {
     bool have_colmin = false;
     // matrix-core (dense regime) sweeps
     float4* rorig = nullptr;    // [Mcap/512] origin of each 512-row block of the last matrix-core row pass
+    float4* corig = nullptr;    // [Ncap/512] origin of each 512-column block of the last fused sweep
+    bool fused_in_iterate = true;  // prg_cpd_iterate(RIGID) switches moments_only on for its own E-steps (prg_cpd_set_moments_only(2): not)
+    bool moments_only = false;  // E-steps of this plan feed a RIGID M-step and nothing else: the dense regime may run the fused
+                                // single sweep, which leaves no per-point p1 / px (prg_cpd_set_moments_only, prg_cpd_iterate)
+    bool init_rot_orthonormal = true;  // ... only from a rotation: the column-side sums are mapped back through s R
+    int pred_fused = 0;         // the previous E-step ran the fused sweep (what the host launches ahead of the decision)
+    bool last_estep_fused = false;
+    bool rowacc_valid = false;  // the per-point block (p1, px) holds the last E-step's result (not after a fused sweep)
     float* zchunk = nullptr;    // [Mcap/256][8] box of every 256-point chunk of the transformed source (per E-step)
     float* tchunk = nullptr;    // [Ncap/256][8] box + largest b_n of every 256-point chunk of the target (per E-step)
     int dense_engine = 1;       // 0: VALU sweeps only, 1: matrix-core sweeps in the dense regime,

@@ -48,6 +48,7 @@ void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineD
 int mfma_stream_planes(int64_t owned_points, int64_t streamed_points);  // planes per block in stream mode, 0: not applicable
 // zchunk + bounding box of z4 -> motion[8..13]; eng != null: the last thread also takes the engine decision (EngineArgs)
 void launch_chunk_meta_bbox(prg_cpd* h, const EngineArgs* eng);
+void launch_fused_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard);  // the single sweep (k_colpass_mfma<FUSED>)
 void launch_rowpass_mfma(prg_cpd* h, int S, bool fine, bool lean, bool stream);  // lean: without the residual sums (plane 4)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  // 256-point chunks one workgroup walks

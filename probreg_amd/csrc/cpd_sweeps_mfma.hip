@@ -208,7 +208,22 @@ __device__ __forceinline__ WorkItem sk_item(unsigned u, unsigned u_end, unsigned
 // ---- sweep 1 on the matrix cores: den_n of cpd.py:80 --------------------------------------------------------------
 // grid = (ceil(N / 512), S); plane blockIdx.y receives (min d^2 over the segment, sum of exp2(kk d^2 + L_n)) with
 // L_n = prg::col_seed_offset - the same for every segment of a column.
-__global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
+//
+// FUSED [r4]: the ONE sweep of a rigid EM iteration in the dense regime.  Everything the rigid M-step (cpd.py:160-192)
+// consumes is a sum over the columns n of per-column sums over the sources m:
+//   A_n = sum_m K_mn,   B_n = sum_m K_mn (z_m - o),   E_n = sum_m K_mn |z_m - o|^2        (K_mn = exp2(kk d^2 + L_n), o = the
+//   block's origin) -  den_n = A_n 2^-L_n, pt1_n = den_n / (den_n + c), and with q_n = pt1_n / A_n:
+//   S0 = sum pt1,  Sx = sum pt1 x,  sum_m p1_m z_m = sum_n q_n B_n + pt1_n o,  sum_m px_m z_m^T = sum_n x_n (...)^T,
+//   sum_m p1_m |z_m|^2 = sum_n q_n (E_n + 2 o.B_n) + pt1_n |o|^2,  sum_n pt1_n |x_n|^2
+// (k_colfinal_fused; z -> y through the transformation the E-step ran with) - no row pass, ONE exponential per pair and
+// iteration instead of two.  The kernel is the column pass with the full row pass' contraction on the streamed (source) side:
+// 5 channels (1, dx, dy, dz, |d|^2) per pair, the accumulators of k_rowpass_mfma<false>.  Like the lean row pass it carries no
+// residual sums against the NEW transformation, so it is used only while sigma2's amplification mean |x|^2 / (sigma2 D) is
+// within the lean factor (the decision kernel's `lean`), i.e. in the dense regime it was built for.  Output plane layout:
+// fpart[plane][6][ncap] = (min d^2, A, Bx, By, Bz, E); grid mode only.
+template <bool FUSED>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, FUSED ? 3 : 10))) void k_colpass_mfma(
+                                                         const float4* __restrict__ tgt4, const float4* __restrict__ z4,
                                                          const BoxMeta* __restrict__ tmeta,
                                                          const BoxMeta* __restrict__ zmeta,
                                                          const BoxMeta* __restrict__ zchunk,
@@ -220,18 +235,20 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                                                          float2* __restrict__ colpart, int64_t ncap,
                                                          unsigned* __restrict__ wgcount, unsigned long long* __restrict__ work,
                                                          int first, int fine,
-                                                         const EngineDecision* __restrict__ guard, const StreamCut sk) {
+                                                         const EngineDecision* __restrict__ guard, const StreamCut sk,
+                                                         float4* __restrict__ corig) {
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
     if (guard) {  // launched ahead of the engine decision (cpd.hip, estep_impl): run only if it came out this way
-        if (guard->col != 1) return;
+        const bool fused_wanted = guard->col == 1 && guard->row == 1 && guard->lean == 1 && guard->fused == 1;
+        if (FUSED ? !fused_wanted : (guard->col != 1 || fused_wanted)) return;
         fine = guard->fine;
     }
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const float kk = (float)(-kLog2e / (2.0 * params[13]));
     const float mo = __uint_as_float(*motion);
     const int nchunks = (int)((m_total + kChunk - 1) / kChunk), nblocks = (int)((n_total + kWgPoints - 1) / kWgPoints);
-    const int sk_g = sk.g, sk_pmax = sk.pmax;
+    const int sk_g = FUSED ? 0 : sk.g, sk_pmax = sk.pmax;
     unsigned unit = sk_g ? sk_start(blockIdx.x, sk) : 0u;
     const unsigned unit_end = sk_g ? sk_start(blockIdx.x + 1u, sk) : 0u;
     for (;;) {  // work items of this workgroup (grid mode: exactly one)
@@ -278,16 +295,19 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
     }
     const int k = lane >> 4, j = lane & 15;
     bf16x8 bx[kOwn];
-    float s[kOwn], tm[kOwn], off[kOwn];
+    float s[kOwn], tm[kOwn], off[FUSED ? 1 : kOwn];
+    f32x2 uxy[FUSED ? kOwn : 1], uze[FUSED ? kOwn : 1];  // FUSED: (sum K dx, sum K dy), (sum K dz, sum K |d|^2); s = sum K
 #pragma unroll
     for (int t = 0; t < kOwn; ++t) {
         const float4 x = tgt4[n0 + 16 * t + j];
         const float xx = x.x - o.x, xy = x.y - o.y, xz = x.z - o.z;
         const float xsq = fmaf(xz, xz, fmaf(xy, xy, xx * xx));
-        off[t] = first ? 0.f : prg::col_seed_offset(kk, colmin_prev[n0 + 16 * t + j], mo);
-        bx[t] = owned_operand(k, kk, xx, xy, xz, fmaf(kk, xsq, off[t]));
+        const float offt = first ? 0.f : prg::col_seed_offset(kk, colmin_prev[n0 + 16 * t + j], mo);
+        if (!FUSED) off[t] = offt;  // (FUSED: recomputed in the epilogue - eight registers the contraction needs)
+        bx[t] = owned_operand(k, kk, xx, xy, xz, fmaf(kk, xsq, offt));
         s[t] = 0.f;
         tm[t] = -INFINITY;
+        if (FUSED) uxy[t] = uze[t] = (f32x2){0.f, 0.f};
     }
     unsigned tiles_done = 0;
     const int64_t c0 = item.c0;
@@ -320,14 +340,29 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
             // software pipeline: the MFMA of the NEXT (tile, column tile) pair is issued before the current pair's
             // accumulator is exponentiated.  tile_step works on accumulator d of tile (a1, cz) and leaves the first
             // accumulator of tile (a1n, czn) in d.
-            auto tile_step = [&](f32x4& d, const bf16x8 a1, const f32x4 cz, const bf16x8 a1n, const f32x4 czn) {
+            auto tile_step = [&](f32x4& d, const float* __restrict__ tb, const bf16x8 a1, const f32x4 cz, const bf16x8 a1n,
+                                 const f32x4 czn) {
+                // FUSED: this lane's four streamed sources 4k .. 4k+3 of the tile: (dx, dy) and (dz, |d|^2) pairs (stage_point)
+                f32x2 xy0, xy1, xy2, xy3, zs0, zs1, zs2, zs3;
+                if (FUSED) {
+                    const f32x4 a01 = *reinterpret_cast<const f32x4*>(tb + 272 + 8 * k), a23 = *reinterpret_cast<const f32x4*>(tb + 276 + 8 * k),
+                                b01 = *reinterpret_cast<const f32x4*>(tb + 304 + 8 * k), b23 = *reinterpret_cast<const f32x4*>(tb + 308 + 8 * k);
+                    xy0 = (f32x2){a01[0], a01[1]}; xy1 = (f32x2){a01[2], a01[3]}; xy2 = (f32x2){a23[0], a23[1]}; xy3 = (f32x2){a23[2], a23[3]};
+                    zs0 = (f32x2){b01[0], b01[1]}; zs1 = (f32x2){b01[2], b01[3]}; zs2 = (f32x2){b23[0], b23[1]}; zs3 = (f32x2){b23[2], b23[3]};
+                }
 #pragma unroll
                 for (int u = 0; u < kOwn; ++u) {
                     const f32x4 dn = u + 1 < kOwn ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bx[u + 1], cz, 0, 0, 0)
                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1n, bx[0], czn, 0, 0, 0);
                     tm[u] = fmaxf(fmaxf(tm[u], d[0]), d[1]);
                     tm[u] = fmaxf(fmaxf(tm[u], d[2]), d[3]);
-                    s[u] += (exp2r(d[0]) + exp2r(d[1])) + (exp2r(d[2]) + exp2r(d[3]));
+                    const float q0 = exp2r(d[0]), q1 = exp2r(d[1]), q2 = exp2r(d[2]), q3 = exp2r(d[3]);
+                    s[u] += (q0 + q1) + (q2 + q3);
+                    if (FUSED) {
+                        const f32x2 s0 = {q0, q0}, s1 = {q1, q1}, s2 = {q2, q2}, s3 = {q3, q3};
+                        uxy[u] = __builtin_elementwise_fma(s3, xy3, __builtin_elementwise_fma(s2, xy2, __builtin_elementwise_fma(s1, xy1, __builtin_elementwise_fma(s0, xy0, uxy[u]))));
+                        uze[u] = __builtin_elementwise_fma(s3, zs3, __builtin_elementwise_fma(s2, zs2, __builtin_elementwise_fma(s1, zs1, __builtin_elementwise_fma(s0, zs0, uze[u]))));
+                    }
                     d = dn;
                 }
             };
@@ -339,7 +374,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                     const float* __restrict__ tn = buf + (t + 1 < kChunkTiles ? t + 1 : t) * kTileFloats;
                     const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
                     const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
-                    tile_step(d, a1, cz, a1n, czn);
+                    tile_step(d, buf + t * kTileFloats, a1, cz, a1n, czn);
                     a1 = a1n;
                     cz = czn;
                 }
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
                     const float* __restrict__ tn = buf + t2 * kTileFloats;
                     const bf16x8 a1n = reinterpret_cast<const bf16x8*>(tn)[lane];
                     const f32x4 czn = *reinterpret_cast<const f32x4*>(tn + 256 + 4 * k);
-                    tile_step(d, a1, cz, a1n, czn);
+                    tile_step(d, buf + t * kTileFloats, a1, cz, a1n, czn);
                     if (!more) break;
                     t = t2;
                     a1 = a1n;
@@ -374,6 +409,27 @@ __global__ __launch_bounds__(kBlock) void k_colpass_mfma(const float4* __restric
         const unsigned tiles = wave_tiles[0] + wave_tiles[1] + wave_tiles[2] + wave_tiles[3];
         wgcount[(int64_t)item.plane * nblocks + item.blk] = tiles;
         if (tiles) atomicAdd(work, (unsigned long long)tiles);  // what the next E-step's engine decision goes by
+    }
+    if (FUSED) {
+        float* __restrict__ fout = reinterpret_cast<float*>(colpart) + (int64_t)item.plane * 6 * ncap + n0;
+#pragma unroll
+        for (int u2 = 0; u2 < kOwn; ++u2) {
+            const float st = xor_sum(s[u2]), tt = xor_max(tm[u2]);
+            const float bxs = xor_sum(uxy[u2][0]), bys = xor_sum(uxy[u2][1]), bzs = xor_sum(uze[u2][0]), es = xor_sum(uze[u2][1]);
+            if (lane < 16) {
+                const float offt = first ? 0.f : prg::col_seed_offset(kk, colmin_prev[n0 + 16 * u2 + lane], mo);
+                float dmin = fmaxf((tt - offt) / kk, 0.f);
+                dmin = fmaf(dmin, 2.0e-4f, dmin) + 1.0e-12f;
+                fout[16 * u2 + lane] = tt == -INFINITY ? INFINITY : dmin;
+                fout[ncap + 16 * u2 + lane] = st;
+                fout[2 * ncap + 16 * u2 + lane] = bxs;
+                fout[3 * ncap + 16 * u2 + lane] = bys;
+                fout[4 * ncap + 16 * u2 + lane] = bzs;
+                fout[5 * ncap + 16 * u2 + lane] = es;
+            }
+        }
+        if (item.plane == 0 && threadIdx.x == 0) corig[item.blk] = o;
+        break;
     }
     float2* __restrict__ out = colpart + (int64_t)item.plane * ncap + n0;
 #pragma unroll
@@ -704,7 +760,12 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     const bool dense = ok && (eng.forced || r_col >= eng.r_col_bound);
     // (the row pass' bound depends on which row pass it would be: lean - cheaper per chunk, competitive for longer - or full)
     const bool lean_ok = eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.lean_factor * eng.owned_col >= eng.tsum[3];
-    if (!(r_row >= (lean_ok ? eng.r_row_bound : eng.r_row_bound_full))) row_off = 1;
+    // after a fused sweep there is no row pass to count: the pairs per source point follow from the column side's count
+    if (prev.fused && tc && !eng.reset) r_row = (float)((double)r_col * eng.owned_col / eng.owned_row);
+    // the fused sweep (one exponential per pair instead of two) stays ahead of any pairing of the two-sweep engines for as long
+    // as it may run at all, so the row pass' bound is not asked while it can
+    const bool fused_try = eng.fused_allowed && lean_ok && !row_off;
+    if (!fused_try && !(r_row >= (lean_ok ? eng.r_row_bound : eng.r_row_bound_full))) row_off = 1;
     // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
     // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold
     // (farthest corners of the two bounding boxes: every term of every column is >= 2^-110)
@@ -732,13 +793,14 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     d.sigma2 = (float)sigma2; d.motion = (float)mo; d.cmax = (float)cmax;
     d.nk_ext2 = (float)(nk * eng.ext2); d.nk_width = (float)(nk * width); d.nk_far2 = (float)(nk * far2);
     d.r_col = r_col; d.r_row = r_row; d.row_off = row_off; d.lean = lean ? 1 : 0;
+    d.fused = eng.fused_allowed && col && row && lean ? 1 : 0;
     *eng.dev = d;
     // mailbox: payload first, sequence number last, both at system scope
     EngineDecision* hm = eng.host;
     hm->col = d.col; hm->first = d.first; hm->row = d.row; hm->fine = d.fine; hm->dense = d.dense;
     hm->sigma2 = d.sigma2; hm->motion = d.motion; hm->cmax = d.cmax;
     hm->nk_ext2 = d.nk_ext2; hm->nk_width = d.nk_width; hm->nk_far2 = d.nk_far2;
-    hm->r_col = d.r_col; hm->r_row = d.r_row; hm->row_off = d.row_off; hm->lean = d.lean;
+    hm->r_col = d.r_col; hm->r_row = d.r_row; hm->row_off = d.row_off; hm->lean = d.lean; hm->fused = d.fused;
     __threadfence_system();
     __hip_atomic_store(&hm->seq, d.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -840,14 +902,33 @@ void launch_colpass_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineD
     const StreamCut cut = stream_cut(sp, nblocks, ceil_div(h->M, kChunk));
     if (sp) grid = dim3((unsigned)cut.g, 1);
     // (zchunk: boxes of this E-step's transformed source, written by launch_chunk_meta_bbox before the engine decision)
-    k_colpass_mfma<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
+    k_colpass_mfma<false><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zmeta),
                                                    reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
                                                    h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
                                                    h->colpart, h->Ncap, h->wgcount, h->eng_work, first ? 1 : 0, fine ? 1 : 0, guard,
-                                                   cut);
+                                                   cut, nullptr);
     h->wg_col = nblocks * h->mfma_col_planes;  // (evaluated-tile counters: one per (plane, block))
     h->wg_col_pairs = 128.0 * 16.0;  // counted unit: one wave's 128 points x one 16-point tile
+    h->dense_pairs_col = 0.0;
+}
+
+// the single sweep of a rigid EM iteration (k_colpass_mfma<true>): grid mode, planes of 6 floats per column in h->colpart,
+// block origins in h->corig
+void launch_fused_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDecision* guard) {
+    const int cps = mfma_chunks_per_seg(h->N, h->M, S);
+    const int64_t nblocks = ceil_div(h->N, kWgPoints);
+    dim3 grid((unsigned)nblocks, (unsigned)ceil_div(ceil_div(h->M, kChunk), cps));
+    h->mfma_col_planes = (int)grid.y;
+    const StreamCut none = {0, 0, 0u, 0u};
+    k_colpass_mfma<true><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const BoxMeta*>(h->tmeta),
+                                                         reinterpret_cast<const BoxMeta*>(h->zmeta),
+                                                         reinterpret_cast<const BoxMeta*>(h->zchunk), h->colmin, h->colmin + h->Ncap,
+                                                         h->motion + ((h->estep_count - 1) & 1), cps, h->M, h->N, h->params,
+                                                         h->colpart, h->Ncap, h->wgcount, h->eng_work, first ? 1 : 0, fine ? 1 : 0, guard,
+                                                         none, h->corig);
+    h->wg_col = nblocks * h->mfma_col_planes;
+    h->wg_col_pairs = 128.0 * 16.0;
     h->dense_pairs_col = 0.0;
 }
 

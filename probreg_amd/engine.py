@@ -136,6 +136,16 @@ class CpdPlan(object):
         """``n_iter`` EM iterations enqueued back to back inside the library (prg_cpd_iterate)."""
         check(lib.prg_cpd_iterate(self._h, int(kind), 1 if update_scale else 0, float(w), int(n_iter)))
 
+    def set_moments_only(self, mode=1):
+        """1: every E-step of this plan feeds a rigid M-step only - the dense regime may run the fused single sweep (no p1 / px
+        afterwards); 0 (default): only ``iterate`` does that; 2: never (prg_cpd_set_moments_only)."""
+        check(lib.prg_cpd_set_moments_only(self._h, int(mode)))
+
+    def last_estep_fused(self):
+        v = ctypes.c_int(0)
+        check(lib.prg_cpd_last_estep_fused(self._h, ctypes.byref(v)))
+        return int(v.value)
+
     # -- moment block as a torch tensor (for a caller-side all-reduce: gloo, tests) -----------
     def moments_tensor(self):
         """Allocate (once) a torch fp64 tensor on the plan's device and bind it as MOMENTS."""
@@ -210,6 +220,12 @@ class CpdPlan(object):
         px = np.empty((self.m, self.dim), dtype=np.float64)
         check(lib.prg_cpd_get_estep(self._h, ptr(pt1), ptr(p1), ptr(px)))
         return pt1, p1, px
+
+    def get_estep_pt1(self):
+        """Column sums pt1 alone (available after every E-step, the fused single sweep included)."""
+        pt1 = np.empty(self.n, dtype=np.float64)
+        check(lib.prg_cpd_get_estep(self._h, ptr(pt1), None, None))
+        return pt1
 
     def get_tsource(self):
         out = np.empty((self.m, self.dim), dtype=np.float32)

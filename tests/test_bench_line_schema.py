@@ -60,7 +60,7 @@ def test_roofline_flop_accounting_is_self_consistent():
     if "row_lean" not in f:  # (lines of earlier rounds)
         return
     assert f["row"] == 21.0 and f["row_lean"] == 19.0 and f["col"] == 14.0
-    assert f["row_lean"] <= f["row_window_average"] <= f["row"]
+    assert f["row_lean"] <= f["row_window_average"] <= max(f["row"], f.get("fused", 0.0))  # (round 4: fused single sweep, 22)
     share = r["matrix_core_share"]
     assert 0.0 <= share["row_pass_lean_iterations"] <= share["row_pass_iterations"] <= 1.0
     # achieved = (pairs x flop/pair) / time, per launch: the line's own per-launch figures reproduce it
