@@ -23,7 +23,9 @@ struct EngineDecision {
     int row_off;
     int lean;      // 1: the matrix-core row pass runs without its residual sums (sigma2 large enough, see k_chunk_meta_bbox)
     int fused;     // 1: ONE sweep for this E-step (k_colpass_mfma<FUSED>: rigid M-step moments from the column side, no row pass)
+    int pad_;      // (64-bit counters and doubles sit right behind the device copy of this struct)
 };
+static_assert(sizeof(EngineDecision) % 8 == 0, "the engine state behind EngineDecision needs 8-byte alignment");
 struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double ext2;
     // matrix-core sweeps while they evaluate at least this many pairs per owned point (see estep_impl)
