@@ -159,7 +159,7 @@ int prg_cpd_set_comm(prg_cpd* h, prg_comm* comm);
  * (tol < 0, no callbacks).  Nothing is read back; prg_cpd_get_params afterwards synchronises. */
 int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter);
 /* What a RIGID EM iteration needs of its E-step (cpd.py:160-192) are 23 sums, not the per-point arrays p1 / px.  mode 1: every
- * prg_cpd_estep of this plan may therefore run, while sigma2 is large (dense regime, sigma2's amplification within the lean
+ * prg_cpd_estep of this plan may therefore run, while sigma2 is large (dense regime, sigma2's amplification within the fused
  * factor), as ONE sweep over the pairs - the column pass with the row pass' contraction on the source side, the moments taken
  * from per-column sums - instead of two: MOMENTS, pt1 and the parameter block come out as always,
  * prg_cpd_get_estep has no p1 / px to return after such an E-step (it says so), and the caller must follow it with
@@ -167,6 +167,10 @@ int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter
  * mode 2: nobody does (two sweeps always: tests, measurements).  prg_cpd_last_estep_fused reports what the last E-step did. */
 int prg_cpd_set_moments_only(prg_cpd* h, int mode);
 int prg_cpd_last_estep_fused(prg_cpd* h, int* fused);
+/* The fused sweep runs while the matrix-core column pass would and mean |x|^2 / (sigma2 D) of the local target <= factor
+ * (default 256: sigma2 within 1.4e-6 of the fp64 oracle's there, within 3e-6 at 1300 - profiles/r4_fused_error_100k.log);
+ * tests force it further with a huge value, 0 switches it off. */
+int prg_cpd_set_fused_factor(prg_cpd* h, double factor);
 
 /* sigma2 initialiser, step 1: local target sums -> MOMENTS[24..27] (others zeroed).
  * Replaces: mu.squared_kernel_sum, math_utils.py:28-29 -> cc/math_utils.cc:5-15

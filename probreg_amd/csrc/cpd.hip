@@ -1416,6 +1416,12 @@ int prg_cpd_set_moments_only(prg_cpd* h, int mode) {
     return PRG_OK;
 }
 
+int prg_cpd_set_fused_factor(prg_cpd* h, double factor) {
+    PRG_REQUIRE(h && factor >= 0.0, PRG_ERR_INVALID, "prg_cpd_set_fused_factor: need a handle and a factor >= 0");
+    h->fused_factor = factor;
+    return PRG_OK;
+}
+
 int prg_cpd_last_estep_fused(prg_cpd* h, int* fused) {
     PRG_REQUIRE(h && fused, PRG_ERR_INVALID, "prg_cpd_last_estep_fused: NULL argument");
     *fused = h->last_estep_fused ? 1 : 0;
@@ -1709,6 +1715,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // the forced pass to 1e-5 up to 128 with w = 0 / 0.1 and on a 2-rank shard.  64 makes every matrix-core row pass of C1 lean.)
         ea.lean_factor = h->lean_factor >= 0.0 ? h->lean_factor : lean_env >= 0.0 ? lean_env : 64.0;
         ea.fused_allowed = allow_fused ? 1 : 0;
+        ea.fused_factor = h->fused_factor;
         ea.reset = h->eng_reset ? 1 : 0;
         h->eng_reset = false;
         for (int k = 0; k < 6; ++k) ea.tbox[k] = h->tbox[k];

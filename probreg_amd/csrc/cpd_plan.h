@@ -35,6 +35,7 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double streamed_col, streamed_row;  // M, N_local: what the count is when nothing is culled (the switch's initial memory)
     const double* tsum;           // (sum x, sum y, sum z, sum |x|^2) of the local target
     double lean_factor;           // lean row pass while mean |x|^2 / (sigma2 D) <= this
+    double fused_factor;          // ... and the fused single sweep while it is <= this
     int dim;
     unsigned long long* work;     // [2] (128 x 16) tiles the matrix-core column / row pass of the PREVIOUS E-step evaluated
     float tbox[6];
@@ -143,6 +144,7 @@ struct prg_cpd {
     bool mfma_stream = true;    // dense-regime launches of the matrix-core sweeps are cut in stream mode (prg_cpd_set_stream_mode)
     int mfma_col_planes = 0, mfma_row_planes = 0;  // partial planes the last matrix-core column / row pass wrote (grid or stream mode)
     bool last_estep_row_lean = false;  // ... matrix-core row pass without its residual sums
+    double fused_factor = 256.0;       // fused single sweep while mean |x|^2 / (sigma2 D) <= this (prg_cpd_set_fused_factor)
     double lean_factor = -1.0;         // lean row pass while mean |x|^2 / (sigma2 D) <= this (< 0: the default, 64; prg_cpd_set_lean_factor)
     bool last_estep_mfma = false, last_estep_row_mfma = false;  // engines of the last E-step's column / row pass
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source

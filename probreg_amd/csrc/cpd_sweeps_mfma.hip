@@ -219,7 +219,7 @@ __device__ __forceinline__ WorkItem sk_item(unsigned u, unsigned u_end, unsigned
 // iteration instead of two.  The kernel is the column pass with the full row pass' contraction on the streamed (source) side:
 // 5 channels (1, dx, dy, dz, |d|^2) per pair, the accumulators of k_rowpass_mfma<false>.  Like the lean row pass it carries no
 // residual sums against the NEW transformation, so it is used only while sigma2's amplification mean |x|^2 / (sigma2 D) is
-// within the lean factor (the decision kernel's `lean`), i.e. in the dense regime it was built for.  Output plane layout:
+// within the fused factor (256; the decision kernel's `fused`) and the matrix-core column pass would run.  Output plane layout:
 // fpart[plane][6][ncap] = (min d^2, A, Bx, By, Bz, E); grid mode only.
 template <bool FUSED>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, FUSED ? 3 : 10))) void k_colpass_mfma(
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, FUSED
     __shared__ __attribute__((aligned(16))) float stage[2][kChunkTiles * kTileFloats];
     __shared__ unsigned wave_tiles[kBlock / 64];
     if (guard) {  // launched ahead of the engine decision (cpd.hip, estep_impl): run only if it came out this way
-        const bool fused_wanted = guard->col == 1 && guard->row == 1 && guard->lean == 1 && guard->fused == 1;
+        const bool fused_wanted = guard->col == 1 && guard->fused == 1;
         if (FUSED ? !fused_wanted : (guard->col != 1 || fused_wanted)) return;
         fine = guard->fine;
     }
@@ -764,7 +764,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     if (prev.fused && tc && !eng.reset) r_row = (float)((double)r_col * eng.owned_col / eng.owned_row);
     // the fused sweep (one exponential per pair instead of two) stays ahead of any pairing of the two-sweep engines for as long
     // as it may run at all, so the row pass' bound is not asked while it can
-    const bool fused_try = eng.fused_allowed && lean_ok && !row_off;
+    // (the fused sweep's moments all come from the same column sums - consistent where the lean pass has to reconcile row sums
+    // with column sums - and stay within 3e-6 of the oracle's sigma2 up to an amplification of 1300, tools/fused_error.py: it
+    // has a factor of its own, far above the lean pass')
+    const bool fused_ok = eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.fused_factor * eng.owned_col >= eng.tsum[3];
+    const bool fused_try = eng.fused_allowed && fused_ok && !row_off;
     if (!fused_try && !(r_row >= (lean_ok ? eng.r_row_bound : eng.r_row_bound_full))) row_off = 1;
     // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
     // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     d.sigma2 = (float)sigma2; d.motion = (float)mo; d.cmax = (float)cmax;
     d.nk_ext2 = (float)(nk * eng.ext2); d.nk_width = (float)(nk * width); d.nk_far2 = (float)(nk * far2);
     d.r_col = r_col; d.r_row = r_row; d.row_off = row_off; d.lean = lean ? 1 : 0;
-    d.fused = eng.fused_allowed && col && row && lean ? 1 : 0;
+    d.fused = eng.fused_allowed && col && row && fused_ok ? 1 : 0;
     *eng.dev = d;
     // mailbox: payload first, sequence number last, both at system scope
     EngineDecision* hm = eng.host;

@@ -141,6 +141,10 @@ class CpdPlan(object):
         afterwards); 0 (default): only ``iterate`` does that; 2: never (prg_cpd_set_moments_only)."""
         check(lib.prg_cpd_set_moments_only(self._h, int(mode)))
 
+    def set_fused_factor(self, factor=256.0):
+        """Fused single sweep while mean |x|^2 / (sigma2 D) <= factor (prg_cpd_set_fused_factor)."""
+        check(lib.prg_cpd_set_fused_factor(self._h, float(factor)))
+
     def last_estep_fused(self):
         v = ctypes.c_int(0)
         check(lib.prg_cpd_last_estep_fused(self._h, ctypes.byref(v)))
