@@ -204,6 +204,19 @@ class CoherentPointDrift(abc.ABC):
         need_host = bool(self._callbacks) or tol >= 0 or log.isEnabledFor(10)
         if not need_host and maxiter > 0 and self._iterate_native(plan, w, maxiter):
             return self._result_from_params(plan.get_params())
+        # a rigid iteration consumes nothing of its E-step but the 23 moments (callbacks see the transformation only): the
+        # dense regime may run as ONE sweep over the pairs (prg_cpd_set_moments_only; the per-point p1 / px of the public
+        # expectation_step come from a plan of their own)
+        fuse = getattr(self, "_kind", None) == _lib.PRG_TF_RIGID and hasattr(plan, "set_moments_only")
+        if fuse:
+            plan.set_moments_only(1)
+        try:
+            return self._em_loop(plan, w, maxiter, tol, need_host, res, q)
+        finally:
+            if fuse:
+                plan.set_moments_only(0)
+
+    def _em_loop(self, plan, w, maxiter, tol, need_host, res, q):
         for i in range(maxiter):
             plan.estep(w)
             self._all_reduce_moments(plan)

@@ -33,6 +33,7 @@ p2 = engine.CpdPlan()
 p2.set_source(src - reg._cy)
 p2.set_target(tgt[rows] - reg._cx, n_global=n)
 p2.init_sums()
+p2.set_moments_only(1)
 ptr = ctypes.c_void_p()
 _lib.check(_lib.lib.prg_cpd_params_ptr(p2._h, ctypes.byref(ptr)))
 

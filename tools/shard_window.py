@@ -30,6 +30,7 @@ src, tgt, _ = synthetic.rigid_pair(n, seed=0)
 reg = cpd.RigidCPD(src)
 reg._initialize(tgt)
 plan = reg._plan
+plan.set_moments_only(1)
 comm = plan._comm
 assert comm is not None, "library-side RCCL communicator unavailable"
 states = []
@@ -68,6 +69,7 @@ for world in (1, 2, 4, 8):
     p2.set_source(src - cy)
     p2.set_target(tgt[rows] - cx, n_global=n)
     p2.init_sums()  # (as registration does: the local target's sums decide where the lean row pass may run)
+    p2.set_moments_only(1)  # (as the registration's own loop: rigid iterations may run the fused single sweep)
     view = params_view(p2)
     es, its, cps = [], [], []
     for it, st in enumerate(states):
