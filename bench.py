@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one EM iteration (transform + E-step column pass + E-step row pass + fp64 moment reduction +
-[all-reduce] + device M-step) of RigidCPD on BASELINE.json's config C1: synthetic N = M = 100 000 3-D points, fp32 pair
+A "step" is one EM iteration (transform + E-step + fp64 moment reduction + [all-reduce] + device M-step) of RigidCPD on
+BASELINE.json's config C1 - the E-step as the registration's own loop runs it: while sigma2 is large ONE fused sweep over the pairs
+(the rigid M-step's moments from per-column sums; PROBREG_BENCH_TWO_SWEEPS=1 keeps the column pass + row pass),
+afterwards the culled column pass + row pass: synthetic N = M = 100 000 3-D points, fp32 pair
 arithmetic, w = 0.  With N GPUs the SAME problem is solved with the target cloud sharded over the ranks ("scaling":
 "strong"); one all-reduce of 32 doubles per iteration.  Inputs are resident in HBM before the timed region.
 
@@ -386,7 +388,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         "peak": VALU_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
         "frac": row_tf / VALU_F32_PEAK_TFLOPS,
-        "traffic": _pmc_traffic(workload, "rowpass_hbm_bytes_per_launch"),
+        "traffic": _pmc_traffic(workload, "dominant_sweep_hbm_bytes_per_launch") or _pmc_traffic(workload, "rowpass_hbm_bytes_per_launch"),
         "traffic_source": "profiles/pmc_traffic.json - STATIC: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                           "tools/profile_round.sh, (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch; not measured in this run",
         "how": "flop = pairs the kernel evaluated (per-workgroup device counters, prg_cpd_pair_counts) x %g flop/pair (%g in the "
@@ -417,7 +419,8 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
                         "rowpass": {"ms": last["rowpass"], "pairs": last_pairs[1],
                                     "frac": last_pairs[1] * last_fr / (last["rowpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS},
                         "colpass": {"ms": last["colpass"], "pairs": last_pairs[0],
-                                    "frac": last_pairs[0] * FLOP_COL / (last["colpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS}},
+                                    "frac": (last_pairs[0] * FLOP_COL / (last["colpass"] * 1e-3) / 1e12 / VALU_F32_PEAK_TFLOPS)
+                                    if last["colpass"] > 0 else 0.0}},
         "colpass": {"achieved": col_tf, "frac": col_tf / VALU_F32_PEAK_TFLOPS, "avg_launch_ms": acc["colpass"],
                     "pairs_evaluated_per_launch": pairs_col / steps, "flop_per_pair": FLOP_COL},
         "effective_hbm": {"what": "SURVEY 8(d) algorithmic bytes (P written once + read once at fp32 = 4 M N per sweep "

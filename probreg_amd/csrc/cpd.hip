@@ -1690,6 +1690,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         static const double r_col_env = getenv("PRG_ENGINE_RCOL") ? atof(getenv("PRG_ENGINE_RCOL")) : 0.0;
         static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
         ea.r_col_bound = r_col_env > 0.0 ? r_col_env : h->dense_bound > 0.0 ? h->dense_bound : engine_col_bound(h->M, h->N);
+        // one fused sweep against the vector pipe's two: it stays ahead further down than the matrix-core column pass alone does
+        static const double fused_scale = getenv("PRG_FUSED_RCOL_SCALE") ? atof(getenv("PRG_FUSED_RCOL_SCALE")) : 1.0;
+        ea.r_col_bound_fused = ea.r_col_bound * fused_scale;
         ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, true);
         ea.r_row_bound_full = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, false);  // (the device knows which applies)
         ea.streamed_col = (double)h->M;

@@ -30,6 +30,7 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     double ext2;
     // matrix-core sweeps while they evaluate at least this many pairs per owned point (see estep_impl)
     double r_col_bound, r_row_bound;  // (r_row_bound: for the lean row pass)
+    double r_col_bound_fused;         // ... the dense regime's lower end while the fused single sweep may run (it competes with TWO vector-pipe sweeps)
     double r_row_bound_full;          // ... for the row pass with its residual sums (amplification above the lean factor)
     double owned_col, owned_row;  // N_local, M
     double streamed_col, streamed_row;  // M, N_local: what the count is when nothing is culled (the switch's initial memory)

@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     eng.work[1] = 0ull;
     if (tc && !eng.reset) r_col = (float)((double)tc * 2048.0 / eng.owned_col);
     if (tr && !eng.reset) r_row = (float)((double)tr * 2048.0 / eng.owned_row);
-    const bool dense = ok && (eng.forced || r_col >= eng.r_col_bound);
+
     // (the row pass' bound depends on which row pass it would be: lean - cheaper per chunk, competitive for longer - or full)
     const bool lean_ok = eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.lean_factor * eng.owned_col >= eng.tsum[3];
     // after a fused sweep there is no row pass to count: the pairs per source point follow from the column side's count
@@ -769,6 +769,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     // has a factor of its own, far above the lean pass')
     const bool fused_ok = eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.fused_factor * eng.owned_col >= eng.tsum[3];
     const bool fused_try = eng.fused_allowed && fused_ok && !row_off;
+    const bool dense = ok && (eng.forced || r_col >= (fused_try ? eng.r_col_bound_fused : eng.r_col_bound));
     if (!fused_try && !(r_row >= (lean_ok ? eng.r_row_bound : eng.r_row_bound_full))) row_off = 1;
     // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
     // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold

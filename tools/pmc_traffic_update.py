@@ -33,7 +33,14 @@ def sweep_entry(t, what):
         tot = sum(calls[k] for k in ks)
         return int(round(sum(per[k] * calls[k] for k in ks) / tot)) if tot else None
 
+    def mean_of(keys):
+        tot = sum(calls[k] for k in keys)
+        return int(round(sum(per[k] * calls[k] for k in keys) / tot)) if tot else None
+
+    fused = [k for k in per if k.startswith("k_colpass_mfma<true")]       # the fused single sweep of a rigid iteration
+    dominant = fused + [k for k in per if k.startswith("k_rowpass")]      # what bench.py's roofline is quoted on
     return {"rowpass_hbm_bytes_per_launch": mean("k_rowpass"), "colpass_hbm_bytes_per_launch": mean("k_colpass"),
+            "fused_sweep_hbm_bytes_per_launch": mean_of(fused), "dominant_sweep_hbm_bytes_per_launch": mean_of(dominant),
             "per_kernel_bytes_per_launch": per, "launches_in_profile": calls, "how": what, "round": int(tag[1:])}
 
 

@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r2
 # rocprofv3 kernel traces of the default bench line and PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes;
 # never combined with system / runtime traces) for C1, C3 and C4; summaries land in gpurun_out/prof_<tag>/*.txt.
-tag=${1:-r3}
+tag=${1:-r4}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -17,6 +17,7 @@ c1="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads
 # 2. C1 alone: the un-profiled line with its per-iteration (engine, pairs, ms) table, then the kernel trace of the same command -
 # roofline.frac can be recomputed from these two committed files
 $c1 --pairs-log $out/${tag}_c1_pairs_per_iteration.log > $out/${tag}_bench_c1_line.json 2> $out/c1_line.err
+PROBREG_BENCH_TWO_SWEEPS=1 $c1 --pairs-log $out/${tag}_c1_pairs_per_iteration_two_sweeps.log > $out/${tag}_bench_c1_line_two_sweeps.json 2> /dev/null
 rocprofv3 --kernel-trace --stats -d $out/kt_c1 -o b -- $c1 > $out/c1_kt_line.json 2> $out/kt_c1.err
 sum $(db $out/kt_c1) > $out/${tag}_bench_c1_kernel_trace.txt
 pmc() {  # pmc <prefix> <command...> : FETCH_SIZE and WRITE_SIZE in separate passes (+ the SQ pass with PROFILE_FULL=1)
@@ -36,6 +37,7 @@ sum --pmc $(db $out/c1_FETCH_SIZE) $(db $out/c1_WRITE_SIZE) $(db $out/c1_SQ_INST
 python tools/time_registration.py 2>&1 | grep -v "amdgpu.ids" > $out/${tag}_whole_registrations_100k.log
 python tools/shard_window.py 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window.log
 configs='100000:30:surface:1 30000:30:surface:1 250000:30:surface:1 100000:120:volume:1 100000:72:aniso:1 100000:30:surface:8'
+[ -n "$SKIP_SWITCH" ] && configs=''   # (round 4: the engine-switch logs were taken on their own, profiles/r4_engine_switch_*)
 [ -n "$PROFILE_FULL" ] && configs="$configs 12000:30:surface:1 50000:30:surface:1 400000:26:surface:1 100000:30:surface:4 100000:30:surface:2"
 for cfg in $configs; do
   IFS=: read n its kind world <<< "$cfg"
