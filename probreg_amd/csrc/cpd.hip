@@ -1691,7 +1691,10 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         static const double r_row_env = getenv("PRG_ENGINE_RROW") ? atof(getenv("PRG_ENGINE_RROW")) : 0.0;
         ea.r_col_bound = r_col_env > 0.0 ? r_col_env : h->dense_bound > 0.0 ? h->dense_bound : engine_col_bound(h->M, h->N);
         // one fused sweep against the vector pipe's two: it stays ahead further down than the matrix-core column pass alone does
-        static const double fused_scale = getenv("PRG_FUSED_RCOL_SCALE") ? atof(getenv("PRG_FUSED_RCOL_SCALE")) : 1.0;
+        // (measured at C1, profiles/r4_fused_lower_bound.log: with the dense regime's lower end at 1.0 / 0.7 / 0.5 / 0.35 / 0.25 of the
+        // column pass' own bound the window runs at 792 / 815 / 840 / 831 / 830 it/s (+-2 %): half of that bound is where the
+        // gain levels off; with it, and the fused factor of 256, C1 runs fused through EM iteration 14)
+        static const double fused_scale = getenv("PRG_FUSED_RCOL_SCALE") ? atof(getenv("PRG_FUSED_RCOL_SCALE")) : 0.5;
         ea.r_col_bound_fused = ea.r_col_bound * fused_scale;
         ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, true);
         ea.r_row_bound_full = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, false);  // (the device knows which applies)
@@ -1718,7 +1721,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // the forced pass to 1e-5 up to 128 with w = 0 / 0.1 and on a 2-rank shard.  64 makes every matrix-core row pass of C1 lean.)
         ea.lean_factor = h->lean_factor >= 0.0 ? h->lean_factor : lean_env >= 0.0 ? lean_env : 64.0;
         ea.fused_allowed = allow_fused ? 1 : 0;
-        ea.fused_factor = h->fused_factor;
+        static const double fused_factor_env = getenv("PRG_FUSED_FACTOR") ? atof(getenv("PRG_FUSED_FACTOR")) : -1.0;
+        ea.fused_factor = fused_factor_env >= 0.0 ? fused_factor_env : h->fused_factor;
         ea.reset = h->eng_reset ? 1 : 0;
         h->eng_reset = false;
         for (int k = 0; k < 6; ++k) ea.tbox[k] = h->tbox[k];
