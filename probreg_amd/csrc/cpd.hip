@@ -1475,6 +1475,17 @@ int prg_cpd_set_comm(prg_cpd* h, prg_comm* comm) {
     return PRG_OK;
 }
 
+// R^T R = I to 1e-12 for the row-major 3 x 3 block at `lin` (what the fused single sweep's frame change assumes)
+static bool is_rotation(const double* lin) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double d = 0.0;
+            for (int k = 0; k < 3; ++k) d += lin[3 * k + i] * lin[3 * k + j];
+            if (!(fabs(d - (i == j ? 1.0 : 0.0)) <= 1.0e-12)) return false;
+        }
+    return true;
+}
+
 int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     PRG_REQUIRE(h && h->have_source && h->have_target, PRG_ERR_STATE, "prg_cpd_init_params: clouds not set");
     prg::DeviceGuard g(h->device);
@@ -1499,15 +1510,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     h->pred_fused = 0;
     h->eng_reset = true;
     // the fused single sweep maps its column-side sums back through s R: R has to be a rotation (the M-step's own results are)
-    h->init_rot_orthonormal = true;
-    if (init_params_host) {
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
-                double d = 0.0;
-                for (int k = 0; k < 3; ++k) d += init_params_host[3 * k + i] * init_params_host[3 * k + j];
-                if (fabs(d - (i == j ? 1.0 : 0.0)) > 1.0e-12) h->init_rot_orthonormal = false;
-            }
-    }
+    h->init_rot_orthonormal = !init_params_host || is_rotation(init_params_host);
     return PRG_OK;
 }
 
@@ -2001,6 +2004,7 @@ int prg_cpd_set_params(prg_cpd* h, const double* params_host) {
     prg::DeviceGuard g(h->device);
     PRG_HIP(hipMemcpyAsync(h->params, params_host, PRG_NPARAMS * sizeof(double), hipMemcpyHostToDevice, h->stream));
     PRG_HIP(hipStreamSynchronize(h->stream));
+    h->init_rot_orthonormal = is_rotation(params_host);  // (a caller-set linear part that is no rotation keeps the two sweeps)
     return PRG_OK;
 }
 
