@@ -44,7 +44,12 @@ def main():
             ang = np.deg2rad(rng.uniform(-25, 25))
             rot = np.identity(dim)
             rot[:2, :2] = [[np.cos(ang), -np.sin(ang)], [np.sin(ang), np.cos(ang)]]
-            init = dict(rot=rot, t=rng.uniform(-0.05, 0.05, dim), scale=float(rng.uniform(0.9, 1.1)))
+            scale0 = float(rng.uniform(0.9, 1.1))
+            # a starting transform that turns the source about ITS OWN centroid (clouds may sit hundreds of units from the origin:
+            # a rotation about the origin would throw the source far from the target - there every P underflows float32, n_p is
+            # 1e-77 in the reference's float64 and nothing is left to compare)
+            cen = src.mean(axis=0)
+            init = dict(rot=rot, t=rng.uniform(-0.05, 0.05, dim) + cen - scale0 * rot @ cen, scale=scale0)
         kw = dict(update_scale=upd) if kind == "rigid" else {}
         if init is not None:
             kw["tf_init_params"] = init

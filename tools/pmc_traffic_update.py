@@ -58,7 +58,7 @@ if t:
 t = table("filterreg_500k")
 if t:
     # one launch of the M-step's terms kernel per EM iteration (round 3 folded k_fr_finish into it; round 4 split it out again)
-    iters = max(t.get("k_fr_terms", (0, 0))[1], t.get("k_fr_terms_pt2pl", (0, 0))[1])
+    iters = max([n for k, (b, n) in t.items() if k.startswith("k_fr_terms")] + [0])  # (k_fr_terms<true>, <false>, _pt2pl)
     total = sum(b * n for k, (b, n) in t.items() if not k.startswith(("k_sks", "k_sums", "k_fr_values")))
     out["filterreg_500k"] = {"iteration_hbm_bytes": int(round(total / iters)) if iters else None, "iterations_in_profile": iters,
                              "how": "sum over every kernel of an EM iteration of (2*FETCH_SIZE + WRITE_SIZE)*1024 x launches, "
