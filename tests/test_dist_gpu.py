@@ -80,7 +80,9 @@ def test_two_ranks_on_one_gpu_match_the_unsharded_oracle():
             assert np.array_equal(a["w"], b["w"])
             g = co.rbf_kernel(src, src, 2.0).astype(np.float64)  # compare displacements G W (W itself is ill-conditioned)
             disp = g @ p["w"]
-            assert np.max(np.abs(g @ a["w"] - disp)) <= 3e-4 * max(1.0, np.max(np.abs(disp)))
+            err_nr = np.max(np.abs(g @ a["w"] - disp)) / max(1.0, np.max(np.abs(disp)))
+            print("sharded non-rigid displacement error %.2e" % err_nr)
+            assert err_nr <= TOL_T  # (round 3 granted 3e-4 here; measured 3.3e-7)
         else:
             assert np.array_equal(a["lin"], b["lin"]) and np.array_equal(a["t"], b["t"])
             lin = p["rot"] if kind == "rigid" else p["b"]
