@@ -140,7 +140,7 @@ int prg_cpd_params_ptr(prg_cpd* h, double** params_dev);
  * (the Python layer broadcasts them through torch.distributed), every rank calls prg_comm_create (ncclCommInitRank;
  * collective).  prg_comm_adopt wraps an ncclComm_t the caller already has (not destroyed by prg_comm_destroy).
  * With prg_cpd_set_comm(plan, comm) the plan's prg_cpd_init_sums and prg_cpd_estep END with the SUM all-reduce of
- * MOMENTS (a non-rigid plan: of the per-point block of prg_cpd_rowacc_ptr as well) on the plan's own stream: an EM
+ * MOMENTS (init_sums: all 32 doubles; an E-step: the 24 it wrote; a non-rigid plan: the per-point block of prg_cpd_rowacc_ptr as well) on the plan's own stream: an EM
  * iteration is enqueue-only, nothing between the E-step's last kernel and the M-step leaves the library.
  * comm == NULL detaches (the caller all-reduces MOMENTS itself, e.g. through prg_cpd_bind_moments). */
 #define PRG_COMM_ID_BYTES 128

@@ -1822,7 +1822,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         k_fused_final<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk_f, h->params, h->moments);
         if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
         PRG_HIP(hipGetLastError());
-        if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));
+        // (the E-step's 24 sums only: [24..27] hold the target sums prg_cpd_init_sums has already made global)
+        if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, kMomComp, h->stream));
         h->wg_row = 0;
         h->dense_pairs_row = 0.0;
         h->qcol_live = h->qrow_live = false;
@@ -1867,7 +1868,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     PRG_HIP(hipGetLastError());
     // target sharded over ranks: the one exchange step of the path - partial moments -> moments, on this stream
     if (h->comm) {
-        PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, PRG_NMOMENTS, h->stream));
+        PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, kMomComp, h->stream));  // (the E-step's 24 sums; see above)
         if (h->nonrigid) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->rowacc, 4 * h->Mcap, h->stream));
     }
     h->qcol_live = col_queue;
