@@ -246,3 +246,9 @@ def reset_native_comms():
         if c is not None:
             c.close()
     _native.clear()
+
+
+import atexit  # noqa: E402
+
+# communicators are torn down while the HIP / RCCL runtimes are still up, not by garbage collection at interpreter shutdown
+atexit.register(reset_native_comms)
