@@ -208,29 +208,53 @@ def native_comm(device):
         else:
             wanted = mode == "1"
         if wanted:
-            ok, why = 1, ""
-            try:
-                ids = [NativeComm.unique_id() if rank == 0 else None]
+            import ctypes
+
+            from . import _lib
+
+            def agree(flag):  # every rank takes the same branch: the verdicts are min-reduced over the process group
+                if not have_pg:
+                    return flag
+                v = torch.tensor([flag], dtype=torch.int32, device="cuda:%d" % device)
+                tdist.all_reduce(v, op=tdist.ReduceOp.MIN)
+                return int(v.item())
+
+            why = ""
+            # 1. can every rank bind librccl at all?  (a rank that cannot must not leave the others waiting in a collective)
+            ver = ctypes.c_int(0)
+            ok = 1 if _lib.lib.prg_comm_available(ctypes.byref(ver)) == _lib.PRG_OK else 0
+            if not ok:
+                why = _lib.last_error()
+            ok_all = agree(ok)
+            ident = None
+            if ok_all:
+                # 2. rank 0 draws the id; EVERY rank takes part in the broadcast (None tells the others that it failed)
+                if rank == 0:
+                    try:
+                        ident = NativeComm.unique_id()
+                    except Exception as e:
+                        why = "%s: %s" % (type(e).__name__, e)
                 if have_pg:
-                    tdist.broadcast_object_list(ids, src=0)
-                comm = NativeComm(ids[0], rank, nranks, device)
-                with torch.cuda.device(device):
-                    probe = torch.tensor([1.0, rank + 1.0], dtype=torch.float64, device="cuda:%d" % device)
-                    st = torch.cuda.current_stream().cuda_stream
-                    comm.all_reduce_f64_(probe, st)
-                    got = probe.cpu().tolist()
-                if got != [float(nranks), nranks * (nranks + 1) / 2.0]:
-                    ok, why = 0, "test all-reduce returned %r" % (got,)
-            except Exception as e:  # RCCL not bindable, init failure: fall back together
-                ok, why = 0, "%s: %s" % (type(e).__name__, e)
-            if have_pg:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda:%d" % device)
-                tdist.all_reduce(flag, op=tdist.ReduceOp.MIN)
-                all_ok = int(flag.item())
-            else:
-                all_ok = ok
-            if not all_ok:
-                if not ok:
+                    box = [ident]
+                    tdist.broadcast_object_list(box, src=0)
+                    ident = box[0]
+                ok_all = 1 if ident is not None else 0
+            if ok_all:
+                # 3. join (collective), then the test all-reduce and a last agreement
+                ok = 1
+                try:
+                    comm = NativeComm(ident, rank, nranks, device)
+                    with torch.cuda.device(device):
+                        probe = torch.tensor([1.0, rank + 1.0], dtype=torch.float64, device="cuda:%d" % device)
+                        comm.all_reduce_f64_(probe, torch.cuda.current_stream().cuda_stream)
+                        got = probe.cpu().tolist()
+                    if got != [float(nranks), nranks * (nranks + 1) / 2.0]:
+                        ok, why = 0, "test all-reduce returned %r" % (got,)
+                except Exception as e:
+                    ok, why = 0, "%s: %s" % (type(e).__name__, e)
+                ok_all = agree(ok)
+            if not ok_all:
+                if why:
                     warnings.warn("probreg_amd: library-side RCCL communicator unavailable (%s); the per-iteration "
                                   "all-reduce goes through torch.distributed" % why)
                 if comm is not None:
