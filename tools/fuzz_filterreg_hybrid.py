@@ -60,14 +60,9 @@ def run(driver, src, tgt, kw):
     return rot, t, s2
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    _lib.check(_lib.lib.prg_lattice_set_splat_mode(2))
-    drivers = ("G/O", "O/G", "G/G")
-    bad = {d: 0 for d in drivers}
-    bitwise = 0
-    print("# error against O/O: max(|d rot|, |d t| / max(1, |t|), 10 x relative sigma2 error); tolerance 1e-4")
+def fuzz_cases(cases=30, seed=0):
+    """The generator of tools/fuzz_filterreg.py: yields (index, source, target, keyword arguments, description)."""
+    rng = np.random.default_rng(seed)
     for c in range(cases):
         m = int(rng.choice([rng.integers(5, 60), rng.integers(60, 800), rng.integers(800, 5000)]))
         n = int(rng.choice([rng.integers(5, 60), rng.integers(60, 800), rng.integers(800, 5000)]))
@@ -76,13 +71,23 @@ def main():
         upd = bool(rng.integers(0, 2))
         iters = int(rng.integers(1, 14))
         sigma2 = None if rng.random() < 0.5 else float(10 ** rng.uniform(-3.5, -1.0))
-        seed = int(rng.integers(0, 10 ** 6))
-        src, tgt, _ = synthetic.filterreg_pair(n, m=m, seed=seed)
+        seed_c = int(rng.integers(0, 10 ** 6))
+        src, tgt, _ = synthetic.filterreg_pair(n, m=m, seed=seed_c)
         if dim == 2:
             src, tgt = src[:, :2].copy(), tgt[:, :2].copy()
         kw = dict(sigma2=sigma2, update_sigma2=upd, w=w, maxiter=iters, tol=-1.0)
+        yield c, src, tgt, kw, "case %2d m=%4d n=%4d dim=%d w=%.2f update=%d it=%2d:" % (c, m, n, dim, w, upd, iters)
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    _lib.check(_lib.lib.prg_lattice_set_splat_mode(2))
+    drivers = ("G/O", "O/G", "G/G")
+    bad = {d: 0 for d in drivers}
+    bitwise = 0
+    print("# error against O/O: max(|d rot|, |d t| / max(1, |t|), 10 x relative sigma2 error); tolerance 1e-4")
+    for c, src, tgt, kw, line in fuzz_cases(cases, int(sys.argv[2]) if len(sys.argv) > 2 else 0):
         rot0, t0, s0 = run("O/O", src, tgt, kw)
-        line = "case %2d m=%4d n=%4d dim=%d w=%.2f update=%d it=%2d:" % (c, m, n, dim, w, upd, iters)
         for d in drivers:
             rot, t, s2 = run(d, src, tgt, kw)
             err = max(float(np.max(np.abs(rot - rot0))), float(np.max(np.abs(t - t0))) / max(1.0, float(np.max(np.abs(t0)))),
