@@ -30,6 +30,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert not extra, "ctypes signature without a header declaration: %s" % extra
 
 
+def test_every_declared_symbol_is_mapped_to_the_reference_in_integration_md():
+    """INTEGRATION.md section 2 names every entry point with the reference interface it replaces (or says that there is none)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _declared_symbols() if "`%s`" % n not in text]
+    assert not missing, "INTEGRATION.md does not name %s" % missing
+
+
 def test_version_and_error_channel():
     from probreg_amd import _lib
 
