@@ -171,6 +171,13 @@ int prg_cpd_last_estep_fused(prg_cpd* h, int* fused);
  * (default 256: sigma2 within 1.4e-6 of the fp64 oracle's there, within 3e-6 at 1300 - profiles/r4_fused_error_100k.log);
  * tests force it further with a huge value, 0 switches it off. */
 int prg_cpd_set_fused_factor(prg_cpd* h, double factor);
+/* Below the dense regime (column pass on the vector pipe) the same E-steps - those that feed nothing but a rigid M-step,
+ * cpd.py:160-192 - run as ONE sweep as well: the culled / queued column pass carries the residual sums of its columns,
+ * U_n = sum_m K (x_n - z_m) and R_n = sum_m K |x_n - z_m|^2, and the moments follow per column in fp64 (no
+ * amplification limit: the sums are residuals against the current transformation).  on = 1 (default) / 0: two sweeps there
+ * (A/B measurements, tests).  prg_cpd_last_estep_fused reports 1 for either single sweep, prg_cpd_last_estep_engine which pipe
+ * its column pass ran on. */
+int prg_cpd_set_resid_sweep(prg_cpd* h, int on);
 
 /* sigma2 initialiser, step 1: local target sums -> MOMENTS[24..27] (others zeroed).
  * Replaces: mu.squared_kernel_sum, math_utils.py:28-29 -> cc/math_utils.cc:5-15

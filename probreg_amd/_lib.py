@@ -89,6 +89,7 @@ SIGNATURES = {
     "prg_cpd_set_moments_only": [_vp, _i],
     "prg_cpd_last_estep_fused": [_vp, _c.POINTER(_i)],
     "prg_cpd_set_fused_factor": [_vp, _d],
+    "prg_cpd_set_resid_sweep": [_vp, _i],
     "prg_cpd_init_sums": [_vp],
     "prg_cpd_init_params": [_vp, _vp],
     "prg_cpd_estep": [_vp, _d],

@@ -142,8 +142,8 @@ class CoherentPointDrift(abc.ABC):
         # the per-iteration collective: issued by the library itself on the plan's stream (RCCL, prg_cpd_set_comm) when the
         # process group is an nccl one; through torch.distributed on the bound moment tensor otherwise (gloo)
         comm = pdist.native_comm(plan.device) if hasattr(plan, "set_comm") else None
-        if comm is not None and getattr(plan, "_comm", None) is not comm:
-            plan.set_comm(comm)
+        if hasattr(plan, "set_comm") and getattr(plan, "_comm", None) is not comm:
+            plan.set_comm(comm)  # (also None: a reused plan must not keep a communicator that is gone or no longer wanted)
         mom = plan.moments_tensor() if comm is None and pdist.initialized() else None
         plan.init_sums()
         if mom is not None:

@@ -545,6 +545,172 @@ __global__ __launch_bounds__(kBlock) void k_colfinal_fused(float4* __restrict__ 
     if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Residual-form single sweep of a rigid EM iteration on the vector pipe (k_colpass_cull<true> / k_colpass_queue<true>,
+// DESIGN.md 3.1f): per column n the partials hold (min d^2, A, Ux, Uy, Uz, R) with A = sum_m K, U = sum_m K (x_n - z_m),
+// R = sum_m K |x_n - z_m|^2, K = exp2(kk d^2 + off), off the offset of the partial's OWN minimum (prg::col_offset).  This
+// kernel merges them online in fp64 (k_colfinal's merge with five channels), applies cpd.py:78-82 (den == 0 -> eps32, + c),
+// writes b_n / pt1_n / the next column pass' seeds AND the column's share of the rigid M-step's moments - k_colfinal_fused's
+// terms with the column's own x_n as the origin:  sum_m K z = x A - U,  sum_m K |z|^2 = |x|^2 A - 2 x.U + R:
+//   [0] pt1   [1..3] pt1 x   [4..6] pz = pt1 x - q U   [7..15] x pz^T   [16] pt1 |x|^2 + q (R - 2 x.U)   [22] pt1 |x|^2,
+// q = pt1 / A.  The sums are residuals against the CURRENT transformation (small where P is not), so sigma2 keeps the accuracy of
+// the row pass' residual form at any amplification mean|x|^2 / (sigma2 D) - unlike the matrix-core fused sweep, whose
+// origin is a 512-column block's.  k_fused_final maps the z-side sums back to the source's frame.
+// QUEUE: the partials are the slots of the block's units, [unit][6][128], walked chunk by chunk, unit by unit (fixed order);
+// otherwise planes [plane][6][ncap] with one touched flag per (128-column block, plane) behind them.
+// ---------------------------------------------------------------------------------------------
+template <bool QUEUE>
+__global__ __launch_bounds__(kBlock) void k_colfinal_resid(float4* __restrict__ tgt4, const float* __restrict__ fpart, int nseg,
+                                                           int64_t ncap, int64_t n, float* __restrict__ pt1,
+                                                           const double* __restrict__ params, double w, double m_over_n, int dim,
+                                                           float* __restrict__ colmin, float* __restrict__ colmin_g,
+                                                           float* __restrict__ gmeta, unsigned* __restrict__ stat, int slot,
+                                                           const unsigned char* __restrict__ colflag, const QueueView qv,
+                                                           double* __restrict__ mompart) {
+    const int64_t i_own = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (QUEUE) queue_reset(qv);
+    const bool valid = i_own < n;
+    const int64_t i = valid ? i_own : n - 1;  // lanes past the end redo the last column and store nothing: the wave stays whole
+    const int lane = threadIdx.x & 63;
+    const double sigma2 = params[13];
+    const float kkf = (float)(-kLog2e / (2.0 * sigma2));
+    float gmin = INFINITY, goff = INFINITY;
+    double A = 0.0, U[3] = {0.0, 0.0, 0.0}, R = 0.0;
+    auto merge = [&](float pm, float a, float u0, float u1, float u2, float r) {
+        if (pm < gmin) {
+            const float noff = prg::col_offset(kkf, pm);
+            const double f = (double)__builtin_amdgcn_exp2f(noff - goff);  // first partial: 0 * exp2(-inf) = 0
+            A *= f; U[0] *= f; U[1] *= f; U[2] *= f; R *= f;
+            gmin = pm;
+            goff = noff;
+        }
+        if (a != 0.f) {
+            const float f = __builtin_amdgcn_exp2f(goff - prg::col_offset(kkf, pm));
+            A += (double)(a * f);
+            U[0] += (double)(u0 * f);
+            U[1] += (double)(u1 * f);
+            U[2] += (double)(u2 * f);
+            R += (double)(r * f);
+        }
+    };
+    if (QUEUE) {
+        const int2* __restrict__ cb = qv.chunk + (i >> 7) * qv.nchunk;
+        for (int c0 = 0; c0 < qv.nchunk; c0 += 64) {
+            const int2 mine = c0 + lane < qv.nchunk ? cb[c0 + lane] : make_int2(0, 0);
+            const int lim = qv.nchunk - c0 < 64 ? qv.nchunk - c0 : 64;
+            int c = -1, left = 0, next = 0;
+            auto next_slot = [&]() -> int {  // (wave-uniform)
+                while (left == 0) {
+                    if (++c >= lim) return -1;
+                    next = __builtin_amdgcn_readlane(mine.x, c);
+                    left = __builtin_amdgcn_readlane(mine.y, c);
+                }
+                --left;
+                return next++;
+            };
+            for (;;) {
+                int sl[2];
+                sl[0] = next_slot();
+                if (sl[0] < 0) break;
+                sl[1] = next_slot();
+                float v[2][6];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float* __restrict__ o = fpart + (int64_t)(sl[q] < 0 ? sl[0] : sl[q]) * 768 + (i & 127);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) v[q][k] = o[128 * k];
+                }
+                merge(v[0][0], v[0][1], v[0][2], v[0][3], v[0][4], v[0][5]);
+                if (sl[1] < 0) break;
+                merge(v[1][0], v[1][1], v[1][2], v[1][3], v[1][4], v[1][5]);
+            }
+        }
+    } else {
+        // the wave's 64 columns lie in one 128-column block: lane l looks at the flag of plane p0 + l, a ballot gives the live planes
+        const unsigned char* __restrict__ fl = colflag + (i >> 7) * nseg;
+        for (int p0 = 0; p0 < nseg; p0 += 64) {
+            unsigned long long live = __ballot(p0 + lane < nseg && fl[p0 + lane] != 0);
+            while (live) {
+                const int s0 = p0 + __builtin_ctzll(live);
+                live &= live - 1;
+                const int s1 = live ? p0 + __builtin_ctzll(live) : -1;
+                live &= live - 1;  // (0 stays 0)
+                const float* __restrict__ o0 = fpart + (int64_t)s0 * 6 * ncap + i;
+                const float* __restrict__ o1 = fpart + (int64_t)(s1 < 0 ? s0 : s1) * 6 * ncap + i;
+                float v0[6], v1[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    v0[k] = o0[k * ncap];
+                    v1[k] = o1[k * ncap];
+                }
+                merge(v0[0], v0[1], v0[2], v0[3], v0[4], v0[5]);
+                if (s1 >= 0) merge(v1[0], v1[1], v1[2], v1[3], v1[4], v1[5]);
+            }
+        }
+    }
+    const double den = A * exp2(-(double)goff);  // underflows to 0 exactly where fp64 exp() does
+    double c = 0.0;
+    if (w > 0.0) c = pow(2.0 * M_PI * sigma2, dim * 0.5) * (w / (1.0 - w) * m_over_n);
+    float b, p;
+    double pd = 0.0, qn = 0.0;
+    if (den == 0.0) {  // cpd.py:81: den = eps32, the column of P is all zero
+        b = -INFINITY;
+        p = 0.f;
+    } else {
+        const double tot = den + c;
+        b = (float)(-log2(tot));
+        pd = den / tot;
+        p = (float)pd;
+        qn = pd / A;
+    }
+    float cmin = 0.f;
+    double a[kMomComp];
+#pragma unroll
+    for (int k = 0; k < kMomComp; ++k) a[k] = 0.0;
+    if (valid) {
+        reinterpret_cast<float*>(tgt4 + i)[3] = b;
+        pt1[i] = p;
+        colmin[i] = gmin;
+        cmin = gmin;
+        const float4 xf = tgt4[i];
+        const double x[3] = {xf.x, xf.y, xf.z};
+        double pz[3], xu = 0.0, xx = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pz[k] = pd * x[k] - qn * U[k];
+            xu += x[k] * U[k];
+            xx += x[k] * x[k];
+        }
+        a[0] = pd;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            a[1 + r] = pd * x[r];
+            a[4 + r] = pz[r];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) a[7 + 3 * r + k] = x[r] * pz[k];
+        }
+        a[16] = pd * xx + qn * (R - 2.0 * xu);
+        a[22] = pd * xx;
+    } else {
+        b = 0.f;
+    }
+    block_reduce_store(a, mompart);
+    {  // per group of 32 columns the largest of the minima, and the shard's largest (exactly as k_colfinal)
+        const float gm = half_max(cmin);
+        if ((threadIdx.x & 31) == 0) colmin_g[(int64_t)blockIdx.x * (kBlock / 32) + (threadIdx.x >> 5)] = gm;
+        __shared__ float wg_max[kBlock / 32];
+        if ((threadIdx.x & 31) == 0) wg_max[threadIdx.x >> 5] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float mx = wg_max[0];
+#pragma unroll
+            for (int k = 1; k < kBlock / 32; ++k) mx = fmaxf(mx, wg_max[k]);
+            if (mx > 0.f) atomicMax(stat + 4 + slot, __float_as_uint(mx));
+        }
+    }
+    if (gmeta) block_group_meta(0.f, 0.f, 0.f, b, b, false, gmeta);
+}
+
 // block partials of k_colfinal_fused -> MOMENTS in the layout k_mstep reads.  The sweep saw the TRANSFORMED source
 // z = s R y + t; the rigid M-step wants sums over y: y = R^T (z - t) / s, so
 //   Sy = R^T (Sz - S0 t) / s,   Sxy = (Sxz - Sx t^T) R / s,   tr Syy = (tr Szz - 2 t.Sz + S0 |t|^2) / s^2
@@ -1170,6 +1336,7 @@ int prg_cpd_create(prg_cpd** out, int device, void* hip_stream) {
     h->stream = (hipStream_t)hip_stream;
     if (const char* eng = getenv("PRG_DENSE_ENGINE")) h->dense_engine = std::max(0, std::min(2, atoi(eng)));  // experiments
     if (const char* eng = getenv("PRG_SPARSE_ENGINE")) h->sparse_engine = std::max(0, std::min(2, atoi(eng)));
+    if (const char* eng = getenv("PRG_RESID_SWEEP")) h->resid_sweep = atoi(eng) != 0;  // (A/B runs of the two-sweep sparse regime)
     hipError_t e = hipMalloc((void**)&h->state, (PRG_NMOMENTS + PRG_NPARAMS) * sizeof(double));
     if (e != hipSuccess) {
         delete h;
@@ -1416,6 +1583,12 @@ int prg_cpd_set_moments_only(prg_cpd* h, int mode) {
     return PRG_OK;
 }
 
+int prg_cpd_set_resid_sweep(prg_cpd* h, int on) {
+    PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_resid_sweep: NULL handle");
+    h->resid_sweep = on != 0;
+    return PRG_OK;
+}
+
 int prg_cpd_set_fused_factor(prg_cpd* h, double factor) {
     PRG_REQUIRE(h && factor >= 0.0, PRG_ERR_INVALID, "prg_cpd_set_fused_factor: need a handle and a factor >= 0");
     h->fused_factor = factor;
@@ -1621,8 +1794,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const int64_t qcol_elems = use_queue ? prg::queue_max_units(h->N, h->M) * 128 : 0,
                   qrow_elems = use_queue ? prg::queue_max_units(h->M, h->N) * 640 : 0;
     const int64_t fused_elems = allow_fused ? (int64_t)3 * prg::mfma_planes(h->N, h->M, mfma_seg) * h->Ncap : 0;  // 6 floats per (plane, column)
+    // the residual-form single sweep on the vector pipe: the same callers as the fused sweep, any sigma2, no
+    // matrix cores needed - 6 floats per (plane, column) + a touched flag per (128-column block, plane), or 6 x 128 floats per unit
+    const bool allow_resid = use_cull && h->resid_sweep && h->moments_only && !h->nonrigid && !h->bcpd && !h->srcw && h->init_rot_orthonormal;
+    const int64_t resid_elems = allow_resid ? std::max<int64_t>((int64_t)3 * PA * h->Ncap + (prg::ceil_div(h->N, 128) * PA + 64) / 8 + 8, 3 * qcol_elems) : 0;
     PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems,
-                          std::max<int64_t>(std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems), fused_elems)));
+                          std::max<int64_t>(std::max<int64_t>(std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems), fused_elems), resid_elems)));
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems,
                           std::max<int64_t>((int64_t)std::max(PB, PBm) * 5 * h->Mcap + (h->Mcap >> 7) * 16, qrow_elems)));  // + touched flags: 64 bytes per 128 rows
     PRG_TRY(ensure_mompart(h));
@@ -1665,6 +1842,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     bool row_lean = false;                    // ... row pass without its residual sums (k_rowpass_mfma<LEAN>)
     bool col_launched = false;
     bool fused = false;                       // ... ONE sweep for the whole E-step (rigid M-step moments from the column side)
+    bool resid = false;                       // ... ONE sweep on the vector pipe: the residual-form column pass (k_colpass_cull<true> / k_colpass_queue<true>)
     const bool cull_seed = h->have_colmin && !h->srcw;  // the seed bound assumes unweighted distances
     const bool ask = mfma_possible && !h->mfma_off;
     if (ev && !ask) PRG_HIP(hipEventRecord(ev[1], h->stream));
@@ -1745,7 +1923,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         else if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
             prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev, h->mfma_stream && h->pred_fine == 0);
         else if (!use_queue)
-            prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev);
+            prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev, allow_resid);
         // (pred == vector pipe with the work queue: nothing goes out ahead - inside the dense regime that engine only runs
         // when the bracket of the column minima is too wide for the matrix-core offsets, a handful of E-steps at most)
         PRG_HIP(hipGetLastError());
@@ -1791,21 +1969,55 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
             col_launched = true;
         }
     }
+    // the vector pipe's column pass of an E-step that feeds nothing but a rigid M-step is the residual-form single sweep
+    resid = allow_resid && !use_mfma;
     h->last_estep_mfma = use_mfma;
-    h->last_estep_row_mfma = row_mfma;
-    h->last_estep_row_lean = row_lean;
+    // (a single-sweep E-step has no row pass: nothing to report for it)
+    h->last_estep_row_mfma = row_mfma && !fused && !resid;
+    h->last_estep_row_lean = row_lean && !fused && !resid;
     const bool col_queue = !col_launched && use_queue, row_queue = !row_mfma && use_queue;
     if (col_launched) {
     } else if (col_queue)
-        PRG_TRY(prg::launch_colpass_queue(h, cull_seed, h->qcol_live ? 0 : h->q_first_col));
+        PRG_TRY(prg::launch_colpass_queue(h, cull_seed, h->qcol_live ? 0 : h->q_first_col, resid));
     else if (use_cull)
-        prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr);
+        prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr, resid);
     else if (ra < 0)
         prg::launch_colpass_scalar(h, RA, SA, segA);
     else
         prg::launch_colpass_packed(h, RA, SA, segA);
     if (ev) PRG_HIP(hipEventRecord(ev[2], h->stream));
-    h->last_estep_fused = fused;
+    h->last_estep_fused = fused || resid;
+    if (resid) {
+        // (A, U, R) per column -> den_n / pt1_n / seeds AND the moments in one merge kernel; no row pass, no per-point block
+        const int nblk_f = (int)prg::ceil_div(h->N, kBlock);
+        const double m_over_n = h->uniform_ratio > 0.0 ? h->uniform_ratio : (double)h->M / (double)h->Nglobal;
+        if (col_queue)
+            k_colfinal_resid<true><<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), 0, h->Ncap, h->N, h->pt1,
+                                                                     h->params, w, m_over_n, h->D, h->colmin, h->colmin + h->Ncap, h->tmeta,
+                                                                     h->motion, slot, nullptr, queue_view(h->qcol, true), h->mompart);
+        else
+            k_colfinal_resid<false><<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), PA, h->Ncap, h->N, h->pt1,
+                                                                      h->params, w, m_over_n, h->D, h->colmin, h->colmin + h->Ncap, h->tmeta,
+                                                                      h->motion, slot, prg::resid_flags(h, PA), queue_view(h->qcol, false),
+                                                                      h->mompart);
+        if (ev) {
+            PRG_HIP(hipEventRecord(ev[3], h->stream));
+            PRG_HIP(hipEventRecord(ev[4], h->stream));
+        }
+        k_fused_final<<<1, kRedBlock, 0, h->stream>>>(h->mompart, nblk_f, h->params, h->moments);
+        if (ev) PRG_HIP(hipEventRecord(ev[5], h->stream));
+        PRG_HIP(hipGetLastError());
+        if (h->comm) PRG_TRY(prg::comm_all_reduce_f64(h->comm, h->moments, kMomComp, h->stream));
+        h->wg_row = 0;
+        h->dense_pairs_row = 0.0;
+        h->qcol_live = col_queue;
+        h->qrow_live = false;
+        h->have_estep = true;
+        h->rowacc_valid = false;
+        h->have_colmin = true;
+        h->last_w = w;
+        return PRG_OK;
+    }
     if (fused) {
         // the single sweep has left per-column (A, B, E): den_n / pt1_n / the next E-step's seeds AND the moments come out of
         // one merge kernel; no row pass, no per-point block
@@ -1953,6 +2165,11 @@ int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {
     PRG_REQUIRE(h && h->have_source, PRG_ERR_STATE, "prg_cpd_mstep: source not set");
     PRG_REQUIRE(kind == PRG_TF_RIGID || kind == PRG_TF_AFFINE, PRG_ERR_INVALID,
                 "prg_cpd_mstep: kind must be PRG_TF_RIGID or PRG_TF_AFFINE (use prg_cpd_mstep_nonrigid)");
+    // a single-sweep E-step (fused / residual form) leaves tr(Y^T P1 Y) in MOMENTS[16] and zeros in [17..21]: enough for the rigid fit,
+    // not for the affine one (cpd.py:230-235 needs all of Y^T diag(p1) Y)
+    PRG_REQUIRE(kind == PRG_TF_RIGID || !(h->have_estep && h->last_estep_fused), PRG_ERR_STATE,
+                "prg_cpd_mstep: the last E-step ran as the single sweep of a rigid iteration (prg_cpd_set_moments_only(1)): its "
+                "moments do not hold Y^T diag(p1) Y, which the affine M-step needs");
     prg::DeviceGuard g(h->device);
     k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
     PRG_HIP(hipGetLastError());
@@ -1968,6 +2185,7 @@ int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter
     // a rigid iteration wants nothing of its E-step but the moments: the dense regime may run the fused single sweep
     const bool keep = h->moments_only;
     if (kind == PRG_TF_RIGID && h->fused_in_iterate) h->moments_only = true;
+    if (kind != PRG_TF_RIGID) h->moments_only = false;  // (an affine M-step needs all of Y^T diag(p1) Y: two sweeps, whatever the caller left set)
     int st = PRG_OK;
     for (int it = 0; it < n_iter && st == PRG_OK; ++it) {
         st = estep_impl(h, w, nullptr);  // (ends with the all-reduce when a communicator is attached)

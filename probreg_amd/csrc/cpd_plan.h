@@ -124,6 +124,8 @@ struct prg_cpd {
     bool moments_only = false;  // E-steps of this plan feed a RIGID M-step and nothing else: the dense regime may run the fused
                                 // single sweep, which leaves no per-point p1 / px (prg_cpd_set_moments_only, prg_cpd_iterate)
     bool init_rot_orthonormal = true;  // ... only from a rotation: the column-side sums are mapped back through s R
+    bool resid_sweep = true;    // ... and, where the column pass runs on the vector pipe, the residual-form single sweep (DESIGN.md 3.1f;
+                                // prg_cpd_set_resid_sweep(0): two sweeps there)
     int pred_fused = 0;         // the previous E-step ran the fused sweep (what the host launches ahead of the decision)
     bool last_estep_fused = false;
     bool rowacc_valid = false;  // the per-point block (p1, px) holds the last E-step's result (not after a fused sweep)

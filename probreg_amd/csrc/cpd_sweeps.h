@@ -60,7 +60,8 @@ constexpr int kQueueMaxUnits = 98304;    // fine units the queue holds (250 MB o
 constexpr int kQueueWorkgroups = 2048;   // persistent grid: 8 workgroups of 4 waves per CU
 // q_init: groups per unit to start from (0: adapt from the previous sweep over the queue; the caller passes 32 when the previous
 // E-step's sweep ran on another engine, i.e. was dense)
-int launch_colpass_queue(prg_cpd* h, bool use_seed, int q_init);  // partial (min, sum) pairs -> colpart[unit][128]
+// resid: the residual-form single sweep of a rigid iteration (k_colpass_queue<true>): (min, A, Ux, Uy, Uz, R) -> colpart[unit][6][128]
+int launch_colpass_queue(prg_cpd* h, bool use_seed, int q_init, bool resid = false);  // partial (min, sum) pairs -> colpart[unit][128]
 int launch_rowpass_queue(prg_cpd* h, int q_init);                 // partial sums -> rowpart[unit][5][128]
 int64_t queue_max_units(int64_t owned_points, int64_t streamed_points);
 int prepare_queues(prg_cpd* h);  // allocations of both queues for the plan's current clouds
@@ -79,7 +80,12 @@ constexpr float kCullExp = (float)PRG_CULL_EXP;
 constexpr int kGroup = 32;     // streamed points per cull group (8 scalar quad loads)
 constexpr int kSuper = 256;    // quantum of a culled segment's length (8 groups)
 // culled variants (packed arithmetic, 2 adjacent points per lane); seg_len must be a multiple of kGroup
-void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const EngineDecision* guard = nullptr);
+// resid: the residual-form single sweep of a rigid iteration (k_colpass_cull<true>): planes of 6 floats per column
+// [plane][6][Ncap] in h->colpart, followed by one touched-flag byte per (128-column block, plane) - resid_flags()
+void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const EngineDecision* guard = nullptr, bool resid = false);
+inline unsigned char* resid_flags(const prg_cpd* h, int planes) {
+    return reinterpret_cast<unsigned char*>(reinterpret_cast<float*>(h->colpart) + (int64_t)planes * 6 * h->Ncap);
+}
 void launch_rowpass_cull(prg_cpd* h, int S, int seg_len);
 void launch_colpass_packed(prg_cpd* h, int R, int S, int seg_len);
 void launch_rowpass_packed(prg_cpd* h, int R, int S, int seg_len);

@@ -266,6 +266,14 @@ __device__ __forceinline__ void wave_box(const GroupMeta* __restrict__ own, floa
 // per group of 32 columns, the largest min_m d^2 of the previous E-step and `motion` the largest displacement any
 // source point made since: (sqrt(colmin) + motion)^2 bounds this iteration's minimum from above (triangle
 // inequality), which is what makes a far group's contribution provably < 2^-127 of the final column sum.
+//
+// RESID: the ONE sweep of a rigid EM iteration on the vector pipe.  Next to the online (min d^2, A = sum K)
+// pair the lane keeps the RESIDUAL sums of its column, U = sum_m K (x_n - z_m) and R = sum_m K |x_n - z_m|^2, under the same
+// rescaling (K = exp2(kk d^2 + off)): 4 more fma per pair, and everything the rigid M-step (cpd.py:160-192) consumes follows
+// from (A, U, R) per column in fp64 (k_colfinal_resid) - no row pass, no per-source-point merge.  A chunk is 4 streamed
+// points (the differences stay in registers); planes of 6 floats per column, [plane][6][ncap], and one byte per
+// (128-column block, plane): touched or not - untouched partials are neither written nor read.
+template <bool RESID>
 __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
                                                          const GroupMeta* __restrict__ zmeta,
                                                          const GroupMeta* __restrict__ tmeta, int seg_len, int nseg,
@@ -274,12 +282,14 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
                                                          const unsigned* __restrict__ motion,
                                                          float2* __restrict__ colpart, int64_t ncap,
                                                          unsigned* __restrict__ wgcount,
-                                                         const EngineDecision* __restrict__ guard) {
+                                                         const EngineDecision* __restrict__ guard,
+                                                         unsigned char* __restrict__ colflag) {
     PRG_TRACE_BEGIN();
     // launched ahead of the E-step's engine decision (cpd.hip, estep_impl; dense regime only - null afterwards): run
     // only if the decision names this engine
     if (guard && guard->col != 0) return;
-    __shared__ float4 part[4][64];
+    __shared__ float4 part[RESID ? 1 : 4][64];
+    __shared__ float2 partr[RESID ? 4 : 1][6][64];
     __shared__ int arrived, wave_groups[4];
     int ngrp = 0;  // (wave, group) blocks this wave evaluates: 128 x 32 pairs each (measurement hook, wave-uniform)
     if (threadIdx.x == 0) arrived = 0;
@@ -289,6 +299,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
     const int64_t n0 = (int64_t)blockIdx.x * 128 + 2 * lane;
     const int seg = blockIdx.y * 4 + wv;
     f2 run = splat(INFINITY), off = splat(INFINITY), s = splat(0.f);
+    f2 ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), rr = splat(0.f);  // RESID: sum K (x - z), sum K |x - z|^2
     if (seg < nseg) {
         const int64_t gw = (int64_t)blockIdx.x * 4;  // the workgroup's four 32-column groups
         float lo[3], hi[3];
@@ -332,6 +343,39 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
                 PRG_TRACE_GROUP();
                 const Quad* __restrict__ q = zp + (int64_t)g * 8;
                 const Quad* __restrict__ qn = zp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
+                if constexpr (RESID) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const Quad nq = (t < 7) ? q[t + 1] : qn[0];  // prefetch: next quad, or the next needed group's first
+                        f2 dx[4], dy[4], dz[4], d2[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            dx[c] = x - splat(qa.q[c].x);
+                            dy[c] = y - splat(qa.q[c].y);
+                            dz[c] = z - splat(qa.q[c].z);
+                            d2[c] = fmav(dz[c], dz[c], fmav(dy[c], dy[c], fmav(dx[c], dx[c], splat(qa.q[c].w))));
+                        }
+                        const f2 cm = minv(minv(d2[0], d2[1]), minv(d2[2], d2[3]));
+                        if ((cm.x < run.x) | (cm.y < run.y)) {  // rare after the first trips: all five sums move to the new minimum
+                            const f2 nm = minv(run, cm);
+                            const f2 noff = col_offset2(kk, nm);
+                            const f2 f = exp2v(noff - off);  // first use: off == +inf -> 0, and the sums are 0 anyway
+                            s *= f; ux *= f; uy *= f; uz *= f; rr *= f;
+                            run = nm;
+                            off = noff;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const f2 pr = exp2v(fmav(d2[c], splat(kk), off));
+                            s += pr;
+                            ux = fmav(pr, dx[c], ux);
+                            uy = fmav(pr, dy[c], uy);
+                            uz = fmav(pr, dz[c], uz);
+                            rr = fmav(pr, d2[c], rr);
+                        }
+                        qa = nq;
+                    }
+                } else {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const Quad qb = q[2 * t + 1];
@@ -360,6 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
 #pragma unroll
                     for (int c = 0; c < 8; ++c) s += exp2v(fmav(d2[c], splat(kk), off));
                 }
+                }
                 if (gnext < 0) break;
                 g = gnext;
             }
@@ -368,19 +413,61 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
     // Merge the four segments' (min, sum) pairs (sums are relative to the offset of their own minimum) without a
     // barrier: every wave leaves its pair in LDS and counts itself in; whoever arrives last does the merge.  An idle
     // wave is gone after its one round trip instead of holding a wave slot until its busiest sibling has finished.
-    part[wv][lane] = make_float4(run.x, s.x, run.y, s.y);
+    if constexpr (RESID) {
+        if (ngrp) {  // an untouched wave contributes nothing and leaves nothing to read
+            partr[wv][0][lane] = make_float2(run.x, run.y);
+            partr[wv][1][lane] = make_float2(s.x, s.y);
+            partr[wv][2][lane] = make_float2(ux.x, ux.y);
+            partr[wv][3][lane] = make_float2(uy.x, uy.y);
+            partr[wv][4][lane] = make_float2(uz.x, uz.y);
+            partr[wv][5][lane] = make_float2(rr.x, rr.y);
+        }
+    } else {
+        part[wv][lane] = make_float4(run.x, s.x, run.y, s.y);
+    }
     int last = 0;
     if (lane == 0) {
         wave_groups[wv] = ngrp;
         last = atomicAdd(&arrived, 1) == 3;  // LDS ops of a wave execute in order: the pair is visible
     }
     if (__builtin_amdgcn_readfirstlane(last)) {
+        const int tk[4] = {wave_groups[0], wave_groups[1], wave_groups[2], wave_groups[3]};
         if (lane == 0)  // one plain store per workgroup; summed on the host when the bench asks (prg_cpd_pair_counts)
-            wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] =
-                (unsigned)(wave_groups[0] + wave_groups[1] + wave_groups[2] + wave_groups[3]);
+            wgcount[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = (unsigned)(tk[0] + tk[1] + tk[2] + tk[3]);
         run = splat(INFINITY);
         off = splat(INFINITY);
         s = splat(0.f);
+        if constexpr (RESID) {
+            const bool any = (tk[0] | tk[1] | tk[2] | tk[3]) != 0;
+            if (lane == 0) colflag[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = any ? 1 : 0;
+            if (any) {
+                ux = uy = uz = rr = splat(0.f);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!tk[k]) continue;
+                    const float2 q0 = partr[k][0][lane], q1 = partr[k][1][lane], q2 = partr[k][2][lane], q3 = partr[k][3][lane],
+                                 q4 = partr[k][4][lane], q5 = partr[k][5][lane];
+                    const f2 orun = {q0.x, q0.y};
+                    const f2 nm = minv(run, orun);
+                    const f2 noff = col_offset2(kk, nm);
+                    const f2 fa = exp2v(noff - off), fb = exp2v(noff - col_offset2(kk, orun));
+                    s = s * fa + (f2){q1.x, q1.y} * fb;
+                    ux = ux * fa + (f2){q2.x, q2.y} * fb;
+                    uy = uy * fa + (f2){q3.x, q3.y} * fb;
+                    uz = uz * fa + (f2){q4.x, q4.y} * fb;
+                    rr = rr * fa + (f2){q5.x, q5.y} * fb;
+                    run = nm;
+                    off = noff;
+                }
+                float* __restrict__ o = reinterpret_cast<float*>(colpart) + (int64_t)blockIdx.y * 6 * ncap + n0;
+                *reinterpret_cast<float2*>(o) = make_float2(run.x, run.y);
+                *reinterpret_cast<float2*>(o + ncap) = make_float2(s.x, s.y);
+                *reinterpret_cast<float2*>(o + 2 * ncap) = make_float2(ux.x, ux.y);
+                *reinterpret_cast<float2*>(o + 3 * ncap) = make_float2(uy.x, uy.y);
+                *reinterpret_cast<float2*>(o + 4 * ncap) = make_float2(uz.x, uz.y);
+                *reinterpret_cast<float2*>(o + 5 * ncap) = make_float2(rr.x, rr.y);
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float4 o = part[k][lane];
@@ -394,6 +481,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_cull(const float4* __restric
         }
         float4* out = reinterpret_cast<float4*>(colpart + (int64_t)blockIdx.y * ncap + n0);
         *out = make_float4(run.x, s.x, run.y, s.y);
+        }
     }
     PRG_TRACE_END(0);
 }
@@ -531,13 +619,20 @@ extern "C" int prg_debug_set_wave_trace(unsigned long long* dev_buffer, unsigned
 #endif
 
 // S segments of seg_len streamed points, four per workgroup: S/4 (rounded up) partial planes
-void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const EngineDecision* guard) {
+void launch_colpass_cull(prg_cpd* h, int S, int seg_len, bool use_seed, const EngineDecision* guard, bool resid) {
     dim3 grid((unsigned)ceil_div(h->N, 128), (unsigned)ceil_div(S, 4));
-    k_colpass_cull<<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
+    if (resid)  // planes of 6 floats per column, then one touched-flag byte per (128-column block, plane)
+        k_colpass_cull<true><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
+                                                             reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len, S, h->params,
+                                                             use_seed ? h->colmin + h->Ncap : nullptr,
+                                                             h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap,
+                                                             h->wgcount, guard, resid_flags(h, (int)grid.y));
+    else
+    k_colpass_cull<false><<<grid, kBlock, 0, h->stream>>>(h->tgt4, h->z4, reinterpret_cast<const GroupMeta*>(h->zmeta),
                                                    reinterpret_cast<const GroupMeta*>(h->tmeta), seg_len, S, h->params,
                                                    use_seed ? h->colmin + h->Ncap : nullptr,
                                                    h->motion + ((h->estep_count - 1) & 1), h->colpart, h->Ncap,
-                                                   h->wgcount, guard);
+                                                   h->wgcount, guard, nullptr);
     h->wg_col = (int64_t)grid.x * grid.y;
     h->wg_col_pairs = 128.0 * kGroup;  // (a mispredicted matrix-core launch ahead of this one has left its own unit here)
     h->dense_pairs_col = 0.0;

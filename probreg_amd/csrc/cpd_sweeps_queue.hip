@@ -301,6 +301,9 @@ __global__ __launch_bounds__(kBlock) void k_rowpass_queue(const float4* __restri
 
 // Column pass over the queue: lane owns columns b * 128 + 2 * lane, +1; slot u receives (min d^2, sum exp2) pairs as
 // [128] float2 (sums relative to the offset of their own minimum, as the culled column pass leaves them).
+// RESID: the residual-form single sweep of a rigid iteration (k_colpass_cull<true> in cpd_sweeps_packed.hip has the algebra):
+// slot u receives (min d^2, A, Ux, Uy, Uz, R) as [6][128] floats.
+template <bool RESID>
 __global__ __launch_bounds__(kBlock) void k_colpass_queue(const float4* __restrict__ tgt4, const float4* __restrict__ z4,
                                                           const unsigned long long* __restrict__ masks, int nwords,
                                                           const int2* __restrict__ units, int* __restrict__ ctrl,
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_colpass_queue(const float4* __restri
             const float4 xa = tgt4[n0], xb = tgt4[n0 + 1];
             const f2 x = {xa.x, xb.x}, y = {xa.y, xb.y}, z = {xa.z, xb.z};
             f2 run = splat(INFINITY), off = splat(INFINITY), sm = splat(0.f);
+            f2 ux = splat(0.f), uy = splat(0.f), uz = splat(0.f), rr = splat(0.f);
             int ngrp = 0;
             UnitWalk walk;
             walk.init(masks + (int64_t)b * nwords, un.y & 0x3FFFFF, (int)((unsigned)un.y >> 22), lane);
@@ -331,6 +335,39 @@ __global__ __launch_bounds__(kBlock) void k_colpass_queue(const float4* __restri
                     ++ngrp;
                     const Quad* __restrict__ q = zp + (int64_t)g * 8;
                     const Quad* __restrict__ qn = zp + (int64_t)(gnext >= 0 ? gnext : g) * 8;
+                    if constexpr (RESID) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            const Quad nq = (t < 7) ? q[t + 1] : qn[0];
+                            f2 dx[4], dy[4], dz[4], d2[4];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                dx[c] = x - splat(qa.q[c].x);
+                                dy[c] = y - splat(qa.q[c].y);
+                                dz[c] = z - splat(qa.q[c].z);
+                                d2[c] = fmav(dz[c], dz[c], fmav(dy[c], dy[c], fmav(dx[c], dx[c], splat(qa.q[c].w))));
+                            }
+                            const f2 cm = minv(minv(d2[0], d2[1]), minv(d2[2], d2[3]));
+                            if ((cm.x < run.x) | (cm.y < run.y)) {
+                                const f2 nm = minv(run, cm);
+                                const f2 noff = col_offset2(kk, nm);
+                                const f2 f = exp2v(noff - off);
+                                sm *= f; ux *= f; uy *= f; uz *= f; rr *= f;
+                                run = nm;
+                                off = noff;
+                            }
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                const f2 pr = exp2v(fmav(d2[c], splat(kk), off));
+                                sm += pr;
+                                ux = fmav(pr, dx[c], ux);
+                                uy = fmav(pr, dy[c], uy);
+                                uz = fmav(pr, dz[c], uz);
+                                rr = fmav(pr, d2[c], rr);
+                            }
+                            qa = nq;
+                        }
+                    } else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const Quad qb = q[2 * t + 1];
@@ -359,10 +396,21 @@ __global__ __launch_bounds__(kBlock) void k_colpass_queue(const float4* __restri
 #pragma unroll
                         for (int c = 0; c < 8; ++c) sm += exp2v(fmav(d2[c], splat(kk), off));
                     }
+                    }
                     g = gnext;
                 }
             }
-            *reinterpret_cast<float4*>(slots + (int64_t)slot * 128 + 2 * lane) = make_float4(run.x, sm.x, run.y, sm.y);
+            if constexpr (RESID) {
+                float* __restrict__ o = reinterpret_cast<float*>(slots) + (int64_t)slot * (6 * 128) + 2 * lane;
+                *reinterpret_cast<float2*>(o) = make_float2(run.x, run.y);
+                *reinterpret_cast<float2*>(o + 128) = make_float2(sm.x, sm.y);
+                *reinterpret_cast<float2*>(o + 256) = make_float2(ux.x, ux.y);
+                *reinterpret_cast<float2*>(o + 384) = make_float2(uy.x, uy.y);
+                *reinterpret_cast<float2*>(o + 512) = make_float2(uz.x, uz.y);
+                *reinterpret_cast<float2*>(o + 640) = make_float2(rr.x, rr.y);
+            } else {
+                *reinterpret_cast<float4*>(slots + (int64_t)slot * 128 + 2 * lane) = make_float4(run.x, sm.x, run.y, sm.y);
+            }
             if (lane == 0) ucount[slot] = (unsigned)ngrp;
         } else if (lane == 0) {
             ucount[slot] = 0u;
@@ -437,10 +485,15 @@ int prepare_queues(prg_cpd* h) {
     return PRG_OK;
 }
 
-int launch_colpass_queue(prg_cpd* h, bool use_seed, int q_init) {
+int launch_colpass_queue(prg_cpd* h, bool use_seed, int q_init, bool resid) {
     PRG_TRY(build_queue<false>(h, h->qcol, h->N, h->M, h->tmeta, h->zmeta, use_seed, q_init));
     SweepQueue& q = h->qcol;
-    k_colpass_queue<<<kQueueWorkgroups, kBlock, 0, h->stream>>>(h->tgt4, h->z4, q.masks, q.nchunk * (kQueueChunkGroups / 64), q.units,
+    if (resid)
+        k_colpass_queue<true><<<kQueueWorkgroups, kBlock, 0, h->stream>>>(h->tgt4, h->z4, q.masks, q.nchunk * (kQueueChunkGroups / 64), q.units,
+                                                                         q.ctrl, q.cap_soft, h->params, reinterpret_cast<float2*>(h->colpart),
+                                                                         q.ucount);
+    else
+    k_colpass_queue<false><<<kQueueWorkgroups, kBlock, 0, h->stream>>>(h->tgt4, h->z4, q.masks, q.nchunk * (kQueueChunkGroups / 64), q.units,
                                                                q.ctrl, q.cap_soft, h->params, reinterpret_cast<float2*>(h->colpart),
                                                                q.ucount);
     h->wg_col = -1;  // counted per unit (prg_cpd_pair_counts reads the unit counts and ucount)

@@ -13,6 +13,7 @@ two-ranks-on-one-GPU rig) and as the fallback when RCCL cannot be bound.
 """
 import os
 import warnings
+import weakref
 
 import numpy as np
 
@@ -140,6 +141,13 @@ class NativeComm(object):
         buf = (ctypes.c_ubyte * _lib.PRG_COMM_ID_BYTES).from_buffer_copy(bytes(id_bytes))
         _lib.check(_lib.lib.prg_comm_create(ctypes.byref(self._h), buf, int(rank), int(nranks), int(device)))
         self.rank, self.nranks, self.device = int(rank), int(nranks), int(device)
+        self._plans = weakref.WeakSet()  # plans whose C side points at this communicator (CpdPlan.set_comm)
+
+    def _attached(self, plan):
+        self._plans.add(plan)
+
+    def _detached(self, plan):
+        self._plans.discard(plan)
 
     @staticmethod
     def unique_id():
@@ -168,6 +176,14 @@ class NativeComm(object):
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
+            # no plan may keep a pointer to a destroyed communicator: its next prg_cpd_estep / prg_cpd_init_sums would
+            # all-reduce through freed memory (and the Python side would skip the torch.distributed all-reduce)
+            for plan in list(getattr(self, "_plans", ())):
+                try:
+                    if getattr(plan, "_comm", None) is self and getattr(plan, "_h", None):
+                        plan.set_comm(None)
+                except Exception:  # pragma: no cover  (a plan that is being torn down itself)
+                    pass
             self._lib.lib.prg_comm_destroy(self._h)
             self._h = None
 
@@ -178,7 +194,16 @@ class NativeComm(object):
             pass
 
 
-_native = {}  # device -> NativeComm or None (None: tried and given up - every rank took the same decision)
+_native = {}  # (device, process-group identity) -> NativeComm or None (None: tried and given up - every rank took the same decision)
+
+
+def _pg_key():
+    """Identity of the default process group (None without one): the collective decision below is taken once per group."""
+    if not initialized():
+        return None
+    import torch.distributed as tdist
+
+    return (id(tdist.group.WORLD), tdist.get_backend(), tdist.get_world_size())
 
 
 def native_comm(device):
@@ -192,9 +217,15 @@ def native_comm(device):
     so that all ranks use the same path.
     """
     device = int(device)
-    if device in _native:
-        return _native[device]
+    key = (device, _pg_key())
+    if key in _native:
+        return _native[key]
     mode = os.environ.get("PROBREG_NATIVE_RCCL", "")
+    if key[1] is None and mode != "1":
+        # no process group (yet) and no request for a one-rank communicator: nothing to decide, and nothing to remember - a
+        # group created later is a new key, and EVERY rank then enters the collective set-up below together (a rank that had
+        # cached "None" from a single-process registration before init_process_group would issue other collectives than its peers)
+        return None
     comm = None
     if mode != "0":
         import torch
@@ -225,6 +256,9 @@ def native_comm(device):
             ok = 1 if _lib.lib.prg_comm_available(ctypes.byref(ver)) == _lib.PRG_OK else 0
             if not ok:
                 why = _lib.last_error()
+            elif ver.value and not (20000 <= ver.value < 30000):
+                # comm.hip restates the ABI of RCCL / NCCL 2.x (ncclUniqueId by value, ncclFloat64 = 8, ncclSum = 0)
+                ok, why = 0, "librccl reports version code %d, the restated ABI is that of 2.x" % ver.value
             ok_all = agree(ok)
             ident = None
             if ok_all:
@@ -240,7 +274,14 @@ def native_comm(device):
                     ident = box[0]
                 ok_all = 1 if ident is not None else 0
             if ok_all:
-                # 3. join (collective), then the test all-reduce and a last agreement
+                # 3a. what could make ONE rank raise before it enters ncclCommInitRank (the others would wait in it for good):
+                # checked locally and agreed on first
+                pre = 1 if (len(ident) == _lib.PRG_COMM_ID_BYTES and 0 <= device < torch.cuda.device_count()) else 0
+                if not pre:
+                    why = "bad communicator id (%d bytes) or device %d" % (len(ident), device)
+                ok_all = agree(pre)
+            if ok_all:
+                # 3b. join (collective), then the test all-reduce and a last agreement
                 ok = 1
                 try:
                     comm = NativeComm(ident, rank, nranks, device)
@@ -260,7 +301,7 @@ def native_comm(device):
                 if comm is not None:
                     comm.close()
                 comm = None
-    _native[device] = comm
+    _native[key] = comm
     return comm
 
 

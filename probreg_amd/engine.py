@@ -130,7 +130,12 @@ class CpdPlan(object):
     def set_comm(self, comm):
         """Attach a ``dist.NativeComm`` (None detaches): init_sums / estep then end with the all-reduce themselves."""
         check(lib.prg_cpd_set_comm(self._h, comm._h if comm is not None else None))
+        old = getattr(self, "_comm", None)
+        if old is not None and old is not comm:
+            old._detached(self)
         self._comm = comm  # keeps the communicator alive as long as the plan uses it
+        if comm is not None:
+            comm._attached(self)  # ... and the communicator detaches the plan before it is destroyed (NativeComm.close)
 
     def iterate(self, kind, update_scale, w, n_iter):
         """``n_iter`` EM iterations enqueued back to back inside the library (prg_cpd_iterate)."""
@@ -140,6 +145,10 @@ class CpdPlan(object):
         """1: every E-step of this plan feeds a rigid M-step only - the dense regime may run the fused single sweep (no p1 / px
         afterwards); 0 (default): only ``iterate`` does that; 2: never (prg_cpd_set_moments_only)."""
         check(lib.prg_cpd_set_moments_only(self._h, int(mode)))
+
+    def set_resid_sweep(self, on=True):
+        """Residual-form single sweep where a rigid iteration's column pass runs on the vector pipe (prg_cpd_set_resid_sweep)."""
+        check(lib.prg_cpd_set_resid_sweep(self._h, 1 if on else 0))
 
     def set_fused_factor(self, factor=256.0):
         """Fused single sweep while mean |x|^2 / (sigma2 D) <= factor (prg_cpd_set_fused_factor)."""

@@ -231,11 +231,15 @@ class FilterReg(abc.ABC):
             raise ValueError("source and target must both be (n, 2) or (n, 3) arrays.")
         if feature_fn is None:  # documented selector of the device-resident path
             feature_fn = _identity
-        if feature_fn is not _identity and feature_fn(self._source) is self._source:
+        if feature_fn is not _identity:
             # the reference's own idiom `feature_fn=lambda x: x` (filterreg.py:121): a callable that hands the very
-            # object it was given back IS the identity - no numerical probe on a sample (an extractor that needs
-            # neighbourhoods would misbehave on one), just the one call on the whole source cloud
-            feature_fn = _identity
+            # object it was given back, UNCHANGED, is the identity - no numerical probe on a sample (an extractor that needs
+            # neighbourhoods would misbehave on one), just one call on a COPY of the whole source cloud (an in-place
+            # extractor - `x -= x.mean(0); return x` - also returns its argument: it must neither be taken for the
+            # identity nor touch the live source)
+            probe = self._source.copy()
+            if feature_fn(probe) is probe and np.array_equal(probe, self._source):
+                feature_fn = _identity
         if feature_fn is not _identity:
             # any other callable takes the reference's loop (features on the host every iteration)
             return self._registration_features(target, w, objective_type, maxiter, tol, min_sigma2, feature_fn)

@@ -191,6 +191,14 @@ def test_library_side_rccl_all_reduce_one_rank():
         # with a tolerance to test (host reads q every iteration) the Python loop runs: same collective, same numbers
         res2 = cpd.registration_cpd(src, tgt, "rigid", maxiter=12, tol=0.0)
         assert res2.sigma2 == plain.sigma2
+        # a reused plan must not keep a communicator that is gone: reset_native_comms detaches it before destroying it, and
+        # the next registration of the same object (no communicator wanted any more) runs plain
+        dist.reset_native_comms()
+        assert reg._plan._comm is None
+        os.environ["PROBREG_NATIVE_RCCL"] = "0"
+        res3 = reg.registration(tgt, maxiter=12, tol=-1.0)
+        assert res3.sigma2 == plain.sigma2 and np.array_equal(res3.transformation.rot, plain.transformation.rot)
+        os.environ["PROBREG_NATIVE_RCCL"] = "1"
         # non-rigid: the per-point block goes through the library's all-reduce as well
         s_n, t_n = synthetic.nonrigid_pair(3000, seed=6)
         os.environ["PROBREG_NATIVE_RCCL"] = "0"

@@ -81,9 +81,13 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
 
     # ---- from the identity: every pair is evaluated (dense regime) ----
     res = reg.registration(tgt, w=0.0, maxiter=k_dense, tol=-1.0)
-    # the iteration just compared ran on the matrix cores with the LEAN row pass (no residual sums; default factor 16):
-    # what is held to the oracle below is that kernel, by name
-    assert reg._plan.last_estep_engines() == (1, 1) and reg._plan.last_estep_lean() == 1
+    # what is held to the oracle below, by name: C1 - the FUSED single sweep on the matrix cores (no row pass: nothing reported
+    # for one); C2 - the matrix-core column pass and the LEAN matrix-core row pass (no residual sums)
+    if kind == "rigid":
+        assert reg._plan.last_estep_fused() == 1 and reg._plan.last_estep_engines() == (1, 0) and reg._plan.last_estep_lean() == 0
+        reg._plan.set_moments_only(1)   # the registration's own E-steps below as well: single sweeps in every regime
+    else:
+        assert reg._plan.last_estep_fused() == 0 and reg._plan.last_estep_engines() == (1, 1) and reg._plan.last_estep_lean() == 1
     s2_0 = co.squared_kernel_sum_closed_form(src, tgt)
     p, s2, q = _oracle_iterations(kind, src, tgt, ident, s2_0, k_dense)
     _check(kind, res, p, s2, q)
@@ -118,6 +122,8 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
     for _ in range(k_late):
         plan.estep(0.0)
         reg._device_mstep(plan)
+    if kind == "rigid":   # the late regime of C1 is the residual-form single sweep over the work queue
+        assert plan.last_estep_fused() == 1 and plan.last_estep_engines() == (0, 0)
     res = reg._result_from_params(plan.get_params())
     p, s2, q = _oracle_iterations(kind, src, tgt, _state_as_oracle_params(kind, warm), warm.sigma2, k_late)
     _check(kind, res, p, s2, q)

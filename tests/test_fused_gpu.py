@@ -127,10 +127,11 @@ def test_a_non_orthonormal_starting_matrix_keeps_the_two_sweeps():
 
 @pytest.mark.parametrize("forced", [False, True])
 def test_fused_sweep_along_a_100k_registration(forced):
-    """C1's clouds, every E-step allowed to fuse: at the iterations listed the GPU's state before the iteration goes to the C
-    oracle and the two M-step results are compared.  Default: the fused sweep runs while the matrix-core column pass would and
-    hands over once, for good.  Forced (both engines pinned to the matrix cores, prg_cpd_set_fused_factor(1e30)): sigma2 held
-    to 1e-5 beyond the default factor of 256."""
+    """C1's clouds, every E-step a single sweep: at the iterations listed the GPU's state before the iteration goes to the C
+    oracle and the two M-step results are compared.  Default: 50 iterations - the fused matrix-core sweep while the matrix-core
+    column pass would run, then, once and for good, the residual-form sweep of the vector pipe down to the noise
+    floor (amplification > 1e3: the residual form has no limit).  Forced (both engines pinned to the matrix cores,
+    prg_cpd_set_fused_factor(1e30)): the fused sweep's sigma2 held to 1e-5 beyond its default factor of 256."""
     from oracle import cpd_c, cpd_numpy as co
     from probreg_amd import cpd, synthetic
 
@@ -143,32 +144,38 @@ def test_fused_sweep_along_a_100k_registration(forced):
         plan.set_dense_engine(2)
         plan.set_fused_factor(1e30)
     mean_x2 = float(np.mean(np.sum((tgt - tgt.mean(0)) ** 2, axis=1)))
-    fused_flags, worst, top_amp = [], 0.0, 0.0
-    for it in range(18 if forced else 22):
+    single, engines, worst, top_amp, worst_v, top_amp_v = [], [], 0.0, 0.0, 0.0, 0.0
+    for it in range(18 if forced else 50):
         st = reg._result_from_params(plan.get_params())
         amp = mean_x2 / (3.0 * st.sigma2)
         plan.estep(0.0)
-        fused = plan.last_estep_fused()
-        fused_flags.append(fused)
+        single.append(plan.last_estep_fused())
+        engines.append(plan.last_estep_engine())
+        assert plan.last_estep_engines()[1] == 0 and plan.last_estep_lean() == 0   # no row pass ran: nothing reported for it
         reg._device_mstep(plan)
-        if it in ((0, 6, 11, 14, 16, 17) if forced else (0, 3, 6, 8, 11, 13, 15, 16, 18)):
+        if it in ((0, 11, 16, 17) if forced else (0, 6, 11, 14, 17, 22, 35, 49)):
             out = reg._result_from_params(plan.get_params())
             tr = st.transformation
             es = co.EstepResult(*cpd_c.expectation_step(co.transform("rigid", dict(rot=tr.rot, t=tr.t, scale=float(tr.scale)), src),
                                                         tgt, st.sigma2, 0.0))
             p, s2, q = co.mstep_rigid(src, tgt, es)
             err = abs(out.sigma2 - s2) / s2
-            assert err <= TOL_SIGMA2, (it, amp, fused, err)
+            assert err <= TOL_SIGMA2, (it, amp, engines[-1], err)
             assert np.max(np.abs(out.transformation.rot - p["rot"])) <= TOL_TF
-            if fused:
+            assert np.max(np.abs(out.transformation.t - p["t"])) <= TOL_TF
+            if engines[-1]:
                 worst, top_amp = max(worst, err), max(top_amp, amp)
+            else:
+                worst_v, top_amp_v = max(worst_v, err), max(top_amp_v, amp)
+    assert single == [1] * len(single), single
     if forced:
-        assert fused_flags == [1] * 18 and top_amp >= 500.0, (fused_flags, top_amp)
+        assert engines == [1] * 18 and top_amp >= 500.0, (engines, top_amp)
     else:
-        assert fused_flags[:12] == [1] * 12 and fused_flags[-1] == 0, fused_flags
-        assert fused_flags == sorted(fused_flags, reverse=True)   # hands over once, for good
-        assert top_amp >= 20.0
-    print("fused sweep (forced %d): worst sigma2 error %.2e up to amplification %.0f; fused iterations %s" % (forced, worst, top_amp, fused_flags))
+        assert engines[:12] == [1] * 12 and engines[-1] == 0, engines
+        assert engines == sorted(engines, reverse=True)   # hands over once, for good
+        assert top_amp >= 20.0 and top_amp_v >= 1000.0, (top_amp, top_amp_v)
+    print("single sweeps (forced %d): fused worst sigma2 error %.2e up to amplification %.0f; residual form %.2e up to %.0f; column engines %s"
+          % (forced, worst, top_amp, worst_v, top_amp_v, engines))
 
 
 def _free_port():

@@ -79,3 +79,83 @@ def test_column_side_sums_give_the_reference_moments(w, sigma2, scale):
     p, s2, _q = co.mstep_rigid(y, x, es)
     assert np.max(np.abs(r_new - p["rot"])) < 1e-9 and abs(s_new - p["scale"]) < 1e-9 and np.max(np.abs(t_new - p["t"])) < 1e-9
     assert abs(sigma2_new - s2) < 1e-8 * s2
+
+
+def _col_offset(kk, dmin):
+    """prg::col_offset (cpd_sweeps.h): the float just below -kk * dmin."""
+    p = np.float32(-(np.float32(kk) * np.float32(dmin)))
+    if not p > 0:
+        return np.float32(0.0)
+    return np.frombuffer(np.uint32(np.frombuffer(np.float32(p).tobytes(), np.uint32)[0] - 1).tobytes(), np.float32)[0]
+
+
+@pytest.mark.parametrize("w,sigma2,scale,nseg", [(0.0, 0.02, 1.0, 1), (0.15, 0.004, 1.05, 5), (0.1, 0.2, 0.95, 3)])
+def test_residual_column_sums_give_the_reference_moments(w, sigma2, scale, nseg):
+    """DESIGN.md 3.1f (k_colpass_cull<true> / k_colpass_queue<true> -> k_colfinal_resid -> k_fused_final): per column and per
+    segment of the source (min d^2, A, U, R) with A = sum K, U = sum K (x - z), R = sum K |x - z|^2 and K relative to the
+    offset of the SEGMENT's own minimum; merged online, turned into the column's moment terms with x_n as the origin, mapped back
+    to the source's frame - against the reference's row-side moments and the oracle's M-step."""
+    rng = np.random.default_rng(11)
+    m, n = 600, 800
+    y = rng.normal(size=(m, 3))
+    rot, t = _rot(-0.2, 0.4, 0.1), np.array([-0.2, 0.15, 0.3])
+    x = (scale * 0.99) * y[rng.integers(0, m, n)] @ _rot(-0.22, 0.37, 0.12).T + t + 0.04 * rng.normal(size=(n, 3))
+    z = scale * y @ rot.T + t
+    es = co.expectation_step(z, x, sigma2, w)
+    pt1, p1, px, n_p = es
+    ref = dict(S0=n_p, Sx=px.sum(0), Sy=y.T @ p1, Sxy=px.T @ y, trSyy=float(np.sum(p1 * np.sum(y * y, axis=1))),
+               Sxx=float(np.sum(pt1 * np.sum(x * x, axis=1))))
+    kk = -np.log2(np.e) / (2.0 * sigma2)
+    c = (2.0 * np.pi * sigma2) ** 1.5 * w / (1.0 - w) * m / n if w > 0 else 0.0
+    bounds = np.linspace(0, m, nseg + 1).astype(int)
+    mom = np.zeros(24)
+    for j in range(n):
+        gmin, goff = np.inf, np.inf
+        A, U, R = 0.0, np.zeros(3), 0.0
+        for s in range(nseg):
+            zs = z[bounds[s]:bounds[s + 1]]
+            d = x[j] - zs
+            d2 = np.sum(d * d, axis=1)
+            pm = d2.min()
+            off = float(_col_offset(kk, pm))
+            K = np.exp2(kk * d2 + off)
+            a, u, r = K.sum(), K @ d, K @ d2
+            if pm < gmin:                                      # k_colfinal_resid's merge
+                noff = float(_col_offset(kk, pm))
+                f = 0.0 if np.isinf(goff) else np.exp2(noff - goff)
+                A, U, R = A * f, U * f, R * f
+                gmin, goff = pm, noff
+            f = np.exp2(goff - off)
+            A, U, R = A + a * f, U + u * f, R + r * f
+        den = A * np.exp2(-goff)
+        pd = den / (den + c)
+        qn = pd / A
+        pz = pd * x[j] - qn * U
+        mom[0] += pd
+        mom[1:4] += pd * x[j]
+        mom[4:7] += pz
+        mom[7:16] += np.outer(x[j], pz).ravel()
+        mom[16] += pd * (x[j] @ x[j]) + qn * (R - 2.0 * x[j] @ U)
+        mom[22] += pd * (x[j] @ x[j])
+    S0, Sx, Sz, Sxz = mom[0], mom[1:4], mom[4:7], mom[7:16].reshape(3, 3)
+    Sy = rot.T @ (Sz - S0 * t) / scale
+    Sxy = (Sxz - np.outer(Sx, t)) @ rot / scale
+    trSyy = (mom[16] - 2.0 * t @ Sz + S0 * (t @ t)) / scale ** 2
+    assert abs(S0 - ref["S0"]) < 1e-11 * ref["S0"]
+    assert np.max(np.abs(Sx - ref["Sx"])) < 1e-10 * ref["S0"]
+    assert np.max(np.abs(Sy - ref["Sy"])) < 1e-10 * ref["S0"]
+    assert np.max(np.abs(Sxy - ref["Sxy"])) < 1e-10 * ref["S0"]
+    assert abs(trSyy - ref["trSyy"]) < 1e-10 * ref["S0"]
+    assert abs(mom[22] - ref["Sxx"]) < 1e-10 * ref["S0"]
+    mu_x, mu_y = Sx / S0, Sy / S0
+    a = Sxy - np.outer(Sx, mu_y)
+    u, _, vh = np.linalg.svd(a)
+    cdiag = np.ones(3)
+    cdiag[-1] = np.linalg.det(u @ vh)
+    r_new = (u * cdiag) @ vh
+    tr_atr = np.trace(a.T @ r_new)
+    s_new = tr_atr / (trSyy - S0 * (mu_y @ mu_y))
+    sigma2_new = (mom[22] - S0 * (mu_x @ mu_x) - s_new * tr_atr) / (S0 * 3)
+    p, s2, _q = co.mstep_rigid(y, x, es)
+    assert np.max(np.abs(r_new - p["rot"])) < 1e-9 and abs(s_new - p["scale"]) < 1e-9
+    assert abs(sigma2_new - s2) < 1e-8 * s2

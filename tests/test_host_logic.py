@@ -151,3 +151,38 @@ def test_engine_switch_bounds_follow_the_cost_model():
         assert r < n_local
     with pytest.raises(Exception):
         engine.engine_bounds(0, 100)
+
+
+def test_native_comm_decision_is_not_cached_without_a_process_group(monkeypatch):
+    """A single-process registration BEFORE init_process_group must leave nothing behind: a cached "no communicator" would
+    keep this rank out of the collective set-up its peers enter once the group exists (mismatched collectives)."""
+    from probreg_amd import dist
+
+    monkeypatch.delenv("PROBREG_NATIVE_RCCL", raising=False)
+    dist._native.clear()
+    assert dist.native_comm(0) is None
+    assert dist._native == {}
+    # ... and a plan that held a communicator is detached when the communicator goes away
+    class _Plan(object):
+        _h = 1
+
+        def set_comm(self, comm):
+            self._comm = comm
+
+    comm = object.__new__(dist.NativeComm)
+    comm._h, comm._plans = None, __import__("weakref").WeakSet()
+    plan = _Plan()
+    plan._comm = comm
+    comm._attached(plan)
+
+    class _Lib(object):
+        class lib(object):
+            destroyed = []
+
+            @staticmethod
+            def prg_comm_destroy(h):
+                _Lib.lib.destroyed.append(h)
+
+    comm._lib, comm._h = _Lib, 7
+    comm.close()
+    assert plan._comm is None and _Lib.lib.destroyed == [7] and comm._h is None

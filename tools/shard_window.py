@@ -9,7 +9,9 @@ probreg_amd.dist.spatial_shard) is then put in each of those states and timed ba
                 the collective are in the measurement, the peers' latency is not), then k_mstep - with the state restored by
                 a 256-byte device-to-device copy on the same stream, whose cost is measured on its own and subtracted
 
-    python tools/shard_window.py [n] [K]    -> tables per world size and the sums the 8-GPU projection of DESIGN.md uses
+    python tools/shard_window.py [n] [K] [rigid|affine]   -> tables per world size and the sums the 8-GPU projection of DESIGN.md uses
+                                                             (C1: 100000 20 rigid; C2, the configuration BASELINE.md quotes the
+                                                             8-GPU target on: 200000 20 affine)
 """
 import ctypes
 import os
@@ -25,19 +27,25 @@ from probreg_amd import _lib, cpd, dist, engine, synthetic  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-REPS = 30
-src, tgt, _ = synthetic.rigid_pair(n, seed=0)
-reg = cpd.RigidCPD(src)
+KIND = sys.argv[3] if len(sys.argv) > 3 else "rigid"
+REPS = 30 if n <= 100000 else 10
+if KIND == "rigid":
+    src, tgt, _ = synthetic.rigid_pair(n, seed=0)
+    reg, KIND_ID = cpd.RigidCPD(src), _lib.PRG_TF_RIGID
+else:
+    src, tgt, _ = synthetic.affine_pair(n, seed=0)
+    reg, KIND_ID = cpd.AffineCPD(src), _lib.PRG_TF_AFFINE
 reg._initialize(tgt)
 plan = reg._plan
-plan.set_moments_only(1)
+if KIND == "rigid":
+    plan.set_moments_only(1)
 comm = plan._comm
 assert comm is not None, "library-side RCCL communicator unavailable"
 states = []
 for it in range(K):
     states.append(plan.get_params())
     plan.estep(0.0)
-    plan.mstep(_lib.PRG_TF_RIGID, True)
+    plan.mstep(KIND_ID, True)
 cy, cx = reg._cy, reg._cx
 
 
@@ -69,7 +77,8 @@ for world in (1, 2, 4, 8):
     p2.set_source(src - cy)
     p2.set_target(tgt[rows] - cx, n_global=n)
     p2.init_sums()  # (as registration does: the local target's sums decide where the lean row pass may run)
-    p2.set_moments_only(1)  # (as the registration's own loop: rigid iterations may run the fused single sweep)
+    if KIND == "rigid":
+        p2.set_moments_only(1)  # (as the registration's own loop: rigid iterations run single sweeps)
     view = params_view(p2)
     es, its, cps = [], [], []
     for it, st in enumerate(states):
@@ -85,7 +94,7 @@ for world in (1, 2, 4, 8):
         def iteration():
             view.copy_(saved)
             p2.estep(0.0)                       # ... + ncclAllReduce(moments) on the plan's stream
-            p2.mstep(_lib.PRG_TF_RIGID, True)
+            p2.mstep(KIND_ID, True)
 
         its.append(timed(iteration))
         cps.append(timed(lambda: view.copy_(saved)))
@@ -93,7 +102,7 @@ for world in (1, 2, 4, 8):
     p2.set_comm(None)
     p2.close()
 
-print("# rank 0 of N, RigidCPD N=M=%d, EM iterations 0..%d, back to back on one MI355X (ms)" % (n, K - 1))
+print("# rank 0 of N, %s N=M=%d, EM iterations 0..%d, back to back on one MI355X (ms)" % ("RigidCPD" if KIND == "rigid" else "AffineCPD", n, K - 1))
 print("# E-step alone | whole iteration = E-step + ncclAllReduce(32 fp64, 1-rank communicator, plan's stream) + M-step, minus the state-restoring copy")
 print("%3s %9s %9s %9s %9s | %9s %9s %9s %9s" % ("it", "1 rank", "2 ranks", "4 ranks", "8 ranks", "1 rank", "2 ranks", "4 ranks", "8 ranks"))
 full = {w: [a - c for a, c in zip(iter_ms[w], copy_ms[w])] for w in iter_ms}
