@@ -133,7 +133,7 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
     return baseline, parity
 
 
-def reference_numpy_baseline(n_full, sizes=(2000, 5000, 10000), iters=2):
+def reference_numpy_baseline(n_full, sizes=(10000, 20000, 30000), iters=2):
     """probreg's own NumPy formulation of the EM iteration (cpd.py:71-88 as ONE dense M x N float64 matrix: scipy cdist,
     exp, divide, sums, dot - oracle/cpd_numpy.expectation_step_unchunked, held to the reference's outputs at 1e-12 by
     tests/test_oracle_golden.py - plus the M-step of cpd.py:160-192) timed on THIS host at three sizes the matrix fits,
@@ -142,6 +142,15 @@ def reference_numpy_baseline(n_full, sizes=(2000, 5000, 10000), iters=2):
     from probreg_amd import synthetic
 
     per_iter = []
+    # [r5] sizes at which the M x N passes dominate (at 2k / 5k the per-call overheads put the fit's residuals at +140 % / +34 %):
+    # 10k / 20k / 30k - 7.2 GB per float64 matrix at 30k, a handful of them alive at once; a host without the room keeps to what fits
+    try:
+        import psutil
+
+        free_gb = psutil.virtual_memory().available / 2.0 ** 30
+        sizes = tuple(ns for ns in sizes if 5.0 * 8.0 * ns * ns / 2.0 ** 30 < 0.6 * free_gb) or (2000, 5000, 10000)
+    except Exception:
+        pass
     src, tgt, _ = synthetic.rigid_pair(500, seed=0)
     co.expectation_step_unchunked(src, tgt, 1.0, 0.0)  # imports, thread pools
     for ns in sizes:
@@ -336,7 +345,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
         with open(pairs_log, "w") as f:
             f.write("# %s: E-step sweeps of the timed window, HIP events on the plan's stream (prg_cpd_estep_timed) and the device's "
                     "counters of evaluated pairs (prg_cpd_pair_counts)\n" % desc)
-            f.write("# row = 2: the FUSED single sweep of a rigid iteration (one sweep per E-step, %g flop per pair, reported in the row columns; the column slot is empty)\n" % FLOP_FUSED)
+            f.write("# row = 2: a SINGLE-sweep E-step of a rigid iteration (col 1: the fused matrix-core sweep, col 0: the residual-form vector-pipe sweep; %g flop per pair, reported in the row columns; the column slot is empty)\n" % FLOP_FUSED)
             f.write("# engine 1 = matrix cores (bf16x3 exponent, csrc/cpd_sweeps_mfma.hip), 0 = culled vector-pipe sweeps; "
                     "frac = pairs x flop/pair / ms / %.1f TFLOP/s (flop/pair: row %g - %g where the matrix-core row pass ran "
                     "without its residual sums, column `fr` - column %g)\n"
@@ -381,9 +390,10 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     out["late_it_s"] = 1.0 / t_late
     out["roofline"] = {
         "bound": "valu",
-        "kernel": "the E-step's dominant pair sweep: the fused single sweep k_colpass_mfma<FUSED> (den, P1, PX sums from the column "
-                  "side, one exponential per pair and iteration) while sigma2 is large, the row pass (k_rowpass_mfma / "
-                  "k_rowpass_queue) afterwards",
+        "kernel": "the E-step's dominant pair sweep: rigid - ONE sweep per iteration in every regime (the fused matrix-core sweep "
+                  "k_colpass_mfma<FUSED> while sigma2 is large, the residual-form vector-pipe sweep k_colpass_queue<RESID> / "
+                  "k_colpass_cull<RESID> afterwards; den, P1, PX sums from the column side, one exponential per pair and iteration); "
+                  "affine - the row pass (k_rowpass_mfma / k_rowpass_queue) of its two sweeps",
         "achieved": row_tf,
         "peak": VALU_F32_PEAK_TFLOPS,
         "unit": "TFLOP/s",
@@ -405,7 +415,8 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
                               "row_pass_iterations": sum(1 for r in per_iteration if r[3]) / float(steps),
                               "row_pass_pairs": sum(r[5] for r in per_iteration if r[3]) / max(pairs_row, 1.0),
                               "row_pass_lean_iterations": sum(1 for r in per_iteration if r[9] == FLOP_ROW_LEAN) / float(steps),
-                              "fused_single_sweep_iterations": sum(1 for r in per_iteration if r[3] == 2) / float(steps)},
+                              "fused_single_sweep_iterations": sum(1 for r in per_iteration if r[3] == 2 and r[2]) / float(steps),
+                              "residual_form_single_sweep_iterations": sum(1 for r in per_iteration if r[3] == 2 and not r[2]) / float(steps)},
         "avg_launch_ms": acc["rowpass"],
         "pairs_evaluated_per_launch": pairs_row / steps,
         "pairs_total_per_launch": float(m_pts) * n_loc,

@@ -242,11 +242,19 @@ def transform(kind, params, source, g=None):
 
 def registration(kind, source, target, w=0.0, maxiter=50, tol=0.001, update_scale=True,
                  tf_init_params=None, beta=2.0, lmd=2.0, chunk=1024, closed_form_init=False,
-                 history=None, alpha=1e-8, idx_source=None, idx_target=None):
+                 history=None, alpha=1e-8, idx_source=None, idx_target=None, c_estep=False):
     """EM driver, cpd.py:106-120 with the per-type ``_initialize`` (:145-153, :209-217, :277-282).
 
     Returns (params, sigma2, q, n_iter).  ``history`` (a list) receives (sigma2, q) per iteration.
+    ``c_estep``: the E-step through oracle/cpd_estep_c.c (C / OpenMP fp64, the same arithmetic, held to this module's
+    ``expectation_step`` by tests/test_oracle_c.py) instead of the chunked numpy one - an order of magnitude faster.
     """
+    estep = expectation_step
+    if c_estep:
+        from . import cpd_c
+
+        def estep(ts, target, sigma2, w, chunk=None):
+            return EstepResult(*cpd_c.expectation_step(ts, target, sigma2, w))
     source = np.asarray(source, dtype=np.float64)
     target = np.asarray(target, dtype=np.float64)
     dim = source.shape[1]
@@ -276,7 +284,7 @@ def registration(kind, source, target, w=0.0, maxiter=50, tol=0.001, update_scal
     n_iter = 0
     for _ in range(maxiter):
         ts = transform(kind, params, source, g)
-        es = expectation_step(ts, target, sigma2, w, chunk=chunk)
+        es = estep(ts, target, sigma2, w, chunk=chunk)
         if kind == "rigid":
             params, sigma2_new, q_new = mstep_rigid(source, target, es, update_scale)
         elif kind == "affine":

@@ -1681,6 +1681,7 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
     h->pred_col = 1;
     h->pred_fine = 0;
     h->pred_fused = 0;
+    h->mfma_grid_fine = false;
     h->eng_reset = true;
     // the fused single sweep maps its column-side sums back through s R: R has to be a rotation (the M-step's own results are)
     h->init_rot_orthonormal = !init_params_host || is_rotation(init_params_host);
@@ -1690,6 +1691,24 @@ int prg_cpd_init_params(prg_cpd* h, const double* init_params_host) {
 // Below how many evaluated pairs per owned point does a matrix-core sweep lose to the vector-pipe sweep?  The two-line cost
 // model of DESIGN.md 3.1c (see estep_impl): segment chain of a workgroup + late start on grids deeper than the chip, against
 // evenly shared blocks.  Host arithmetic only.
+// Segments of a matrix-core launch once its chunk / tile masks skip work ([r5]).  The default grid fills the
+// chip's 768 workgroup slots about once when there are few owned blocks (a target shard's column pass: 25 blocks x 30 segments
+// of 14 chunks at 1/8 of C1) - fine while every chunk is needed, but a culled sweep then lasts as long as its busiest
+// workgroup, which still needs its whole segment: rank 0 of 8 stayed at 0.31 ms from EM iteration 6 to 10 while one GPU went
+// 1.78 -> 0.87 ms (profiles/r4_shard_window.log).  With >= 3 rounds of shorter segments the slots even the load out.
+// 0: the default grid is already that deep (C1 on one GPU: 4.85 rounds), or PRG_MFMA_SEG pins the count.
+static int mfma_fine_segments(int64_t owned, int64_t streamed, int max_planes) {
+    static const int seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;
+    static const bool off = getenv("PRG_MFMA_FINE_GRID") && atoi(getenv("PRG_MFMA_FINE_GRID")) == 0;
+    if (seg || off) return seg;
+    const int64_t blocks = prg::ceil_div(owned, prg::kMfmaWgPoints), chunks = prg::ceil_div(streamed, 256);
+    int64_t want = prg::ceil_div(3 * 768 + 256, blocks);
+    want = std::min<int64_t>(std::min<int64_t>(want, chunks / 4), max_planes);
+    return want > prg::mfma_planes(owned, streamed, 0) ? (int)want : 0;
+}
+
+// (the model and its constants describe the DEFAULT grid, which is what the crossovers were measured on; the finer grid of a
+// culling sweep only makes the matrix cores faster near the crossover - leaving at this bound is then slightly early, never late)
 static double engine_leave_below(int64_t owned, int64_t streamed, double tau, double delta, double c_v) {
     static const int seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;
     const double cps = (double)prg::mfma_chunks_per_seg(owned, streamed, seg);
@@ -1784,16 +1803,20 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // the column-side sums back through
     const bool allow_fused = mfma_possible && h->moments_only && !h->nonrigid && !h->bcpd && h->init_rot_orthonormal;
     static const int mfma_seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;  // 0: fill the chip once
-    // (buffers are sized for whichever way a matrix-core launch is cut: grid of segments or stream mode)
-    const int PAm = mfma_possible ? std::max(prg::mfma_planes(h->N, h->M, mfma_seg), prg::mfma_stream_planes(h->N, h->M)) : 0,
-              PBm = mfma_possible ? std::max(prg::mfma_planes(h->M, h->N, mfma_seg), prg::mfma_stream_planes(h->M, h->N)) : 0;
+    // ... and, once the previous sweep skipped a tenth of its pairs, in >= 3 rounds of shorter segments (mfma_fine_segments)
+    const int seg_col_fine = mfma_possible ? mfma_fine_segments(h->N, h->M, 256) : 0, seg_row_fine = mfma_possible ? mfma_fine_segments(h->M, h->N, 64) : 0;
+    // (buffers are sized for whichever way a matrix-core launch is cut: grid of segments - default or fine - or stream mode)
+    const int PAm = mfma_possible ? std::max(std::max(prg::mfma_planes(h->N, h->M, mfma_seg), prg::mfma_planes(h->N, h->M, seg_col_fine)),
+                                             prg::mfma_stream_planes(h->N, h->M)) : 0,
+              PBm = mfma_possible ? std::max(std::max(prg::mfma_planes(h->M, h->N, mfma_seg), prg::mfma_planes(h->M, h->N, seg_row_fine)),
+                                             prg::mfma_stream_planes(h->M, h->N)) : 0;
     // sparse regime: sweeps over a device-built work queue (cpd_sweeps_queue.hip) - partial results per unit, not per plane
     // ... when both clouds are large: the queue costs a build pass and leaves more partial results than the grid of culled
     // waves, which only pays off while a sweep is long (measured at C1: ahead with the target on 1 or 2 ranks, behind on 4 and 8)
     const bool use_queue = use_cull && (h->sparse_engine == 2 || (h->sparse_engine == 1 && h->M >= 32768 && h->N >= 32768));
     const int64_t qcol_elems = use_queue ? prg::queue_max_units(h->N, h->M) * 128 : 0,
                   qrow_elems = use_queue ? prg::queue_max_units(h->M, h->N) * 640 : 0;
-    const int64_t fused_elems = allow_fused ? (int64_t)3 * prg::mfma_planes(h->N, h->M, mfma_seg) * h->Ncap : 0;  // 6 floats per (plane, column)
+    const int64_t fused_elems = allow_fused ? (int64_t)3 * std::max(prg::mfma_planes(h->N, h->M, mfma_seg), prg::mfma_planes(h->N, h->M, seg_col_fine)) * h->Ncap : 0;  // 6 floats per (plane, column)
     // the residual-form single sweep on the vector pipe: the same callers as the fused sweep, any sigma2, no
     // matrix cores needed - 6 floats per (plane, column) + a touched flag per (128-column block, plane), or 6 x 128 floats per unit
     const bool allow_resid = use_cull && h->resid_sweep && h->moments_only && !h->nonrigid && !h->bcpd && !h->srcw && h->init_rot_orthonormal;
@@ -1875,8 +1898,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // (measured at C1, profiles/r4_fused_lower_bound.log: with the dense regime's lower end at 1.0 / 0.7 / 0.5 / 0.35 / 0.25 of the
         // column pass' own bound the window runs at 792 / 815 / 840 / 831 / 830 it/s (+-2 %): half of that bound is where the
         // gain levels off; with it, and the fused factor of 256, C1 runs fused through EM iteration 14)
-        static const double fused_scale = getenv("PRG_FUSED_RCOL_SCALE") ? atof(getenv("PRG_FUSED_RCOL_SCALE")) : 0.5;
-        ea.r_col_bound_fused = ea.r_col_bound * fused_scale;
+        // [r5] what the fused sweep competes with below the dense regime is ONE vector-pipe sweep too (the residual-form column pass,
+        // DESIGN.md 3.1f), whose per-pair cost is above the plain column pass' the bound was fitted on - as the fused sweep's is
+        // above the matrix-core column pass': same command, lower end at 0.5 / 0.75 / 1.0 / 1.4 of the column pass' bound:
+        // 828 / 841 / 855 / 859 it/s (profiles/r5_fused_lower_bound.log); 1.4 hands over at EM iteration 12 of C1 (0.64 -> 0.57 ms)
+        static const double fused_scale = getenv("PRG_FUSED_RCOL_SCALE") ? atof(getenv("PRG_FUSED_RCOL_SCALE")) : -1.0;
+        ea.r_col_bound_fused = ea.r_col_bound * (fused_scale > 0.0 ? fused_scale : allow_resid ? 1.4 : 0.5);
         ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, true);
         ea.r_row_bound_full = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, false);  // (the device knows which applies)
         ea.streamed_col = (double)h->M;
@@ -1918,10 +1945,11 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         prg::launch_chunk_meta_bbox(h, &ea);
         if (ev) PRG_HIP(hipEventRecord(ev[1], h->stream));
         const bool pred = h->pred_col != 0, pred_fused = allow_fused && h->pred_fused != 0;
+        int seg_col = h->mfma_grid_fine && seg_col_fine ? seg_col_fine : mfma_seg;  // (from the count the previous decision saw)
         if (pred_fused)  // (the single sweep of a rigid iteration, if the previous E-step ran it)
-            prg::launch_fused_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev);
+            prg::launch_fused_mfma(h, seg_col, !h->have_colmin, false, h->eng_dev);
         else if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
-            prg::launch_colpass_mfma(h, mfma_seg, !h->have_colmin, false, h->eng_dev, h->mfma_stream && h->pred_fine == 0);
+            prg::launch_colpass_mfma(h, seg_col, !h->have_colmin, false, h->eng_dev, h->mfma_stream && h->pred_fine == 0 && !h->mfma_grid_fine);
         else if (!use_queue)
             prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev, allow_resid);
         // (pred == vector pipe with the work queue: nothing goes out ahead - inside the dense regime that engine only runs
@@ -1942,6 +1970,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         row_lean = row_mfma && mb->lean != 0;
         fused = allow_fused && mb->fused != 0;
         if (!mb->dense) h->mfma_off = true;
+        // the previous matrix-core column pass skipped a tenth of its pairs: its masks are at work, cut the grid finer from here on
+        h->mfma_grid_fine = !first_mfma && (double)mb->r_col < 0.9 * (double)h->M;
         static const bool debug_engine = getenv("PRG_DEBUG_ENGINE") != nullptr;
         if (debug_engine)
             fprintf(stderr, "[engine] sigma2 %.4e nk*ext2 %.1f pairs per owned point col %.0f (bound %.0f) row %.0f (bound %.0f) motion %.3e cmax %.3e nk*width %.1f "
@@ -1961,11 +1991,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         h->pred_col = use_mfma ? 1 : 0;
         h->pred_fine = fine_cull ? 1 : 0;
         h->pred_fused = fused ? 1 : 0;
+        seg_col = h->mfma_grid_fine && seg_col_fine ? seg_col_fine : mfma_seg;
         if (!col_launched && fused) {  // (the guarded launch has returned at once; rare: the engine changes a few times per registration)
-            prg::launch_fused_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev);
+            prg::launch_fused_mfma(h, seg_col, first_mfma, fine_cull, h->eng_dev);
             col_launched = true;
         } else if (!col_launched && use_mfma) {
-            prg::launch_colpass_mfma(h, mfma_seg, first_mfma, fine_cull, h->eng_dev, h->mfma_stream && !fine_cull);
+            prg::launch_colpass_mfma(h, seg_col, first_mfma, fine_cull, h->eng_dev, h->mfma_stream && !fine_cull && !h->mfma_grid_fine);
             col_launched = true;
         }
     }
@@ -2054,7 +2085,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                       queue_view(h->qcol, col_queue), row_lean ? xpart : nullptr);
     if (ev) PRG_HIP(hipEventRecord(ev[3], h->stream));
     if (row_mfma)
-        prg::launch_rowpass_mfma(h, mfma_seg, fine_cull, row_lean, h->mfma_stream && !fine_cull);
+        prg::launch_rowpass_mfma(h, h->mfma_grid_fine && seg_row_fine ? seg_row_fine : mfma_seg, fine_cull, row_lean, h->mfma_stream && !fine_cull && !h->mfma_grid_fine);
     else if (row_queue)
         PRG_TRY(prg::launch_rowpass_queue(h, h->qrow_live ? 0 : h->q_first_row));
     else if (use_cull)

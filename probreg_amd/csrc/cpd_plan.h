@@ -144,6 +144,7 @@ struct prg_cpd {
     EngineDecision* eng_host_dev = nullptr;  // ... as the device addresses it
     int pred_col = 1;           // the column-pass engine the host launches ahead of the decision (= the previous decision)
     int pred_fine = 0;          // ... and whether that decision had the per-wave tile masks on (0: dense regime -> stream mode)
+    bool mfma_grid_fine = false; // the previous matrix-core column pass skipped >= 10 % of its pairs: launches are cut into >= 3 rounds of shorter segments
     bool mfma_stream = true;    // dense-regime launches of the matrix-core sweeps are cut in stream mode (prg_cpd_set_stream_mode)
     int mfma_col_planes = 0, mfma_row_planes = 0;  // partial planes the last matrix-core column / row pass wrote (grid or stream mode)
     bool last_estep_row_lean = false;  // ... matrix-core row pass without its residual sums

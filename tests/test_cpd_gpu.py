@@ -158,11 +158,11 @@ def test_rigid_and_affine_vs_oracle_medium(n, m, k, w):
     from probreg_amd import cpd, synthetic
 
     src, tgt, _ = synthetic.rigid_pair(n, m=m, seed=11)
-    p, s2, q, _ = co.registration("rigid", src, tgt, w=w, maxiter=k, tol=-1.0, closed_form_init=True)
+    p, s2, q, _ = co.registration("rigid", src, tgt, w=w, maxiter=k, tol=-1.0, closed_form_init=True, c_estep=n * m > 10 ** 7)
     res = cpd.registration_cpd(src, tgt, "rigid", w=w, maxiter=k, tol=-1.0)
     _check_rigid(res, p["rot"], p["t"], p["scale"], s2)
     src, tgt, _ = synthetic.affine_pair(n, m=m, seed=12)
-    p, s2, q, _ = co.registration("affine", src, tgt, w=w, maxiter=k, tol=-1.0, closed_form_init=True)
+    p, s2, q, _ = co.registration("affine", src, tgt, w=w, maxiter=k, tol=-1.0, closed_form_init=True, c_estep=n * m > 10 ** 7)
     res = cpd.registration_cpd(src, tgt, "affine", w=w, maxiter=k, tol=-1.0)
     _check_affine(res, p["b"], p["t"], s2)
 

@@ -60,7 +60,7 @@ def test_deep_late_regime_matches_oracle():
     src, tgt, _ = synthetic.rigid_pair(3500, m=3000, seed=91)
     for kind, w in (("rigid", 0.0), ("affine", 0.1)):
         res = cpd.registration_cpd(src, tgt, kind, w=w, maxiter=40, tol=-1.0)
-        p, s2, q, _ = co.registration(kind, src, tgt, w=w, maxiter=40, tol=-1.0, closed_form_init=True)
+        p, s2, q, _ = co.registration(kind, src, tgt, w=w, maxiter=40, tol=-1.0, closed_form_init=True, c_estep=True)
         _check(kind, res, p, s2)
     assert res.sigma2 < 1e-3
 

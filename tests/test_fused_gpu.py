@@ -70,7 +70,7 @@ def test_fused_sweep_moments_equal_the_two_sweep_engine(n, m, w):
         plan.get_estep()
 
 
-@pytest.mark.parametrize("case", ["c1_100k", "scale_fixed_w", "two_d", "init_rot"])
+@pytest.mark.parametrize("case", ["c1_50k", "scale_fixed_w", "two_d", "init_rot"])
 def test_registration_through_the_fused_sweep_matches_the_oracle(case):
     """`registration` with tol < 0 runs prg_cpd_iterate: rigid iterations take the fused sweep while they may.  Against the
     reference's loop (C E-step + numpy M-step, fp64)."""
@@ -78,8 +78,8 @@ def test_registration_through_the_fused_sweep_matches_the_oracle(case):
     from probreg_amd import cpd, synthetic
 
     kw, init = dict(), None
-    if case == "c1_100k":
-        src, tgt, _ = synthetic.rigid_pair(100000, seed=0)
+    if case == "c1_50k":   # (C1 itself, 100k from the identity: tests/test_fullsize_gpu.py)
+        src, tgt, _ = synthetic.rigid_pair(50000, seed=0)
         k, w = 4, 0.0
     elif case == "scale_fixed_w":
         src, tgt, _ = synthetic.rigid_pair(30000, m=26000, seed=7)
@@ -153,7 +153,7 @@ def test_fused_sweep_along_a_100k_registration(forced):
         engines.append(plan.last_estep_engine())
         assert plan.last_estep_engines()[1] == 0 and plan.last_estep_lean() == 0   # no row pass ran: nothing reported for it
         reg._device_mstep(plan)
-        if it in ((0, 11, 16, 17) if forced else (0, 6, 11, 14, 17, 22, 35, 49)):
+        if it in ((0, 11, 16, 17) if forced else (0, 11, 14, 19, 30, 49)):
             out = reg._result_from_params(plan.get_params())
             tr = st.transformation
             es = co.EstepResult(*cpd_c.expectation_step(co.transform("rigid", dict(rot=tr.rot, t=tr.t, scale=float(tr.scale)), src),

@@ -27,11 +27,12 @@ def _oracle_step(kind, src, tgt, st, w):
 
 @pytest.mark.parametrize("w", [0.0, 0.1])
 def test_forced_lean_pass_along_a_100k_rigid_registration(w):
-    """C1's clouds; both sweeps pinned to the matrix cores, the row pass lean in EVERY iteration; at the iterations listed
-    the GPU's state before the iteration goes to the C oracle and the two M-step results are compared."""
+    """C1's clouds (w = 0; half of C1's points with w = 0.1 - the oracle's cost goes with n^2); both sweeps pinned to the matrix
+    cores, the row pass lean in EVERY iteration; at the iterations listed the GPU's state before the iteration goes to the C
+    oracle and the two M-step results are compared."""
     from probreg_amd import cpd, synthetic
 
-    n = 100000
+    n = 100000 if w == 0.0 else 50000
     src, tgt, _ = synthetic.rigid_pair(n, seed=0)
     reg = cpd.RigidCPD(src)
     reg._initialize(tgt)
@@ -47,7 +48,7 @@ def test_forced_lean_pass_along_a_100k_rigid_registration(w):
         assert plan.last_estep_lean() == 1, it
         assert plan.last_estep_engines() == (1, 1)
         reg._device_mstep(plan)
-        if it in (0, 4, 8, 10, 12, 13):
+        if it in ((0, 8, 12, 13) if w == 0.0 else (0, 4, 8, 10, 12, 13)):
             out = reg._result_from_params(plan.get_params())
             p, s2, q = _oracle_step("rigid", src, tgt, st, w)
             err = abs(out.sigma2 - s2) / s2
@@ -55,7 +56,7 @@ def test_forced_lean_pass_along_a_100k_rigid_registration(w):
             assert np.max(np.abs(out.transformation.rot - p["rot"])) <= TOL_TF
             assert abs(out.q - q) <= 1e-4 * abs(q)
             worst, top_amp, checked = max(worst, err), max(top_amp, amp), checked + 1
-    assert checked == 6 and top_amp >= 64.0, (checked, top_amp)  # held up to an amplification of >= 64 (default limit: 16)
+    assert checked == (4 if w == 0.0 else 6) and top_amp >= 64.0, (checked, top_amp)  # held up to an amplification of >= 64 (default limit: 16)
     print("forced lean pass, w = %g: worst sigma2 error %.2e up to amplification %.0f" % (w, worst, top_amp))
 
 
@@ -74,12 +75,12 @@ def test_default_lean_window_and_switch_off():
         plan.set_lean_factor(factor)
         flags, rows = [], []
         for it in range(15):
-            st = reg._result_from_params(plan.get_params()) if it == 6 else None
+            st = reg._result_from_params(plan.get_params()) if it == 6 and factor != 16.0 else None
             plan.estep(0.0)
             flags.append(plan.last_estep_lean())
             rows.append(plan.last_estep_engines()[1])
             reg._device_mstep(plan)
-            if it == 6:
+            if st is not None:
                 _, s2, _ = _oracle_step("rigid", src, tgt, st, 0.0)
                 out = reg._result_from_params(plan.get_params())
                 assert abs(out.sigma2 - s2) <= TOL_SIGMA2 * s2

@@ -54,7 +54,7 @@ def test_late_regime_against_the_oracle_through_the_queue(monkeypatch):
     monkeypatch.setenv("PRG_SPARSE_ENGINE", "2")
     src, tgt, _ = synthetic.rigid_pair(6000, m=5000, seed=17)
     res = cpd.registration_cpd(src, tgt, "rigid", w=0.05, maxiter=35, tol=-1.0)
-    p, s2, q, _ = co.registration("rigid", src, tgt, w=0.05, maxiter=35, tol=-1.0, closed_form_init=True)
+    p, s2, q, _ = co.registration("rigid", src, tgt, w=0.05, maxiter=35, tol=-1.0, closed_form_init=True, c_estep=True)
     assert rel_err(res.transformation.rot, p["rot"]) < 1e-4 and np.max(np.abs(res.transformation.t - p["t"])) < 1e-4
     assert abs(res.sigma2 - s2) <= 1e-5 * s2
 

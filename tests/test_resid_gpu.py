@@ -86,7 +86,7 @@ def test_resid_sweep_moments_equal_the_two_sweep_engine(n, m, w, sparse, warm):
     plan.get_estep()
 
 
-@pytest.mark.parametrize("case", ["w01_30k", "two_d", "scale_fixed", "queue_40k", "vector_only"])
+@pytest.mark.parametrize("case", ["w01_30k", "two_d", "scale_fixed", "queue_30k", "vector_only"])
 def test_registration_through_the_single_sweeps_matches_the_oracle(case):
     """`registration` with tol < 0 runs prg_cpd_iterate: every rigid E-step is ONE sweep - the fused matrix-core sweep while
     sigma2 is large, the residual-form vector sweep afterwards - for 30+ iterations, into the sparse regime.  Against the
@@ -105,9 +105,9 @@ def test_registration_through_the_single_sweeps_matches_the_oracle(case):
     elif case == "scale_fixed":
         src, tgt, _ = synthetic.rigid_pair(25000, seed=47)
         k, w, kw = 30, 0.2, dict(update_scale=False)
-    elif case == "queue_40k":
-        src, tgt, _ = synthetic.rigid_pair(40000, seed=49)
-        k, w = 36, 0.0
+    elif case == "queue_30k":
+        src, tgt, _ = synthetic.rigid_pair(30000, seed=49)
+        k, w = 32, 0.0
         setup = lambda plan: plan.set_sparse_engine(2)   # noqa: E731
     else:
         src, tgt, _ = synthetic.rigid_pair(12000, m=15000, seed=51)
@@ -118,7 +118,9 @@ def test_registration_through_the_single_sweeps_matches_the_oracle(case):
         reg._initialize(tgt)
         setup(reg._plan)   # (engine modes are plan state: they survive the second upload of `registration`)
     res = reg.registration(tgt, w=w, maxiter=k, tol=-1.0)
-    assert reg._plan.last_estep_fused() == 1 and reg._plan.last_estep_engines() == (0, 0)
+    assert reg._plan.last_estep_fused() == 1 and reg._plan.last_estep_engines()[1] == 0
+    if case != "scale_fixed":   # (with the scale pinned at 1 sigma2 settles above the noise level: that run may end on the matrix cores)
+        assert reg._plan.last_estep_engine() == 0
     dim = src.shape[1]
     s2_0 = co.squared_kernel_sum_closed_form(src, tgt)
     p, s2, q = _oracle_iterations(src, tgt, dict(rot=np.identity(dim), t=np.zeros(dim), scale=1.0), s2_0, k, w,
