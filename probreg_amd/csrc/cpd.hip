@@ -608,21 +608,22 @@ __global__ __launch_bounds__(kBlock) void k_colfinal_resid(float4* __restrict__ 
                 --left;
                 return next++;
             };
-            for (;;) {
-                int sl[2];
-                sl[0] = next_slot();
-                if (sl[0] < 0) break;
-                sl[1] = next_slot();
-                float v[2][6];
+            for (;;) {  // four units (24 loads) in flight per trip, merged in order
+                int sl[4];
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < 4; ++q) sl[q] = next_slot();
+                if (sl[0] < 0) break;
+                float v[4][6];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
                     const float* __restrict__ o = fpart + (int64_t)(sl[q] < 0 ? sl[0] : sl[q]) * 768 + (i & 127);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) v[q][k] = o[128 * k];
                 }
-                merge(v[0][0], v[0][1], v[0][2], v[0][3], v[0][4], v[0][5]);
-                if (sl[1] < 0) break;
-                merge(v[1][0], v[1][1], v[1][2], v[1][3], v[1][4], v[1][5]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (sl[q] >= 0) merge(v[q][0], v[q][1], v[q][2], v[q][3], v[q][4], v[q][5]);
+                if (sl[3] < 0) break;
             }
         }
     } else {

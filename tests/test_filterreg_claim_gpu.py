@@ -45,7 +45,7 @@ def test_gpu_estep_under_the_oracle_mstep_is_the_oracle_bit_for_bit(hybrid):
 def test_every_single_step_from_the_oracle_state_is_within_tolerance(hybrid):
     """The excursion cases step by step: at each iteration the product does ONE EM iteration from the oracle's state
     (transform, sigma2) and is compared with the oracle's next state.  Bars: transform 2e-6 (rotation entries, translation over
-    max(1, |t|)), sigma2 4e-5 relative (measured: 3.0e-7 and 7.6e-6 at worst) - against a whole-trajectory tolerance of 1e-4
+    max(1, |t|)), sigma2 1e-5 relative, the north star itself (measured: 3.0e-7 and 7.6e-6 at worst) - against a whole-trajectory tolerance of 1e-4
     that the same cases miss by up to 0.7 when left to run freely."""
     from oracle import filterreg_numpy as fo
     from probreg_amd import filterreg
@@ -71,4 +71,4 @@ def test_every_single_step_from_the_oracle_state_is_within_tolerance(hybrid):
         worst[c] = (e_tf, e_s2)
     assert set(worst) == set(EXCURSIONS)
     print("worst one-step differences (transform, sigma2):", worst)
-    assert all(a < 2e-6 and b < 4e-5 for a, b in worst.values()), worst
+    assert all(a < 2e-6 and b <= 1e-5 for a, b in worst.values()), worst   # (north star: sigma2 within 1e-5; measured worst 7.6e-6)

@@ -97,12 +97,14 @@ def test_cpd_bench_config_vs_oracle_dense_and_late(config):
     done = k_dense
     while True:
         mid = reg._result_from_params(plan.get_params())
-        if (mid.sigma2 < 3e-3 and done >= 8) or done >= k_warm - 2:
+        # (rigid: the fused sweep hands over to the vector pipe earlier than the matrix-core column pass of the two-sweep engine
+        # does - C1: EM iteration 12, sigma2 = 2.7e-3 - so its masked matrix-core iteration is taken at sigma2 < 8e-3, iteration 10)
+        if (mid.sigma2 < (8e-3 if kind == "rigid" else 3e-3) and done >= 8) or done >= k_warm - 2:
             break
         plan.estep(0.0)
         reg._device_mstep(plan)
         done += 1
-    assert 1e-4 < mid.sigma2 < 3e-3 and done < k_warm - 2, (done, mid.sigma2)
+    assert 1e-4 < mid.sigma2 < 8e-3 and done < k_warm - 2, (done, mid.sigma2)
     plan.estep(0.0)
     assert plan.last_estep_engine() == 1  # this iteration's column pass ran on the matrix cores (tile-mask regime)
     col_pairs, _row_pairs = plan.pair_counts()

@@ -48,7 +48,7 @@ def test_forced_lean_pass_along_a_100k_rigid_registration(w):
         assert plan.last_estep_lean() == 1, it
         assert plan.last_estep_engines() == (1, 1)
         reg._device_mstep(plan)
-        if it in ((0, 8, 12, 13) if w == 0.0 else (0, 4, 8, 10, 12, 13)):
+        if it in ((0, 12, 13) if w == 0.0 else (0, 4, 8, 10, 12, 13)):
             out = reg._result_from_params(plan.get_params())
             p, s2, q = _oracle_step("rigid", src, tgt, st, w)
             err = abs(out.sigma2 - s2) / s2
@@ -56,7 +56,7 @@ def test_forced_lean_pass_along_a_100k_rigid_registration(w):
             assert np.max(np.abs(out.transformation.rot - p["rot"])) <= TOL_TF
             assert abs(out.q - q) <= 1e-4 * abs(q)
             worst, top_amp, checked = max(worst, err), max(top_amp, amp), checked + 1
-    assert checked == (4 if w == 0.0 else 6) and top_amp >= 64.0, (checked, top_amp)  # held up to an amplification of >= 64 (default limit: 16)
+    assert checked == (3 if w == 0.0 else 6) and top_amp >= 64.0, (checked, top_amp)  # held up to an amplification of >= 64 (default limit: 16)
     print("forced lean pass, w = %g: worst sigma2 error %.2e up to amplification %.0f" % (w, worst, top_amp))
 
 

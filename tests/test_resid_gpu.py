@@ -86,7 +86,7 @@ def test_resid_sweep_moments_equal_the_two_sweep_engine(n, m, w, sparse, warm):
     plan.get_estep()
 
 
-@pytest.mark.parametrize("case", ["w01_30k", "two_d", "scale_fixed", "queue_30k", "vector_only"])
+@pytest.mark.parametrize("case", ["w01_20k", "two_d", "scale_fixed", "queue_24k", "vector_only"])
 def test_registration_through_the_single_sweeps_matches_the_oracle(case):
     """`registration` with tol < 0 runs prg_cpd_iterate: every rigid E-step is ONE sweep - the fused matrix-core sweep while
     sigma2 is large, the residual-form vector sweep afterwards - for 30+ iterations, into the sparse regime.  Against the
@@ -95,19 +95,19 @@ def test_registration_through_the_single_sweeps_matches_the_oracle(case):
     from probreg_amd import cpd, synthetic
 
     kw, setup = dict(), None
-    if case == "w01_30k":
-        src, tgt, _ = synthetic.rigid_pair(30000, m=26000, seed=43)
+    if case == "w01_20k":
+        src, tgt, _ = synthetic.rigid_pair(20000, m=18000, seed=43)
         k, w = 32, 0.1
     elif case == "two_d":
-        src, tgt, _ = synthetic.rigid_pair(20000, m=24000, seed=45)
+        src, tgt, _ = synthetic.rigid_pair(14000, m=16000, seed=45)
         src, tgt = src[:, :2].copy(), tgt[:, :2].copy()
         k, w = 30, 0.0
     elif case == "scale_fixed":
-        src, tgt, _ = synthetic.rigid_pair(25000, seed=47)
+        src, tgt, _ = synthetic.rigid_pair(16000, seed=47)
         k, w, kw = 30, 0.2, dict(update_scale=False)
-    elif case == "queue_30k":
-        src, tgt, _ = synthetic.rigid_pair(30000, seed=49)
-        k, w = 32, 0.0
+    elif case == "queue_24k":
+        src, tgt, _ = synthetic.rigid_pair(24000, seed=49)
+        k, w = 30, 0.0
         setup = lambda plan: plan.set_sparse_engine(2)   # noqa: E731
     else:
         src, tgt, _ = synthetic.rigid_pair(12000, m=15000, seed=51)
@@ -155,7 +155,7 @@ def _free_port():
     return p
 
 
-N_SHARD, K_SHARD, W_SHARD = 30000, 26, 0.0
+N_SHARD, K_SHARD, W_SHARD = 24000, 26, 0.0
 
 
 def _shard_worker(rank, world, port, ret, modes):

@@ -38,9 +38,11 @@ def sweep_entry(t, what):
         return int(round(sum(per[k] * calls[k] for k in keys) / tot)) if tot else None
 
     fused = [k for k in per if k.startswith("k_colpass_mfma<true")]       # the fused single sweep of a rigid iteration
-    dominant = fused + [k for k in per if k.startswith("k_rowpass")]      # what bench.py's roofline is quoted on
+    resid = [k for k in per if k.startswith(("k_colpass_queue<true", "k_colpass_cull<true"))]  # ... and the residual-form one (round 5)
+    dominant = fused + resid + [k for k in per if k.startswith("k_rowpass")]  # what bench.py's roofline is quoted on
     return {"rowpass_hbm_bytes_per_launch": mean("k_rowpass"), "colpass_hbm_bytes_per_launch": mean("k_colpass"),
-            "fused_sweep_hbm_bytes_per_launch": mean_of(fused), "dominant_sweep_hbm_bytes_per_launch": mean_of(dominant),
+            "fused_sweep_hbm_bytes_per_launch": mean_of(fused), "resid_sweep_hbm_bytes_per_launch": mean_of(resid),
+            "dominant_sweep_hbm_bytes_per_launch": mean_of(dominant),
             "per_kernel_bytes_per_launch": per, "launches_in_profile": calls, "how": what, "round": int(tag[1:])}
 
 
@@ -52,6 +54,9 @@ out = {}
 t = table("bench_rigid100k")
 if t:
     out["rigid_100k"] = sweep_entry(t, how % "bench_rigid100k")
+t = table("affine_200k")
+if t:
+    out["affine_200k"] = sweep_entry(t, how % "affine_200k")
 t = table("nonrigid_50k")
 if t:
     out["nonrigid_50k"] = sweep_entry(t, how % "nonrigid_50k")
@@ -64,5 +69,13 @@ if t:
                              "how": "sum over every kernel of an EM iteration of (2*FETCH_SIZE + WRITE_SIZE)*1024 x launches, "
                                     "divided by the number of iterations (launches of k_fr_terms); " + how % "filterreg_500k",
                              "round": int(tag[1:])}
+try:  # the code the passes were taken at (run this right after tools/profile_round.sh, before the next commit)
+    import subprocess
+
+    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], universal_newlines=True).strip()
+    dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "probreg_amd", "include"], universal_newlines=True).strip())
+    out["_taken_at"] = {"commit": head, "kernel_sources_modified_since": dirty, "profiles_tag": tag}
+except Exception:
+    pass
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "how"} for k, v in out.items()}, indent=1))

@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r2
 # rocprofv3 kernel traces of the default bench line and PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes;
 # never combined with system / runtime traces) for C1, C3 and C4; summaries land in gpurun_out/prof_<tag>/*.txt.
-tag=${1:-r4}
+tag=${1:-r5}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -44,6 +44,12 @@ for cfg in $configs; do
   python tools/mfma_vs_valu.py $n $its $kind $world 2>&1 | grep -v "amdgpu.ids" > $out/${tag}_engine_switch_${kind}_${n}_w${world}.log
 done
 
+# 3b. C2 (the 8-GPU configuration): HBM traffic of its two sweeps, and the shard replay the 6x projection rests on
+c2="python bench.py --workload affine_200k --steps 20 --warmup 1 --no-cpu-baseline"
+pmc c2 $c2
+sum --pmc $(db $out/c2_FETCH_SIZE) $(db $out/c2_WRITE_SIZE) > $out/${tag}_affine_200k_pmc.txt
+[ -z "$SKIP_SHARD_C2" ] && python tools/shard_window.py 200000 20 affine 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window_c2.log
+
 # 4. C3 and C4: kernel traces and HBM traffic
 c3="python bench.py --workload nonrigid_50k --steps 20 --warmup 2 --no-dense-compare"
 rocprofv3 --kernel-trace --stats -d $out/c3_kt -o b -- $c3 > $out/c3_line.json 2> $out/c3_kt.err
@@ -64,4 +70,4 @@ fi
 ls -la $out/*.txt
 # afterwards, locally: cp gpurun_out/prof_$tag/${tag}_* profiles/ && python tools/pmc_traffic_update.py $tag
 # keep the merged output small: the databases stay on the box
-rm -rf $out/kt_default $out/kt_c1 $out/c1_FETCH_SIZE $out/c1_WRITE_SIZE $out/c1_SQ_INSTS_VALU $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE 2>/dev/null
+rm -rf $out/kt_default $out/kt_c1 $out/c2_FETCH_SIZE $out/c2_WRITE_SIZE $out/c1_FETCH_SIZE $out/c1_WRITE_SIZE $out/c1_SQ_INSTS_VALU $out/c4_kt $out/c4_FETCH_SIZE $out/c4_WRITE_SIZE $out/c3_kt $out/c3_FETCH_SIZE $out/c3_WRITE_SIZE 2>/dev/null
