@@ -363,7 +363,8 @@ def test_nonrigid_vs_reference(cpd_golden, name):
     # bunny.pcd spans 0.08 units, so with beta = 2 every entry of G is within 2.5e-3 of 1.0: the float32
     # kernel carries ~15 significant bits of structure and the reference result itself moves by ~2e-4
     # relative under 1-ulp changes of G (numpy expf vs Eigen expf vs correctly rounded) - looser T there.
-    tol_t = 3e-4 if name.startswith("bunny_nonrigid_k5") else TOL_TF
+    # ([r5] granted 2e-4 - was 3e-4; the HIP path measures 1.3e-4, tools/slack_audit.py)
+    tol_t = 2e-4 if name.startswith("bunny_nonrigid_k5") else TOL_TF
     assert np.max(np.abs(ts - want_ts)) < tol_t * extent
     wmax = np.max(np.abs(want_w))
     assert np.max(np.abs(res.transformation.w - want_w)) < 2e-2 * wmax
@@ -482,12 +483,14 @@ def test_constrained_nonrigid_vs_reference():
         # float32 G entry (6e-8) moves those rows by ~0.6 against c = lmd*sigma2 ~ 0.1, i.e. the reference's own
         # answer depends on how its expf rounds (numpy here, Eigen's vectorised expf in a real build).  Two steps of
         # fp64 iterative refinement in the solver do not move our result, so the residual gap is that input
-        # sensitivity, not solver error; hold such cases to 5e-4 / 1e-3 instead of 1e-5 / 1e-4.
+        # sensitivity, not solver error; hold such cases to 2.5e-4 / 4e-4 instead of 1e-5 / 1e-4 ([r5]: were 5e-4 / 1e-3; the HIP
+        # path measures 1.3e-4 / 2.2e-4, tools/slack_audit.py; tests/test_tolerance_justification.py shows the reference moving
+        # by more than 1e-5 / 1e-4 under 1 ulp of G).
         loose = float(c["alpha"]) <= 1e-6
-        assert abs(res.sigma2 - c["out_sigma2"]) <= (5e-4 if loose else TOL_SIGMA2) * c["out_sigma2"], name
+        assert abs(res.sigma2 - c["out_sigma2"]) <= (2.5e-4 if loose else TOL_SIGMA2) * c["out_sigma2"], name
         ts = res.transformation.transform(c["source"])
         extent = np.max(np.abs(c["out_tsource"] - c["out_tsource"].mean(0)))
-        assert np.max(np.abs(ts - c["out_tsource"])) < (1e-3 if loose else TOL_TF) * extent, name
+        assert np.max(np.abs(ts - c["out_tsource"])) < (4e-4 if loose else TOL_TF) * extent, name
         # the constrained points are pulled onto their partners when alpha is tiny
         if float(c["alpha"]) <= 1e-6:
             d = ts[c["idx_source"]] - c["target"][c["idx_target"]]
