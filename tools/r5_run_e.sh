@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-5 GPU call E: FilterReg embedding with the first probes of stage 2 issued together - parity tests, A/B of C4, kernel trace
+export TMPDIR=/tmp
+out=gpurun_out/r5e
+mkdir -p $out
+timeout 600 python -m pytest tests/test_filterreg_gpu.py tests/test_filterreg_claim_gpu.py tests/test_feature_lattice_gpu.py "tests/test_fullsize_gpu.py::test_filterreg_c4_500k_vs_oracle" -q > $out/pytest_fr.log 2>&1
+echo "filterreg tests rc=$?" > $out/status.txt
+tail -2 $out/pytest_fr.log
+c4="python bench.py --workload filterreg_500k --steps 20 --warmup 3"
+for rep in 1 2; do for v in 0 1; do
+  PRG_EMBED_PREFETCH=$v timeout 200 $c4 > $out/c4_prefetch${v}_$rep.json 2> /dev/null
+done; done
+timeout 300 rocprofv3 --kernel-trace --stats -d $out/c4_kt -o b -- $c4 > $out/c4_kt_line.json 2> $out/c4_kt.err
+python tools/rocpd_summary.py $(ls $out/c4_kt/*.db $out/c4_kt/*/*.db 2>/dev/null | head -1) > $out/r5_filterreg_500k_kernel_trace_prefetch.txt 2>&1
+rm -rf $out/c4_kt
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r5e/c4_prefetch*.json")):
+    d = json.loads(open(f).read().strip().splitlines()[-1])
+    print(f, "%.1f it/s %.4f ms frac %.4f" % (d["value"], d["ms_per_step"], d["roofline"]["frac"]))
+PY
