@@ -168,12 +168,7 @@ constexpr bool kPlainProbe = PRG_PLAIN_PROBE != 0;
 
 // Embed one point (features f, scale factors s) and insert its D + 1 vertices into table T.  pslot_i / bary_i: where the
 // point's slots and barycentric weights go, or null (the side table of the speculative with_blur decision only counts).
-// PRE [r5]: the D + 1 first probes of the point are issued together, before any is consumed (the rounds' keys are independent: one
-// memory round trip instead of D + 1 dependent ones) - for the launch that only LOOKS vertices up (stage 2: the spread sample of
-// stage 1 has created most of them; in round 2, applied to the launch that creates them, the early look made more lanes see "empty"
-// and compare-and-swap the same slot).  A prefetched entry is as good as the plain read it replaces: possibly stale, final if it
-// shows this build's generation, asked again at device scope if it looks free.
-template <int D, bool PRE = false>
+template <int D>
 __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, float s1, float s2, const EmbedTable& T,
                                              int lane, int* __restrict__ pslot_i, float* __restrict__ bary_i) {
     constexpr int D1 = D + 1;
@@ -241,7 +236,6 @@ __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, floa
         cslot[r] = 0;
         ckey[r] = 0;
     }
-    unsigned long long pkr[D1], slot0[D1], pre[D1];
 #pragma unroll
     for (int r = 0; r < D1; ++r) {
         short key[D];
@@ -252,18 +246,8 @@ __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, floa
             const int can = (rk <= D - r) ? r : r - D1;
             key[k] = (short)(rem0[k] + (float)can);
         }
-        pkr[r] = pack_key(key, D);
-        slot0[r] = mix64(pkr[r]) & mask;
-        pre[r] = 0ull;
-    }
-    if (PRE && kPlainProbe) {
-#pragma unroll
-        for (int r = 0; r < D1; ++r) pre[r] = tkeys[slot0[r]];
-    }
-#pragma unroll
-    for (int r = 0; r < D1; ++r) {
-        const unsigned long long pk = pkr[r], mine = pk | gbits;
-        unsigned long long slot = slot0[r];
+        const unsigned long long pk = pack_key(key, D), mine = pk | gbits;
+        unsigned long long slot = mix64(pk) & mask;
         bool claimed = false;
         for (int probes = 0;; ++probes) {
             if (probes > 4096) {  // table (sized from the previous lattice) is too small: the host rebuilds
@@ -277,7 +261,7 @@ __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, floa
             // (that read goes past the L2s to the memory side and costs several times as much).  Once a vertex exists,
             // the ~N/L points sharing it never issue an atomic - a CAS storm on a few hundred hot keys costs milliseconds
             // when sigma is large.
-            unsigned long long cur = kPlainProbe ? ((PRE && probes == 0) ? pre[r] : tkeys[slot]) : 0ull;
+            unsigned long long cur = kPlainProbe ? tkeys[slot] : 0ull;
             if (kPlainProbe && cur == mine) break;
             if (!kPlainProbe || (unsigned)(cur >> 48) != gen)
                 cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -342,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
                                                   int* __restrict__ pslot, float* __restrict__ bary,
                                                   const EmbedTable side, float t0, float t1, float t2, int sample) {
     // sample 0: points [first, n); 1: every 16th point of [0, n) (a sample spread over the whole cloud: it creates most
-    // vertices with few lanes of a wave after the same one); 2: all the others; 3: all the others, first probes issued together
+    // vertices with few lanes of a wave after the same one); 2: all the others
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const int64_t i = sample == 0 ? first + t : (sample == 1 ? 16 * t : t + t / 15 + 1);
     if (i >= n) return;
@@ -372,8 +356,7 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
 #pragma unroll
         for (int k = 0; k < D; ++k) f[k] = feat[i * D + k];
     }
-    if (sample == 3) embed_insert<D, true>(f, s0, s1, s2, table, lane, pslot + i * D1, bary + i * D1);
-    else embed_insert<D>(f, s0, s1, s2, table, lane, pslot + i * D1, bary + i * D1);
+    embed_insert<D>(f, s0, s1, s2, table, lane, pslot + i * D1, bary + i * D1);
     if (side.tkeys) embed_insert<D>(f, t0, t1, t2, side, lane, nullptr, nullptr);
 }
 
@@ -1115,8 +1098,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
                 if (stage == 1) launch_embed(L, d, 0, n / 16, sc, main_table, side_table, side_sc);
                 else launch_embed(L, d, n / 16, n, sc, main_table, side_table, side_sc);
             } else {
-                static const bool prefetch = !(getenv("PRG_EMBED_PREFETCH") && atoi(getenv("PRG_EMBED_PREFETCH")) == 0);
-                launch_embed(L, d, 0, n, sc, main_table, side_table, side_sc, stage == 2 && prefetch ? 3 : stage);
+                launch_embed(L, d, 0, n, sc, main_table, side_table, side_sc, stage);
             }
         };
         if (!L->pinned) PRG_HIP(hipHostMalloc((void**)&L->pinned, 64 * sizeof(double), hipHostMallocDefault));

@@ -202,3 +202,47 @@ def test_stream_mode_equals_grid_mode_and_the_oracle(n, m, w):
     assert np.max(np.abs(a - b)) < 1e-6 * n_p
     # the column side does not depend on how the launch is cut beyond the order fp32 partials are added in
     assert np.max(np.abs(out[True][1][0] - out[False][1][0])) < 1e-6
+
+
+@pytest.mark.parametrize("kind,single", [("rigid", True), ("rigid", False), ("affine", False)])
+def test_fine_grid_of_culling_matrix_core_launches_matches_the_oracle(kind, single):
+    """[r5] DESIGN.md 3.1c: few owned blocks against a long streamed cloud (a shard's shape: 9 000 targets = 18 column blocks against
+    60 000 sources = 235 chunks) - once the masks skip a tenth of the pairs the matrix-core launches are cut into >= 3 rounds of
+    shorter segments (58 column planes instead of 32 here).  Both sweeps pinned to the matrix cores so that they keep running,
+    culling, on that grid - as the fused single sweep and as column pass + row pass: E-step moments against the C oracle from the
+    same state, and the M-step that follows."""
+    from oracle import cpd_c, cpd_numpy as co
+    from probreg_amd import _lib, cpd, synthetic
+
+    n, m = 9000, 60000
+    if kind == "rigid":
+        src, tgt, _ = synthetic.rigid_pair(n, m=m, seed=61)
+        reg, kind_id = cpd.RigidCPD(src), _lib.PRG_TF_RIGID
+    else:
+        src, tgt, _ = synthetic.affine_pair(n, m=m, seed=61)
+        reg, kind_id = cpd.AffineCPD(src), _lib.PRG_TF_AFFINE
+    assert src.shape[0] == m and tgt.shape[0] == n
+    reg._initialize(tgt)
+    plan = reg._plan
+    plan.set_dense_engine(2)
+    plan.set_fused_factor(1e30)
+    plan.set_lean_factor(1e30)
+    plan.set_moments_only(1 if single else 2)
+    culled = 0
+    for it in range(14):
+        st = reg._result_from_params(plan.get_params())
+        plan.estep(0.0)
+        assert plan.last_estep_engine() == 1 and plan.last_estep_fused() == (1 if single else 0)
+        col_pairs, _row_pairs = plan.pair_counts()
+        prev_culled, culled = culled, culled + (col_pairs < 0.9 * float(n) * m)
+        plan.mstep(kind_id, True)
+        if prev_culled >= 2 and it % 2 == 1:   # (the grid of THIS E-step was chosen from the count of the one before the previous)
+            out = reg._result_from_params(plan.get_params())
+            tr = st.transformation
+            p0 = dict(rot=tr.rot, t=tr.t, scale=float(tr.scale)) if kind == "rigid" else dict(b=tr.b, t=tr.t)
+            es = co.EstepResult(*cpd_c.expectation_step(co.transform(kind, p0, src), tgt, st.sigma2, 0.0))
+            p, s2, _q = (co.mstep_rigid if kind == "rigid" else co.mstep_affine)(src, tgt, es)
+            assert abs(out.sigma2 - s2) <= TOL_SIGMA2 * s2, (it, out.sigma2, s2)
+            lin, want = (out.transformation.rot, p["rot"]) if kind == "rigid" else (out.transformation.b, p["b"])
+            assert rel_err(lin, want) < TOL_TF and np.max(np.abs(out.transformation.t - p["t"])) < TOL_TF
+    assert culled >= 4, culled   # the masks were at work for several iterations: the fine grid ran
