@@ -165,6 +165,10 @@ struct EmbedTable {
 #define PRG_PLAIN_PROBE 1
 #endif
 constexpr bool kPlainProbe = PRG_PLAIN_PROBE != 0;
+#ifndef PRG_EMBED_VECTOR_STORES
+#define PRG_EMBED_VECTOR_STORES 1
+#endif
+constexpr bool kVectorStores = PRG_EMBED_VECTOR_STORES != 0;
 
 // Embed one point (features f, scale factors s) and insert its D + 1 vertices into table T.  pslot_i / bary_i: where the
 // point's slots and barycentric weights go, or null (the side table of the speculative with_blur decision only counts).
@@ -229,6 +233,7 @@ __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, floa
     }
     bar[0] = __fadd_rn(bar[0], __fadd_rn(1.0f, bar[D1]));
     unsigned nclaim_mask = 0;  // rounds in which this lane created a vertex, with the slot and key of each
+    int fslot[D1];             // the slot every round ended on
     int cslot[D1];
     unsigned long long ckey[D1];
 #pragma unroll
@@ -281,9 +286,20 @@ __device__ __forceinline__ void embed_insert(const float (&f)[D], float s0, floa
             cslot[r] = (int)slot;
             ckey[r] = pk;
         }
-        if (pslot_i) {
-            pslot_i[r] = (int)slot;
-            bary_i[r] = bar[r];
+        fslot[r] = (int)slot;
+    }
+    if (pslot_i) {
+        // [r5] D = 3: one 16-byte store per point and array (a wave writes 1 KB contiguous) instead of four 4-byte stores at a
+        // stride of 16 bytes each
+        if constexpr (D1 == 4 && kVectorStores) {
+            *reinterpret_cast<int4*>(pslot_i) = make_int4(fslot[0], fslot[1], fslot[2], fslot[3]);
+            *reinterpret_cast<float4*>(bary_i) = make_float4(bar[0], bar[1], bar[2], bar[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < D1; ++r) {
+                pslot_i[r] = fslot[r];
+                bary_i[r] = bar[r];
+            }
         }
     }
     // whoever created a vertex numbers it (no scan of the table afterwards): ONE counter update per wave - the lanes'
@@ -336,21 +352,27 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
     if (FR) {
         const double sigma = sqrt(fr.state[12]);
         if (i < fr.m) {
-            double y[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k = 0; k < D; ++k) y[k] = fr.src[i * D + k];
+            // [r5] source / target / transformed source are stored 4 doubles per point (x, y, z, 0): two 16-byte accesses per
+            // point that a wave issues over contiguous memory, instead of three 8-byte ones at a stride of 24 bytes
+            const double2 ya = reinterpret_cast<const double2*>(fr.src)[2 * i], yb = reinterpret_cast<const double2*>(fr.src)[2 * i + 1];
+            const double y[3] = {ya.x, ya.y, yb.x};
+            double zt[3];
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < D; ++k) acc += y[k] * fr.state[3 * r + k];  // dot(points, rot.T), transformation.py:49-50
                 const double z = r < D ? acc + fr.state[9 + r] : 0.0;
-                fr.ts[i * 3 + r] = z;
+                zt[r] = z;
                 if (r < D) f[r < D ? r : 0] = (float)(z / sigma);
             }
+            reinterpret_cast<double2*>(fr.ts)[2 * i] = make_double2(zt[0], zt[1]);
+            reinterpret_cast<double2*>(fr.ts)[2 * i + 1] = make_double2(zt[2], 0.0);
         } else {
+            const double2 xa = reinterpret_cast<const double2*>(fr.tgt)[2 * (i - fr.m)], xb = reinterpret_cast<const double2*>(fr.tgt)[2 * (i - fr.m) + 1];
+            const double xt[3] = {xa.x, xa.y, xb.x};
 #pragma unroll
-            for (int k = 0; k < D; ++k) f[k] = (float)(fr.tgt[(i - fr.m) * D + k] / sigma);
+            for (int k = 0; k < D; ++k) f[k] = (float)(xt[k] / sigma);
         }
     } else {
 #pragma unroll
@@ -555,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int
                                                     const int* __restrict__ slot_id, int* __restrict__ count,
                                                     int* __restrict__ count2, LatticeMail* __restrict__ mail,
                                                     unsigned seq) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // (one int4 = four entries per thread)
     if (i == 0 && mail) {
         mail->size = count[0];
         mail->overflow = count[1];
@@ -566,7 +588,16 @@ __global__ __launch_bounds__(kBlock) void k_resolve(int* __restrict__ pslot, int
         count[0] = count[1] = 0;
         if (count2) count2[0] = count2[1] = 0;
     }
-    if (i < total) pslot[i] = slot_id[pslot[i]];
+    if (4 * i + 3 < total) {
+        int4 v = reinterpret_cast<int4*>(pslot)[i];
+        v.x = slot_id[v.x];
+        v.y = slot_id[v.y];
+        v.z = slot_id[v.z];
+        v.w = slot_id[v.w];
+        reinterpret_cast<int4*>(pslot)[i] = v;
+    } else {
+        for (int64_t t = 4 * i; t < total; ++t) pslot[t] = slot_id[pslot[t]];
+    }
 }
 
 __device__ __forceinline__ int lookup(const unsigned long long* __restrict__ tkeys, unsigned long long mask,
@@ -645,21 +676,23 @@ __global__ __launch_bounds__(kBlock) void k_splat(const int* __restrict__ offset
 // (256 points / 256 slots per workgroup: 9 KB of LDS (17 KB in fixed point), 8 workgroups per CU.  The first version used 2048 / 2048 = 72 KB:
 // 245 workgroups of one wave per SIMD each, every lane walking 32 incidences through dependent loads and returning LDS
 // atomics with nobody to hide the latency - 52 % of the wave cycles were waits, profiles/r2_filterreg_500k_pmc.txt)
-constexpr int kSplatBits = 8;
-constexpr int kSplatSlots = 1 << kSplatBits;  // LDS table entries (key + up to 8 channels)
+// [r5] The table's value rows are as wide as the filter has channels (STRIDE 5 for FilterReg's point-to-point pass, 8 otherwise), and
+// the five-channel table has 512 slots in the LDS the 256 x 8 one takes (22 KB in fixed point): late EM iterations, where the 1024
+// incidences of a workgroup's 256 points spread over more distinct vertices than 192 slots hold, overflow to global atomics less.
 constexpr int kSplatMaxCh = 8;
 constexpr int kSplatPts = 256;                // points per workgroup
-template <bool FX>
+template <bool FX, int kSplatBits, int STRIDE>
 __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ offset, const float* __restrict__ bary,
                                                       const float* __restrict__ in, int64_t first, int64_t n, int d1,
                                                       int ch, float* __restrict__ vals, long long* __restrict__ fx,
                                                       const double* __restrict__ scale) {
     typedef typename std::conditional<FX, unsigned long long, float>::type acc_t;
+    constexpr int kSplatSlots = 1 << kSplatBits;  // LDS table entries (key + STRIDE channels)
     __shared__ int skey[kSplatSlots];
-    __shared__ acc_t sval[kSplatSlots * kSplatMaxCh];
+    __shared__ acc_t sval[kSplatSlots * STRIDE];
     __shared__ int sfill;
     for (int t = threadIdx.x; t < kSplatSlots; t += kBlock) skey[t] = -1;
-    for (int t = threadIdx.x; t < kSplatSlots * kSplatMaxCh; t += kBlock) sval[t] = (acc_t)0;
+    for (int t = threadIdx.x; t < kSplatSlots * STRIDE; t += kBlock) sval[t] = (acc_t)0;
     if (threadIdx.x == 0) sfill = 0;
     __syncthreads();
     double mul[kSplatMaxCh];
@@ -696,10 +729,10 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
             if (k >= ch || p[k] == 0.f) continue;
             if (slot >= 0) {
                 if (FX)
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&sval[slot * kSplatMaxCh + k]),
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&sval[slot * STRIDE + k]),
                               (unsigned long long)__double2ll_rn((double)p[k] * mul[k]));
                 else
-                    atomicAdd(reinterpret_cast<float*>(&sval[slot * kSplatMaxCh + k]), p[k]);
+                    atomicAdd(reinterpret_cast<float*>(&sval[slot * STRIDE + k]), p[k]);
             } else {
                 splat_add_global<FX>(vals, fx, (int64_t)o * ch + k, p[k], mul[k]);
             }
@@ -710,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void k_splat_lds(const int* __restrict__ of
         const int o = skey[t];
         if (o < 0) continue;
         for (int k = 0; k < ch; ++k) {
-            const acc_t v = sval[t * kSplatMaxCh + k];
+            const acc_t v = sval[t * STRIDE + k];
             if (v == (acc_t)0) continue;
             if (FX)
                 atomicAdd(reinterpret_cast<unsigned long long*>(fx + (int64_t)o * ch + k), (unsigned long long)v);
@@ -1150,7 +1183,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
             // device-to-host copy, no stream synchronisation, the queue does not drain (on an overflow - rare - it has
             // resolved garbage, which the retry overwrites)
             const unsigned seq = ++L->mail_seq;
-            k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id, L->count,
+            k_resolve<<<(unsigned)prg::ceil_div(prg::ceil_div(n * d1, 4), kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id, L->count,
                                                                                  L->side_pending ? L->count2 : nullptr,
                                                                                  L->mail_dev, seq);
             PRG_HIP(hipGetLastError());
@@ -1301,7 +1334,7 @@ int lat_build_generic(Lattice* L, int64_t n, int d, int with_blur) {
             PRG_HIP(hipMalloc((void**)&L->gcheck, want * sizeof(unsigned long long)));
             L->g_alloc_size = want;
         }
-        k_resolve<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id, nullptr, nullptr, nullptr, 0u);
+        k_resolve<<<(unsigned)prg::ceil_div(prg::ceil_div(n * d1, 4), kBlock), kBlock, 0, st>>>(L->pslot, n * d1, L->slot_id, nullptr, nullptr, nullptr, 0u);
         PRG_HIP(hipMemsetAsync(L->gcheck, 0, (size_t)L->size * sizeof(unsigned long long), st));
         PRG_HIP(hipMemsetAsync(L->count + 1, 0, sizeof(int), st));  // now the collision flag
         k_store_keys_g<<<(unsigned)prg::ceil_div(n * d1, kBlock), kBlock, 0, st>>>(L->pslot, n, d, L->rem0s, L->rank8, seed2,
@@ -1463,8 +1496,12 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
             PRG_HIP(hipMemsetAsync(L->fx, 0, (size_t)want * sizeof(long long), st));  // from here on k_fix_to_float keeps it zero
             L->fx_elems = want;
         }
-        if (ch <= kSplatMaxCh)
-            k_splat_lds<true><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
+        static const bool wide_table = !(getenv("PRG_SPLAT_TABLE") && atoi(getenv("PRG_SPLAT_TABLE")) == 0);
+        if (ch <= 5 && wide_table)
+            k_splat_lds<true, 9, 5><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
+                L->pslot, L->bary, in, first, L->n, d1, ch, a, L->fx, L->fx_scale);
+        else if (ch <= kSplatMaxCh)
+            k_splat_lds<true, 8, 8><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
                 L->pslot, L->bary, in, first, L->n, d1, ch, a, L->fx, L->fx_scale);
         else
             k_splat<true><<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(
@@ -1473,7 +1510,7 @@ int lat_filter(Lattice* L, const float* in, int ch, int64_t first, int64_t n_out
     } else {
         PRG_HIP(hipMemsetAsync(a, 0, 2 * plane * sizeof(float), st));
         if (ch <= kSplatMaxCh)
-            k_splat_lds<false><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
+            k_splat_lds<false, 8, 8><<<(unsigned)prg::ceil_div(L->n - first, kSplatPts), kBlock, 0, st>>>(
                 L->pslot, L->bary, in, first, L->n, d1, ch, a, nullptr, nullptr);
         else
             k_splat<false><<<(unsigned)prg::ceil_div((L->n - first) * d1, kBlock), kBlock, 0, st>>>(
@@ -1542,7 +1579,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_values(const double* __restrict__
     if (i >= m + n) return;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (i >= m) {
-        const double* y = tgt + (i - m) * dim;
+        const double* y = tgt + (i - m) * 4;  // (4 doubles per point)
         double s = 0.0;
         v[0] = 1.0f;
         for (int k = 0; k < dim; ++k) {
@@ -1609,7 +1646,8 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms(const float* __restrict__ v
         }
         const float m0 = f[0];
         if (m0 != 0.f) {
-            const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
+            const double2 za = reinterpret_cast<const double2*>(ts)[2 * i], zb = reinterpret_cast<const double2*>(ts)[2 * i + 1];
+            const double z[3] = {za.x, za.y, zb.x};  // (4 doubles per point)
             const float m1[3] = {f[1], f[2], f[3]};
             const float m2 = f[4];
             float tg[3];  // m1m0 = m1 / m0 in float32 (:172)
@@ -1670,7 +1708,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_terms_pt2pl(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         const float m0 = vout[i * 8];
         if (m0 != 0.f) {
-            const double z[3] = {ts[i * 3], ts[i * 3 + 1], ts[i * 3 + 2]};
+            const double z[3] = {ts[i * 4], ts[i * 4 + 1], ts[i * 4 + 2]};  // (4 doubles per point)
             double v[3], t[3], n[3];
             double zz = 0.0, zm1 = 0.0;
 #pragma unroll
@@ -1958,7 +1996,7 @@ __global__ __launch_bounds__(kBlock) void k_fr_pack_estep(const double* __restri
                                                           double* __restrict__ ts, float* __restrict__ vout) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= m) return;
-    for (int k = 0; k < 3; ++k) ts[i * 3 + k] = k < dim ? tsrc[i * dim + k] : 0.0;
+    for (int k = 0; k < 4; ++k) ts[i * 4 + k] = k < dim ? tsrc[i * dim + k] : 0.0;  // (4 doubles per point)
     float* o = vout + i * ch;
     o[0] = m0[i];
     for (int k = 0; k < 3; ++k) o[1 + k] = k < dim ? m1[i * dim + k] : 0.f;
@@ -2153,7 +2191,7 @@ static int fr_alloc(prg_filterreg* h) {
         if (p) (void)hipFree(p);
     h->ts = nullptr; h->vin = nullptr; h->vout = nullptr; h->part = nullptr;
     h->L.fx_scale_key = nullptr;  // new values: the fixed-point scales are recomputed by the next filter call
-    PRG_HIP(hipMalloc((void**)&h->ts, (size_t)h->M * 3 * sizeof(double)));
+    PRG_HIP(hipMalloc((void**)&h->ts, (size_t)h->M * 4 * sizeof(double)));  // (x, y, z, 0) per point
     PRG_HIP(hipMalloc((void**)&h->vin, (size_t)tot * 8 * sizeof(float)));
     PRG_HIP(hipMalloc((void**)&h->vout, (size_t)h->M * 8 * sizeof(float)));
     h->part_blocks = std::min<int64_t>(prg::ceil_div(h->M, kBlock), 512);  // grid-stride M-step term kernels
@@ -2172,25 +2210,27 @@ int prg_fr_set_source(prg_filterreg* h, const double* source_hd, int64_t m, int 
     PRG_HIP(hipStreamSynchronize(h->L.stream));
     if (h->src) (void)hipFree(h->src);
     h->src = nullptr;
-    PRG_HIP(hipMalloc((void**)&h->src, (size_t)m * dim * sizeof(double)));
+    PRG_HIP(hipMalloc((void**)&h->src, (size_t)m * 4 * sizeof(double)));  // (x, y, z, 0) per point: 16-byte accesses in k_embed
     if (h->src_perm) (void)hipFree(h->src_perm);
     h->src_perm = nullptr;
     static const bool sort_source = getenv("PRG_FR_SOURCE_ORDER") == nullptr;  // (set: keep the caller's order, as in round 2)
-    if (sort_source && m >= 4096) {
+    {
         // The source is stored in Morton order like the target: with the lattice's vertices created by a sample spread over
         // both clouds (every 16th point, lat_build), the other points only LOOK vertices up, and neighbouring lanes of a
         // sorted cloud look up the same few table lines.  Every per-point output crosses the ABI through src_perm.
-        std::vector<double> host((size_t)m * dim), sorted((size_t)m * dim);
+        std::vector<double> host((size_t)m * dim), padded((size_t)m * 4, 0.0);
         PRG_HIP(hipMemcpy(host.data(), source_hd, host.size() * sizeof(double), hipMemcpyDefault));
-        const std::vector<int> order = prg::morton_order(host.data(), m, dim);
-        for (int64_t i = 0; i < m; ++i)
-            for (int k = 0; k < dim; ++k) sorted[(size_t)i * dim + k] = host[(size_t)order[i] * dim + k];
-        PRG_HIP(hipMalloc((void**)&h->src_perm, (size_t)m * sizeof(int)));
-        PRG_HIP(hipMemcpyAsync(h->src_perm, order.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, h->L.stream));
-        PRG_HIP(hipMemcpyAsync(h->src, sorted.data(), (size_t)m * dim * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
-        PRG_HIP(hipStreamSynchronize(h->L.stream));
-    } else {
-        PRG_HIP(hipMemcpyAsync(h->src, source_hd, (size_t)m * dim * sizeof(double), hipMemcpyDefault, h->L.stream));
+        std::vector<int> order;
+        if (sort_source && m >= 4096) order = prg::morton_order(host.data(), m, dim);
+        for (int64_t i = 0; i < m; ++i) {
+            const int64_t j = order.empty() ? i : order[(size_t)i];
+            for (int k = 0; k < dim; ++k) padded[(size_t)i * 4 + k] = host[(size_t)j * dim + k];
+        }
+        if (!order.empty()) {
+            PRG_HIP(hipMalloc((void**)&h->src_perm, (size_t)m * sizeof(int)));
+            PRG_HIP(hipMemcpyAsync(h->src_perm, order.data(), (size_t)m * sizeof(int), hipMemcpyHostToDevice, h->L.stream));
+        }
+        PRG_HIP(hipMemcpyAsync(h->src, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
         PRG_HIP(hipStreamSynchronize(h->L.stream));
     }
     h->M = m;
@@ -2208,16 +2248,16 @@ int prg_fr_set_target(prg_filterreg* h, const double* target_hd, int64_t n, int 
     PRG_HIP(hipStreamSynchronize(h->L.stream));
     if (h->tgt) (void)hipFree(h->tgt);
     h->tgt = nullptr;
-    PRG_HIP(hipMalloc((void**)&h->tgt, (size_t)n * dim * sizeof(double)));
+    PRG_HIP(hipMalloc((void**)&h->tgt, (size_t)n * 4 * sizeof(double)));  // (x, y, z, 0) per point
     // The target is stored in Morton order: the splat works on 2048 consecutive target points per workgroup, and
     // spatially close points share lattice vertices, so the workgroup-private LDS table absorbs most updates and
     // the flush touches few global vertices.  Every E-step output is per SOURCE point, so no order leaks out.
-    std::vector<double> host((size_t)n * dim), sorted((size_t)n * dim);
+    std::vector<double> host((size_t)n * dim), sorted((size_t)n * 4, 0.0);
     PRG_HIP(hipMemcpy(host.data(), target_hd, host.size() * sizeof(double), hipMemcpyDefault));
     h->tgt_order = prg::morton_order(host.data(), n, dim);
     for (int64_t i = 0; i < n; ++i)
-        for (int k = 0; k < dim; ++k) sorted[(size_t)i * dim + k] = host[(size_t)h->tgt_order[i] * dim + k];
-    PRG_HIP(hipMemcpyAsync(h->tgt, sorted.data(), (size_t)n * dim * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
+        for (int k = 0; k < dim; ++k) sorted[(size_t)i * 4 + k] = host[(size_t)h->tgt_order[i] * dim + k];
+    PRG_HIP(hipMemcpyAsync(h->tgt, sorted.data(), sorted.size() * sizeof(double), hipMemcpyHostToDevice, h->L.stream));
     // ... and the splat still adds every vertex' terms up in the CALLER's point order (the reference's): caller index -> kernel position
     std::vector<int> inv((size_t)n);
     for (int64_t i = 0; i < n; ++i) inv[(size_t)h->tgt_order[i]] = (int)i;
@@ -2431,7 +2471,7 @@ int prg_fr_mstep_from_arrays(int device, void* hip_stream, const double* t_sourc
                  o_m2 = o_m1 + (size_t)m * dim * sizeof(float), o_nx = o_m2 + (size_t)m * sizeof(float),
                  total = o_nx + (size_t)m * 3 * sizeof(float);
     PRG_HIP(hipMalloc(&b_in.p, total));
-    PRG_HIP(hipMalloc(&b_ts.p, (size_t)m * 3 * sizeof(double)));
+    PRG_HIP(hipMalloc(&b_ts.p, (size_t)m * 4 * sizeof(double)));  // (x, y, z, 0) per point, as the terms kernels read it
     PRG_HIP(hipMalloc(&b_v.p, (size_t)m * ch * sizeof(float)));
     PRG_HIP(hipMalloc(&b_part.p, (size_t)nblk * kFrComp * sizeof(double)));
     PRG_HIP(hipMalloc(&b_state.p, 64 * sizeof(double)));
