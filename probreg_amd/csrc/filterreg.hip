@@ -344,7 +344,9 @@ __global__ __launch_bounds__(kBlock) void k_embed(const float* __restrict__ feat
     // sample 0: points [first, n); 1: every 16th point of [0, n) (a sample spread over the whole cloud: it creates most
     // vertices with few lanes of a wave after the same one); 2: all the others
     const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t i = sample == 0 ? first + t : (sample == 1 ? 16 * t : t + t / 15 + 1);
+    const int period = sample >> 2;  // stage 1 takes every period-th point (sample & 3 == 1), stage 2 the others (== 2)
+    sample &= 3;
+    const int64_t i = sample == 0 ? first + t : (sample == 1 ? (int64_t)period * t : t + t / (period - 1) + 1);
     if (i >= n) return;
     constexpr int D1 = D + 1;
     const int lane = threadIdx.x & 63;
@@ -1041,12 +1043,20 @@ void lat_scale(int d, int with_blur, float (&sc)[3]) {
     for (int i = 0; i < 3; ++i) sc[i] = i < d ? (float)(1.0 / sqrt((double)((i + 2) * (i + 1))) * (double)inv_std) : 0.f;
 }
 
+// every how-many-th point creates the vertices in stage 1 of a build (the others look them up in stage 2); PRG_EMBED_PERIOD for A/B runs
+static int embed_period() {
+    static const int p = getenv("PRG_EMBED_PERIOD") ? std::max(2, std::min(64, atoi(getenv("PRG_EMBED_PERIOD")))) : 16;
+    return p;
+}
+
 // Embedding launch over points [first, last) into `table`; side (tkeys may be null): the same points also go, with the
 // scale factors ssc, into the side table of the speculative with_blur decision.
 void launch_embed(Lattice* L, int d, int64_t first, int64_t last, const float (&sc)[3], const EmbedTable& table,
                   const EmbedTable& side, const float (&ssc)[3], int sample = 0) {
     // sample 1 / 2: first must be 0; the every-16th sample has ceil(last / 16) points, the complement the rest
-    const int64_t count = sample == 0 ? last - first : (sample == 1 ? prg::ceil_div(last, 16) : last - prg::ceil_div(last, 16));
+    const int period = embed_period();
+    const int64_t count = sample == 0 ? last - first : (sample == 1 ? prg::ceil_div(last, period) : last - prg::ceil_div(last, period));
+    if (sample) sample |= period << 2;
     const unsigned nb = (unsigned)prg::ceil_div(count, kBlock);
     if (nb == 0) return;
     hipStream_t st = L->stream;
@@ -1243,7 +1253,7 @@ int lat_build(Lattice* L, int64_t n, int d, int with_blur, int64_t decide_above 
 int lat_side_stage(Lattice* L, int64_t n, int d) {
     const int d1 = d + 1;
     hipStream_t st = L->stream;
-    const int64_t n16 = n / 16;
+    const int64_t n16 = prg::ceil_div(n, embed_period());
     int64_t want = 1;
     while (want < 4 * n16 * d1) want <<= 1;
     if (want > L->cap2) {
