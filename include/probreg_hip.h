@@ -99,7 +99,8 @@ int prg_cpd_engine_bounds(int64_t m, int64_t n_local, double* col_bound, double*
  * 512-point segment) whether it finds work or not (the culled sweeps of csrc/cpd_sweeps_packed.hip).  Same pairs, same
  * arithmetic, exact either way; tests / measurements. */
 int prg_cpd_set_sparse_engine(prg_cpd* h, int mode);
-/* ... and for both sweeps of the last E-step: 1 = matrix cores, 0 = vector pipe (column pass, row pass). */
+/* ... and for both sweeps of the last E-step: 1 = matrix cores, 0 = vector pipe (column pass, row pass).  An E-step that ran as a
+ * single sweep (prg_cpd_last_estep_fused) has no row pass: row_engine and prg_cpd_last_estep_lean report 0 for it. */
 int prg_cpd_last_estep_engines(prg_cpd* h, int* col_engine, int* row_engine);
 /* 1 if the last E-step's matrix-core row pass ran WITHOUT its residual sums sum_n P_mn |x_n - o|^2 (19 instead of 21 flop
  * per pair): while sigma2 * D * 64 >= mean |x|^2 of the local target the M-step's sum_n pt1_n |x_n|^2 is taken from the column

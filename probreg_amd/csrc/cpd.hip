@@ -13,6 +13,10 @@
 //   k_row_moments  sums the segment partials per row in fp64, rebuilds px = u + p1 z and the
 //              23 fp64 moments the rigid / affine M-step needs (the RCCL all-reduce payload).
 //   k_mstep    one thread, fp64: 3x3 one-sided Jacobi SVD / 3x3 solve, sigma2, q.
+// A RIGID iteration (prg_cpd_iterate, prg_cpd_set_moments_only) runs ONE sweep instead of two: the column
+// pass carries per-column sums of the source side as well - on the matrix cores relative to a block origin (k_colpass_mfma<FUSED> ->
+// k_colfinal_fused), on the vector pipe as residuals against the column's own x_n (k_colpass_cull<true> / k_colpass_queue<true> ->
+// k_colfinal_resid) - and k_fused_final maps the z-side sums back to the source's frame: no row pass, no per-point block.
 #include <math.h>
 
 #include <algorithm>
