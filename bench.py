@@ -375,7 +375,7 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
                 else "EM iterations/sec (%s)" % desc, steps / elapsed, elapsed, steps, warmup, desc, "f32", world)
     out["config"].update({
         "window": "EM iterations 0..%d of the registration (state reset after the warm-up steps)" % (steps - 1),
-        "target_sharding": "contiguous runs of the target's Morton order over %d rank(s)" % world,
+        "target_sharding": "cells of a recursive bisection of the target (probreg_amd.dist.bisection_shards) over %d rank(s)" % world,
         "collective": (("1 ncclAllReduce (RCCL, issued by libprobreg_hip.so on the plan's stream) of the moment block's 24 fp64 sums per iteration"
                         if getattr(plan, "_comm", None) is not None else
                         "1 torch.distributed all_reduce (%s) of 32 fp64 per iteration" % torch.distributed.get_backend())

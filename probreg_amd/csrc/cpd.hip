@@ -1275,7 +1275,7 @@ int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int*
             }
         }
     }
-    const std::vector<int> perm = prg::morton_order(host.data(), n, dim);
+    const std::vector<int> perm = prg::spatial_order(host.data(), n, dim);
     if (*perm_dev) (void)hipFree(*perm_dev);
     *perm_dev = nullptr;
     PRG_HIP(hipMalloc((void**)perm_dev, (size_t)n * sizeof(int)));
@@ -1825,7 +1825,8 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // the residual-form single sweep on the vector pipe: the same callers as the fused sweep, any sigma2, no
     // matrix cores needed - 6 floats per (plane, column) + a touched flag per (128-column block, plane), or 6 x 128 floats per unit
     const bool allow_resid = use_cull && h->resid_sweep && h->moments_only && !h->nonrigid && !h->bcpd && !h->srcw && h->init_rot_orthonormal;
-    const int64_t resid_elems = allow_resid ? std::max<int64_t>((int64_t)3 * PA * h->Ncap + (prg::ceil_div(h->N, 128) * PA + 64) / 8 + 8, 3 * qcol_elems) : 0;
+    // (sized for the engine that can run: with the work queue the vector pipe's column pass never goes through the grid of planes)
+    const int64_t resid_elems = !allow_resid ? 0 : use_queue ? 3 * qcol_elems : (int64_t)3 * PA * h->Ncap + (prg::ceil_div(h->N, 128) * PA + 64) / 8 + 8;
     PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems,
                           std::max<int64_t>(std::max<int64_t>(std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems), fused_elems), resid_elems)));
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems,
@@ -2209,6 +2210,8 @@ int prg_cpd_mstep(prg_cpd* h, int kind, int update_scale) {
     prg::DeviceGuard g(h->device);
     k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
     PRG_HIP(hipGetLastError());
+    // the single sweeps map their column-side sums back through s R: only a rigid fit leaves a rotation in the parameter block
+    h->init_rot_orthonormal = kind == PRG_TF_RIGID;
     return PRG_OK;
 }
 
@@ -2225,7 +2228,10 @@ int prg_cpd_iterate(prg_cpd* h, int kind, int update_scale, double w, int n_iter
     int st = PRG_OK;
     for (int it = 0; it < n_iter && st == PRG_OK; ++it) {
         st = estep_impl(h, w, nullptr);  // (ends with the all-reduce when a communicator is attached)
-        if (st == PRG_OK) k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
+        if (st == PRG_OK) {
+            k_mstep<<<1, 64, 0, h->stream>>>(h->moments, h->params, kind, update_scale, h->D);
+            h->init_rot_orthonormal = kind == PRG_TF_RIGID;  // (an affine fit leaves a general B: no single sweeps from it)
+        }
     }
     h->moments_only = keep;
     PRG_TRY(st);
@@ -2331,7 +2337,9 @@ int prg_cpd_moments_from_estep(prg_cpd* h, const double* pt1_hd, const double* p
                                                          h->perm_tgt, h->rowacc, h->pt1);
     PRG_HIP(hipGetLastError());
     PRG_HIP(hipStreamSynchronize(h->stream));
-    h->have_estep = true;  // rowacc / MOMENTS now hold an E-step result (the caller's)
+    h->have_estep = true;  // rowacc / MOMENTS now hold an E-step result (the caller's): all 24 moments and the per-point block
+    h->last_estep_fused = false;
+    h->rowacc_valid = true;
     return PRG_OK;
 }
 

@@ -1,8 +1,8 @@
 """Target sharding across the GPUs of one node (one process per GPU, torch.distributed / RCCL).
 
 The reference is single-process; this is the new data-parallel layer of SURVEY.md section 8(e):
-every rank keeps the whole source cloud, owns a spatially compact block of target rows (a contiguous
-run of the target's Morton order) and all-reduces
+every rank keeps the whole source cloud, owns a spatially compact block of target rows (one cell of a
+recursive bisection of the target) and all-reduces
 the 32-double moment block once per EM iteration (rigid / affine), or the per-point fp64 block
 (non-rigid).  With the ``gloo`` backend the same helpers work on CPU tensors (used by the tests).
 
@@ -74,20 +74,52 @@ def morton_order(points):
     return np.argsort(code, kind="stable")
 
 
-def spatial_shard(target, rank, world_size):
-    """Row indices of ``target`` owned by ``rank``: a contiguous run of the cloud's Morton order.
+def _shard_start(n, rank, world_size):
+    base, rem = divmod(int(n), int(world_size))
+    return rank * base + min(rank, rem)
 
-    Every rank holds the whole target (the reference API passes full arrays), so all ranks derive the same order
-    and take their slice of it.  A shard is then a spatially compact patch: the culled sweeps of a rank skip
+
+def bisection_shards(points, world_size):
+    """Row indices of every rank's shard: recursive bisection of the cloud across the widest axis of the current cell, the
+    ranks split in halves and the points in proportion (shard sizes are ``shard_bounds``'s: near-equal counts).  Every shard is
+    ONE axis-aligned cell of the cloud for any world size - a contiguous run of a space-filling curve can be two pieces
+    either side of one of the curve's jumps.  Deterministic (stable sorts; ties keep the caller's order)."""
+    p = np.asarray(points, dtype=np.float64)
+    n = p.shape[0]
+    out = [None] * int(world_size)
+    stack = [(np.arange(n), 0, int(world_size))]
+    while stack:
+        idx, r0, r1 = stack.pop()
+        if r1 - r0 == 1:
+            out[r0] = np.sort(idx)
+            continue
+        mid = (r0 + r1) // 2
+        cnt = _shard_start(n, mid, world_size) - _shard_start(n, r0, world_size)
+        q = p[idx]
+        ax = int(np.argmax(q.max(axis=0) - q.min(axis=0))) if len(idx) else 0
+        order = np.argsort(q[:, ax], kind="stable")
+        stack.append((idx[order[:cnt]], r0, mid))
+        stack.append((idx[order[cnt:]], mid, r1))
+    return out
+
+
+def spatial_shard(target, rank, world_size):
+    """Row indices of ``target`` owned by ``rank``: one cell of a recursive bisection of the cloud (``bisection_shards``).
+
+    Every rank holds the whole target (the reference API passes full arrays), so all ranks derive the same cut
+    and take their part of it.  A shard is then a spatially compact patch: the culled sweeps of a rank skip
     everything far from its patch, exactly as a single GPU does for one wave's points - a shard in the caller's
     order would be spread over the whole object and lose most of the culling in late EM iterations.  With one
-    rank the order is left alone (the plan sorts on upload anyway).
+    rank the order is left alone (the plan sorts on upload anyway).  ``PROBREG_SHARD_CUT=morton`` restores the cut of
+    rounds 2 - 5 (contiguous runs of the target's Z-curve) for A/B runs.
     """
     n = np.asarray(target).shape[0]
     lo, hi = shard_bounds(n, rank, world_size)
     if world_size == 1:
         return np.arange(lo, hi)
-    return morton_order(target)[lo:hi]
+    if os.environ.get("PROBREG_SHARD_CUT", "") == "morton":
+        return morton_order(target)[lo:hi]
+    return bisection_shards(target, world_size)[rank]
 
 
 def all_reduce_sum_(tensor, stream=None):
@@ -195,15 +227,31 @@ class NativeComm(object):
 
 
 _native = {}  # (device, process-group identity) -> NativeComm or None (None: tried and given up - every rank took the same decision)
+_pg_seen = []  # [(group object, generation)]: the object is KEPT so that its id() cannot be handed to a later group
+_pg_generation = [0]
 
 
 def _pg_key():
-    """Identity of the default process group (None without one): the collective decision below is taken once per group."""
+    """Identity of the default process group (None without one): the collective decision below is taken once per group.
+
+    A generation number, bumped whenever ``torch.distributed.group.WORLD`` is an object this module has not seen: an ``id()``
+    alone can be recycled after ``destroy_process_group`` + ``init_process_group``, and the cache would then hand out a
+    communicator bound to the dead group.  Entries of earlier groups are closed and dropped as soon as a new one shows up.
+    """
     if not initialized():
         return None
     import torch.distributed as tdist
 
-    return (id(tdist.group.WORLD), tdist.get_backend(), tdist.get_world_size())
+    grp = tdist.group.WORLD
+    if not _pg_seen or _pg_seen[-1][0] is not grp:
+        _pg_generation[0] += 1
+        del _pg_seen[:]
+        _pg_seen.append((grp, _pg_generation[0]))
+        for key in [k for k in _native if k[1] is not None]:  # communicators of a group that is gone
+            c = _native.pop(key)
+            if c is not None:
+                c.close()
+    return (_pg_seen[-1][1], tdist.get_backend(), tdist.get_world_size())
 
 
 def native_comm(device):
@@ -311,6 +359,7 @@ def reset_native_comms():
         if c is not None:
             c.close()
     _native.clear()
+    del _pg_seen[:]
 
 
 import atexit  # noqa: E402

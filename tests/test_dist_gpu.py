@@ -140,14 +140,25 @@ def _bench_line(args, extra_env, timeout=900):
     return json.loads(lines[0])
 
 
+_COMMON = ["--steps", "6", "--warmup", "1", "--workload", "rigid_20k", "--no-cpu-baseline", "--no-other-workloads"]
+_PLAIN = {}
+
+
+def _plain_line():
+    """The one-rank line of the reduced workload, run ONCE for the launcher tests below (every `python bench.py` is a fresh
+    process that pays for `import torch` - on a cold box a minute each)."""
+    if "line" not in _PLAIN:
+        _PLAIN["line"] = _bench_line(["--gpus", "1"] + _COMMON, {})
+    return _PLAIN["line"]
+
+
 def test_bench_gpus_2_starts_two_ranks_by_itself():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks itself and report n_gpus = 2
     (round 3: --gpus was parsed and ignored - an 8-GPU scaling run would have recorded one rank).  One GPU here, so both
     ranks share it and the collective is gloo's; launcher, sharding, per-iteration all-reduce and the line are the code an
     8-GPU node runs.  The EM state after the window must be the 1-rank run's."""
-    common = ["--steps", "6", "--warmup", "1", "--workload", "rigid_20k", "--no-cpu-baseline", "--no-other-workloads"]
-    one = _bench_line(["--gpus", "1"] + common, {})
-    two = _bench_line(["--gpus", "2"] + common, {"PROBREG_SHARE_GPU": "1", "PROBREG_DIST_BACKEND": "gloo"})
+    one = _plain_line()
+    two = _bench_line(["--gpus", "2"] + _COMMON, {"PROBREG_SHARE_GPU": "1", "PROBREG_DIST_BACKEND": "gloo"})
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["n_local"] * 2 == two["config"]["n_global"]
     assert "gloo" in two["config"]["collective"]
@@ -216,8 +227,7 @@ def test_library_side_rccl_all_reduce_one_rank():
 def test_nccl_process_group_selects_the_library_side_collective():
     """A (single-rank) nccl process group: `bench.py` must report the library-side RCCL collective in its line - the path an
     8-GPU run takes - and reproduce the run without any process group."""
-    common = ["--gpus", "1", "--steps", "6", "--warmup", "1", "--workload", "rigid_20k", "--no-cpu-baseline", "--no-other-workloads"]
-    plain = _bench_line(common, {})
-    forced = _bench_line(common, {"PROBREG_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())})
+    plain = _plain_line()
+    forced = _bench_line(["--gpus", "1"] + _COMMON, {"PROBREG_FORCE_DIST": "1", "MASTER_PORT": str(_free_port())})
     assert forced["config"]["collective_path"].startswith("library-side RCCL"), forced["config"]
     assert forced["result"]["sigma2"] == plain["result"]["sigma2"] and forced["result"]["q"] == plain["result"]["q"]

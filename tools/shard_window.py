@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""What ONE rank of N does over the bench window (EM iterations 0..K-1 of C1), measured on one GPU: the unsharded registration
-is run once and its parameter block saved before every iteration; rank 0's shard of the target (its run of the Morton order,
-probreg_amd.dist.spatial_shard) is then put in each of those states and timed back to back (no host synchronisation in between):
+"""What EVERY rank of N does over the bench window (EM iterations 0..K-1 of C1), measured on one GPU: the unsharded registration
+is run once and its parameter block saved before every iteration; each rank's shard of the target (its part of the spatial order,
+probreg_amd.dist.spatial_shard) is then put in each of those states and timed back to back (no host synchronisation in between);
+an N-rank iteration is priced at its SLOWEST rank (the per-iteration all-reduce is a barrier) and the projection is made from that:
 
   E-step        prg_cpd_estep alone (round 3's table)
   iteration     the whole EM iteration as a rank issues it: prg_cpd_estep ending with the library's own ncclAllReduce of the
@@ -70,9 +71,12 @@ def timed(fn):
     return (time.perf_counter() - t0) / REPS * 1e3
 
 
-estep_ms, iter_ms, copy_ms = {}, {}, {}
-for world in (1, 2, 4, 8):
-    rows = dist.spatial_shard(tgt, 0, world) if world > 1 else np.arange(n)
+ALL_RANKS = os.environ.get("SHARD_WINDOW_ALL_RANKS", "1") != "0"   # 0: rank 0 only (rounds 3 - 5)
+
+
+def replay(world, rank):
+    """(E-step ms, whole-iteration ms, copy ms) per EM iteration of `rank`'s shard of `world`."""
+    rows = dist.spatial_shard(tgt, rank, world) if world > 1 else np.arange(n)
     p2 = engine.CpdPlan()
     p2.set_source(src - cy)
     p2.set_target(tgt[rows] - cx, n_global=n)
@@ -98,25 +102,48 @@ for world in (1, 2, 4, 8):
 
         its.append(timed(iteration))
         cps.append(timed(lambda: view.copy_(saved)))
-    estep_ms[world], iter_ms[world], copy_ms[world] = es, its, cps
     p2.set_comm(None)
     p2.close()
+    return es, its, cps
 
-print("# rank 0 of N, %s N=M=%d, EM iterations 0..%d, back to back on one MI355X (ms)" % ("RigidCPD" if KIND == "rigid" else "AffineCPD", n, K - 1))
-print("# E-step alone | whole iteration = E-step + ncclAllReduce(32 fp64, 1-rank communicator, plan's stream) + M-step, minus the state-restoring copy")
-print("%3s %9s %9s %9s %9s | %9s %9s %9s %9s" % ("it", "1 rank", "2 ranks", "4 ranks", "8 ranks", "1 rank", "2 ranks", "4 ranks", "8 ranks"))
-full = {w: [a - c for a, c in zip(iter_ms[w], copy_ms[w])] for w in iter_ms}
+
+WORLDS = (1, 2, 4, 8)
+per_rank = {}   # (world, rank) -> (E-step, whole iteration minus the copy) per EM iteration
+copy_us = []
+for world in WORLDS:
+    for rank in range(world if ALL_RANKS else 1):
+        if world > 1:
+            REPS = 12 if n <= 100000 else 6
+        es, its, cps = replay(world, rank)
+        per_rank[(world, rank)] = (np.array(es), np.array(its) - np.array(cps))
+        copy_us.append(1e3 * float(np.mean(cps)))
+
+name = "RigidCPD" if KIND == "rigid" else "AffineCPD"
+print("# %s N=M=%d, EM iterations 0..%d, every rank's shard of 1 / 2 / 4 / 8 replayed back to back on one MI355X (ms)" % (name, n, K - 1))
+print("# an iteration of an N-rank run lasts as long as its SLOWEST rank (the all-reduce is a barrier): per iteration the MAX over the")
+print("# ranks' whole iterations = E-step + ncclAllReduce(32 fp64, 1-rank communicator, plan's stream) + M-step, minus the state-restoring copy;")
+print("# skew = max / mean over the ranks of that iteration (1.00: perfectly balanced shards)")
+ranks_of = {w: [r for r in range(w) if (w, r) in per_rank] for w in WORLDS}
+mx = {w: np.max([per_rank[(w, r)][1] for r in ranks_of[w]], axis=0) for w in WORLDS}
+mean = {w: np.mean([per_rank[(w, r)][1] for r in ranks_of[w]], axis=0) for w in WORLDS}
+emx = {w: np.max([per_rank[(w, r)][0] for r in ranks_of[w]], axis=0) for w in WORLDS}
+print("%3s %9s %9s %9s %9s | %6s %6s %6s | %9s" % ("it", "1 rank", "2 ranks", "4 ranks", "8 ranks", "skew2", "skew4", "skew8", "8: rank 0"))
 for it in range(K):
-    print("%3d %9.3f %9.3f %9.3f %9.3f | %9.3f %9.3f %9.3f %9.3f" % ((it,) + tuple(estep_ms[w][it] for w in (1, 2, 4, 8))
-                                                                      + tuple(full[w][it] for w in (1, 2, 4, 8))))
-te = {w: sum(estep_ms[w]) for w in estep_ms}
-tf = {w: sum(full[w]) for w in full}
-print("sum %9.3f %9.3f %9.3f %9.3f | %9.3f %9.3f %9.3f %9.3f" % (tuple(te[w] for w in (1, 2, 4, 8)) + tuple(tf[w] for w in (1, 2, 4, 8))))
-print("# state-restoring copy (subtracted): %.1f us mean; fixed work per iteration beyond the E-step (collective launch + kernel, M-step): "
-      "1 rank %.1f us, 8 ranks %.1f us" % (1e3 * np.mean(copy_ms[8]), 1e3 * (tf[1] - te[1]) / K, 1e3 * (tf[8] - te[8]) / K))
-print("# E-step only:          2 ranks %.2fx  4 ranks %.2fx  8 ranks %.2fx" % tuple(te[1] / te[w] for w in (2, 4, 8)))
+    print("%3d %9.3f %9.3f %9.3f %9.3f | %6.3f %6.3f %6.3f | %9.3f" % (
+        (it,) + tuple(mx[w][it] for w in WORLDS) + tuple(mx[w][it] / mean[w][it] for w in (2, 4, 8)) + (per_rank[(8, 0)][1][it],)))
+tf = {w: float(np.sum(mx[w])) for w in WORLDS}
+te = {w: float(np.sum(emx[w])) for w in WORLDS}
+print("sum %9.3f %9.3f %9.3f %9.3f | %6.3f %6.3f %6.3f | %9.3f" % (
+    tuple(tf[w] for w in WORLDS) + tuple(tf[w] / float(np.sum(mean[w])) for w in (2, 4, 8)) + (float(np.sum(per_rank[(8, 0)][1])),)))
+print("# per rank of 8, sum over the window (ms): " + "  ".join("%d: %.3f" % (r, float(np.sum(per_rank[(8, r)][1]))) for r in ranks_of[8]))
+print("# state-restoring copy (subtracted): %.1f us mean; E-step alone, max over ranks, summed: %s" % (
+    float(np.mean(copy_us)), "  ".join("%d ranks %.3f" % (w, te[w]) for w in WORLDS)))
+print("# E-step only (max over ranks):          2 ranks %.2fx  4 ranks %.2fx  8 ranks %.2fx" % tuple(te[1] / te[w] for w in (2, 4, 8)))
 for peer_us in (0.0, 10.0, 20.0, 30.0):
-    line = "# whole iterations, + %2.0f us of peer latency per all-reduce (NOT measurable on one GPU):" % peer_us
+    line = "# whole iterations (max over ranks), + %2.0f us of peer latency per all-reduce (NOT measurable on one GPU):" % peer_us
     for w in (2, 4, 8):
         line += "  %d ranks %.2fx" % (w, tf[1] / (tf[w] + peer_us * 1e-3 * K))
     print(line)
+if ALL_RANKS:
+    r0 = {w: float(np.sum(per_rank[(w, 0)][1])) for w in WORLDS}
+    print("# (rank 0 alone, as rounds 3 - 5 projected:  2 ranks %.2fx  4 ranks %.2fx  8 ranks %.2fx)" % tuple(r0[1] / r0[w] for w in (2, 4, 8)))
