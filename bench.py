@@ -83,8 +83,11 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
     from oracle import cpd_c, cpd_numpy as co
     from probreg_amd import cpd, synthetic
 
-    sizes, iters = (10000, 20000, 40000), 2
+    # [r6] 20k / 40k / 60k after one untimed call (the OpenMP pool's start-up sat in the 10k point of round 5's fit: +71 %)
+    sizes, iters = (20000, 40000, 60000), 2
     per_iter, last = [], None
+    w_src, w_tgt, _ = synthetic.rigid_pair(4000, seed=0)
+    cpd_c.expectation_step(w_src, w_tgt, co.squared_kernel_sum_closed_form(w_src, w_tgt), 0.0)
     for ns in sizes:
         src, tgt, _ = synthetic.rigid_pair(ns, seed=0)
         sigma2 = co.squared_kernel_sum_closed_form(src, tgt)
@@ -106,14 +109,14 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
         "cores": cpd_c.threads(),
         "kind": "port",
         "sample": "oracle/cpd_estep_c.c (C/OpenMP fp64 restatement of probreg cpd.py:71-88) + numpy M-step, RigidCPD "
-                  "N=M in {10k, 20k, 40k}, %d iterations each; fit t_iter = a*M*N, value = 1/(a*%d^2) (extrapolated)"
-                  % (iters, n_full),
+                  "N=M in %s, %d iterations each; fit t_iter = a*M*N, value = 1/(a*%d^2) (extrapolated)"
+                  % (list(sizes), iters, n_full),
         "fit": {"a_seconds_per_pair": a, "sizes": list(sizes), "s_per_iteration": per_iter,
                 "relative_residuals": resid},
         "reference_numpy_probe": REFERENCE_NUMPY_PROBE,
     }
     baseline["reference_numpy"] = reference_numpy_baseline(n_full)
-    # parity: the product on the SAME 40k input for the SAME number of iterations
+    # parity: the product on the SAME input (the largest sample) for the SAME number of iterations
     src, tgt, p, s2 = last
     res = cpd.registration_cpd(src, tgt, "rigid", maxiter=iters, tol=-1.0)
     tr = res.transformation

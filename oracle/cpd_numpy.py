@@ -50,6 +50,13 @@ def squared_kernel_sum_closed_form(x, y):
     y = np.asarray(y, dtype=np.float64)
     m, d = x.shape
     n = y.shape[0]
+    # [r6] both clouds are shifted by ONE common point first (the quantity is a sum of squared DIFFERENCES: translation does not
+    # change it): with clouds ~1000 units from the origin the three terms are ~1e15 and their difference ~1e9 - the un-shifted
+    # identity lost 4e-7 there (tools/far_offset_bisect.py; the reference itself sums the differences, math_utils.py:28-29),
+    # and ten EM iterations carried that to 5e-6 in sigma2: the round-5 fuzz's two worst cases were the oracle's, not the GPU's
+    c = (x.sum(axis=0) + y.sum(axis=0)) / (m + n)
+    x = x - c
+    y = y - c
     return (n * np.sum(x * x) + m * np.sum(y * y) - 2.0 * np.dot(x.sum(axis=0), y.sum(axis=0))) / (m * d * n)
 
 

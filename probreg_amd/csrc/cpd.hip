@@ -163,10 +163,15 @@ __device__ __forceinline__ float half_max(float v) {
 // Writes the boxes of the 8 groups of 32 points this workgroup holds (one point per thread): lo.xyz, hi.xyz, max aux,
 // min aux.  write_boxes == false: only the aux range is refreshed (the boxes of a static cloud were written at upload).
 __device__ __forceinline__ void block_group_meta(float x, float y, float z, float wmax_in, float wmin_in,
-                                                 bool write_boxes, float* __restrict__ gmeta) {
+                                                 bool write_boxes, float* __restrict__ gmeta, float* box_out = nullptr,
+                                                 bool real = true) {
     float v[8];
-    v[0] = half_min(x); v[1] = half_min(y); v[2] = half_min(z);
-    v[3] = half_max(x); v[4] = half_max(y); v[5] = half_max(z);
+    // (real == false: a pad; a group of real points and pads gets the box of its real points, an all-pad group the pads' own)
+    v[0] = half_min(real ? x : INFINITY); v[1] = half_min(real ? y : INFINITY); v[2] = half_min(real ? z : INFINITY);
+    v[3] = half_max(real ? x : -INFINITY); v[4] = half_max(real ? y : -INFINITY); v[5] = half_max(real ? z : -INFINITY);
+    if (v[0] == INFINITY) {
+        v[0] = v[3] = x; v[1] = v[4] = y; v[2] = v[5] = z;
+    }
     v[6] = half_max(wmax_in);
     v[7] = half_min(wmin_in);
     if ((threadIdx.x & 31) == 0) {
@@ -175,6 +180,9 @@ __device__ __forceinline__ void block_group_meta(float x, float y, float z, floa
         for (int c = 0; c < 8; ++c)
             if (write_boxes || c >= 6) o[c] = v[c];
     }
+    if (box_out)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) box_out[c] = v[c];
 }
 
 // z = scale * L y + t in fp64, rounded once to fp32 (transformation.py:49-50 / 77-78).  The same kernel measures
@@ -185,7 +193,8 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
                                                              unsigned* __restrict__ motion, int slot,
                                                              float* __restrict__ gmeta,
                                                              const float* __restrict__ srcw,
-                                                             const double* __restrict__ disp) {
+                                                             const double* __restrict__ disp,
+                                                             float* __restrict__ cmeta) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     float moved = 0.f;
     float4 o;
@@ -215,9 +224,17 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
     // slot (next E-step's) is cleared here - nobody touches it until the next launch of this kernel
     // (one atomic per workgroup: ~1600 same-address atomics from every wave cost more than the rest of the kernel)
     __shared__ float wave_moved[kBlock / 64];
+    __shared__ float half_box[kBlock / 32][6];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) moved = fmaxf(moved, __shfl_xor(moved, off, 64));
     if ((threadIdx.x & 63) == 0) wave_moved[threadIdx.x >> 6] = moved;
+    // the boxes of the block's 8 groups of 32 points, and - the block IS one 256-point chunk of the stream - their union: the box
+    // of the chunk (zchunk; level 1 of the owner sweep's hierarchy, cpd_sweeps_owner.hip, in every regime)
+    float gb[6];
+    block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta, gb, i < m);
+    if ((threadIdx.x & 31) == 0)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) half_box[threadIdx.x >> 5][c] = gb[c];
     __syncthreads();
     if (threadIdx.x == 0) {
         float mv = wave_moved[0];
@@ -225,11 +242,16 @@ __global__ __launch_bounds__(kBlock) void k_transform_linear(const float4* __res
         for (int k = 1; k < kBlock / 64; ++k) mv = fmaxf(mv, wave_moved[k]);
         if (mv > 0.f) atomicMax(motion + slot, __float_as_uint(mv));
     }
+    if (threadIdx.x < 6 && cmeta) {
+        float v = half_box[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < kBlock / 32; ++k) v = threadIdx.x < 3 ? fminf(v, half_box[k][threadIdx.x]) : fmaxf(v, half_box[k][threadIdx.x]);
+        cmeta[(int64_t)blockIdx.x * 8 + threadIdx.x] = v;
+    }
     if (i == 0) {
         motion[slot ^ 1] = 0u;
         motion[4 + slot] = 0u;  // k_colfinal of THIS E-step collects the largest column minimum here
     }
-    block_group_meta(o.x, o.y, o.z, 0.f, 0.f, true, gmeta);
 }
 
 // bounding box (+ range of .w) of every group of 32 consecutive points -> meta[g][8] = lo.xyz, hi.xyz, max w, min w
@@ -240,8 +262,12 @@ __global__ __launch_bounds__(kBlock) void k_group_meta(const float4* __restrict_
     const float4* p = pts + g * prg::kGroup;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, wmax = -INFINITY,
           wmin = INFINITY;
+    // a group that holds real points AND pads (the last real group of a cloud) gets the box of its real points: a pad never
+    // contributes to any sum, and a box that reaches out to the pads (1e18 away) makes its owner need every cell of the other cloud
+    const bool mixed = fabsf(p[0].x) < 1e17f && !(fabsf(p[prg::kGroup - 1].x) < 1e17f);  // (pads fill the tail)
     for (int k = 0; k < prg::kGroup; ++k) {
         const float4 v = p[k];
+        if (mixed && !(fabsf(v.x) < 1e17f)) continue;
         lo[0] = fminf(lo[0], v.x); hi[0] = fmaxf(hi[0], v.x);
         lo[1] = fminf(lo[1], v.y); hi[1] = fmaxf(hi[1], v.y);
         lo[2] = fminf(lo[2], v.z); hi[2] = fmaxf(hi[2], v.z);
@@ -1562,7 +1588,8 @@ int prg_cpd_last_estep_engine(prg_cpd* h, int* engine) {
 
 int prg_cpd_set_sparse_engine(prg_cpd* h, int mode) {
     PRG_REQUIRE(h, PRG_ERR_INVALID, "prg_cpd_set_sparse_engine: NULL handle");
-    PRG_REQUIRE(mode >= 0 && mode <= 2, PRG_ERR_INVALID, "prg_cpd_set_sparse_engine: mode must be 0 (grid of culled waves), 1 (work queue for large clouds) or 2 (work queue always)");
+    PRG_REQUIRE(mode >= 0 && mode <= 3, PRG_ERR_INVALID, "prg_cpd_set_sparse_engine: mode must be 0 (grid of culled waves), 1 (default: owner sweep for single-sweep "
+                "iterations, work queue for the two-sweep E-steps of large clouds), 2 (work queue always) or 3 (round 5's default: queue for large clouds, no owner sweep)");
     h->sparse_engine = mode;
     return PRG_OK;
 }
@@ -1818,15 +1845,21 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // sparse regime: sweeps over a device-built work queue (cpd_sweeps_queue.hip) - partial results per unit, not per plane
     // ... when both clouds are large: the queue costs a build pass and leaves more partial results than the grid of culled
     // waves, which only pays off while a sweep is long (measured at C1: ahead with the target on 1 or 2 ranks, behind on 4 and 8)
-    const bool use_queue = use_cull && (h->sparse_engine == 2 || (h->sparse_engine == 1 && h->M >= 32768 && h->N >= 32768));
+    const bool use_queue = use_cull && (h->sparse_engine == 2 || ((h->sparse_engine == 1 || h->sparse_engine == 3) && h->M >= 32768 && h->N >= 32768));
     const int64_t qcol_elems = use_queue ? prg::queue_max_units(h->N, h->M) * 128 : 0,
                   qrow_elems = use_queue ? prg::queue_max_units(h->M, h->N) * 640 : 0;
     const int64_t fused_elems = allow_fused ? (int64_t)3 * std::max(prg::mfma_planes(h->N, h->M, mfma_seg), prg::mfma_planes(h->N, h->M, seg_col_fine)) * h->Ncap : 0;  // 6 floats per (plane, column)
     // the residual-form single sweep on the vector pipe: the same callers as the fused sweep, any sigma2, no
     // matrix cores needed - 6 floats per (plane, column) + a touched flag per (128-column block, plane), or 6 x 128 floats per unit
     const bool allow_resid = use_cull && h->resid_sweep && h->moments_only && !h->nonrigid && !h->bcpd && !h->srcw && h->init_rot_orthonormal;
+    // ... which the column block's owner runs ([r6] cpd_sweeps_owner.hip: the stream dealt out over PO parts x 8 waves per 128-column
+    // block, cells found through the chunk / group hierarchy; prg_cpd_set_sparse_engine(0 / 2 / 3): round 5's grid / queue instead)
+    static const bool owner_env_off = getenv("PRG_OWNER_SWEEP") && atoi(getenv("PRG_OWNER_SWEEP")) == 0;
+    const bool use_owner = allow_resid && h->sparse_engine == 1 && !owner_env_off;
+    const int PO = use_owner ? prg::owner_planes(h->N, h->M) : 0;
     // (sized for the engine that can run: with the work queue the vector pipe's column pass never goes through the grid of planes)
-    const int64_t resid_elems = !allow_resid ? 0 : use_queue ? 3 * qcol_elems : (int64_t)3 * PA * h->Ncap + (prg::ceil_div(h->N, 128) * PA + 64) / 8 + 8;
+    const int64_t resid_elems = !allow_resid ? 0 : use_owner ? (int64_t)3 * PO * h->Ncap + (prg::ceil_div(h->N, 128) * PO + 64) / 8 + 8
+                                : use_queue ? 3 * qcol_elems : (int64_t)3 * PA * h->Ncap + (prg::ceil_div(h->N, 128) * PA + 64) / 8 + 8;
     PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems,
                           std::max<int64_t>(std::max<int64_t>(std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems), fused_elems), resid_elems)));
     PRG_TRY(ensure_buffer(&h->rowpart, &h->rowpart_elems,
@@ -1835,7 +1868,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (use_queue) PRG_TRY(prg::prepare_queues(h));
     if (use_cull) {  // per-workgroup counters of evaluated (wave, group) blocks (prg_cpd_pair_counts)
         const int64_t need = std::max<int64_t>(
-            std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->M, 128) * PB),
+            std::max<int64_t>(prg::ceil_div(h->N, 128) * std::max(PA, PO), prg::ceil_div(h->M, 128) * PB),
             std::max<int64_t>(prg::ceil_div(h->N, prg::kMfmaWgPoints) * PAm, prg::ceil_div(h->M, prg::kMfmaWgPoints) * PBm));
         if (need > h->wg_cap) {
             if (h->wgcount) {
@@ -1857,7 +1890,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const double* disp = h->bcpd ? h->W : nullptr;
     if (h->nonrigid) PRG_TRY(prg::nonrigid_displacement(h, &disp));
     k_transform_linear<<<(unsigned)prg::ceil_div(h->M, kBlock), kBlock, 0, h->stream>>>(
-        h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw, disp);  // pad-only blocks are static
+        h->src4, h->z4, h->M, h->params, h->motion, slot, h->zmeta, h->srcw, disp, h->zchunk);  // pad-only blocks are static
     // Dense regime on the matrix cores?  Decided per E-step from numbers only the device has at this point - sigma2, the
     // source motion of this transform, the largest column minimum of the previous E-step - so the device
     // decides (last thread of k_chunk_meta_bbox) and the host neither reads back nor synchronises: it launches the column
@@ -1956,7 +1989,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
             prg::launch_fused_mfma(h, seg_col, !h->have_colmin, false, h->eng_dev);
         else if (pred)  // (stream mode if the previous decision found nothing to skip: the dense regime)
             prg::launch_colpass_mfma(h, seg_col, !h->have_colmin, false, h->eng_dev, h->mfma_stream && h->pred_fine == 0 && !h->mfma_grid_fine);
-        else if (!use_queue)
+        else if (!use_queue && !use_owner)
             prg::launch_colpass_cull(h, SA, segA, cull_seed, h->eng_dev, allow_resid);
         // (pred == vector pipe with the work queue: nothing goes out ahead - inside the dense regime that engine only runs
         // when the bracket of the column minima is too wide for the matrix-core offsets, a handful of E-steps at most)
@@ -1993,7 +2026,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         else if (pred)
             col_launched = use_mfma && !fused;
         else
-            col_launched = !use_mfma && !use_queue;
+            col_launched = !use_mfma && !use_queue && !use_owner;
         h->pred_col = use_mfma ? 1 : 0;
         h->pred_fine = fine_cull ? 1 : 0;
         h->pred_fused = fused ? 1 : 0;
@@ -2012,9 +2045,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     // (a single-sweep E-step has no row pass: nothing to report for it)
     h->last_estep_row_mfma = row_mfma && !fused && !resid;
     h->last_estep_row_lean = row_lean && !fused && !resid;
-    const bool col_queue = !col_launched && use_queue, row_queue = !row_mfma && use_queue;
+    const bool col_owner = !col_launched && resid && use_owner;
+    const bool col_queue = !col_launched && use_queue && !col_owner, row_queue = !row_mfma && use_queue;
     if (col_launched) {
-    } else if (col_queue)
+    } else if (col_owner)
+        prg::launch_colpass_owner(h, cull_seed, PO);
+    else if (col_queue)
         PRG_TRY(prg::launch_colpass_queue(h, cull_seed, h->qcol_live ? 0 : h->q_first_col, resid));
     else if (use_cull)
         prg::launch_colpass_cull(h, SA, segA, cull_seed, nullptr, resid);
@@ -2033,9 +2069,9 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
                                                                      h->params, w, m_over_n, h->D, h->colmin, h->colmin + h->Ncap, h->tmeta,
                                                                      h->motion, slot, nullptr, queue_view(h->qcol, true), h->mompart);
         else
-            k_colfinal_resid<false><<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), PA, h->Ncap, h->N, h->pt1,
+            k_colfinal_resid<false><<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), col_owner ? PO : PA, h->Ncap, h->N, h->pt1,
                                                                       h->params, w, m_over_n, h->D, h->colmin, h->colmin + h->Ncap, h->tmeta,
-                                                                      h->motion, slot, prg::resid_flags(h, PA), queue_view(h->qcol, false),
+                                                                      h->motion, slot, prg::resid_flags(h, col_owner ? PO : PA), queue_view(h->qcol, false),
                                                                       h->mompart);
         if (ev) {
             PRG_HIP(hipEventRecord(ev[3], h->stream));

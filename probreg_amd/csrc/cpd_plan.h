@@ -154,7 +154,8 @@ struct prg_cpd {
     double text2 = 0.0, sext2 = 0.0;  // squared bounding-box diagonals of the local target and of the source
     float tbox[6] = {0, 0, 0, 0, 0, 0};  // bounding box of the local target (lo.xyz, hi.xyz)
     // sparse regime: device-built work queues of the two sweeps; sparse_engine 1 = use them for the
-    // vector-pipe sweeps (default), 0 = the grid-per-(block, segment) culled sweeps of round 1
+    // vector-pipe sweeps of large clouds AND the owner sweep (cpd_sweeps_owner.hip) for single-sweep rigid iterations (default),
+    // 0 = the grid-per-(block, segment) culled sweeps of round 1, 2 = queue always, 3 = round 5's default (1 without the owner sweep)
     SweepQueue qcol, qrow;
     int sparse_engine = 1;
     bool qcol_live = false, qrow_live = false;  // the previous E-step's column / row pass ran over the queue (its unit size adapts from there)

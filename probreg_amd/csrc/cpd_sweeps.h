@@ -53,6 +53,13 @@ void launch_rowpass_mfma(prg_cpd* h, int S, bool fine, bool lean, bool stream); 
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  // 256-point chunks one workgroup walks
 
+// ---- the single sweep of a rigid iteration on the vector pipe, found and run by the column block's owner (cpd_sweeps_owner.hip) ----
+constexpr int kOwnerWaves = 8;       // waves of the workgroup that owns 128 columns
+constexpr int kOwnerMaxPlanes = 32;  // parts the stream is dealt out over per column block at most (partial planes of the merge)
+int owner_planes(int64_t owned_points, int64_t streamed_points);
+// (min, A, Ux, Uy, Uz, R) -> colpart[plane][6][Ncap] + touched flags (resid_flags): what k_colfinal_resid<false> reads
+void launch_colpass_owner(prg_cpd* h, bool use_seed, int planes);
+
 // ---- sparse-regime work queue (cpd_sweeps_queue.hip) ----
 constexpr int kQueueChunkGroups = 512;   // streamed groups (of 32 points) one wave of the build pass tests: 8 mask words
 constexpr int kQueueTargetUnits = 16384; // the units grow (8 -> 16 -> 32 groups) when a sweep had more than twice as many (~2 per wave slot)

@@ -67,7 +67,12 @@ def test_resid_sweep_moments_equal_the_two_sweep_engine(n, m, w, sparse, warm):
     assert abs((a[16] + a[19] + a[21]) - b[16]) < 2e-6 * n_p and np.all(b[17:22] == 0.0)   # tr Syy
     assert abs(a[22] - b[22]) < 2e-6 * n_p                          # sum pt1 |x|^2
     assert np.max(np.abs(out[2][1] - out[1][1])) < 1e-6             # pt1
-    assert out[2][3] == out[1][3]                                   # the same blocks of pairs evaluated
+    if sparse == 1:
+        # [r6] the default single sweep is the owner sweep (csrc/cpd_sweeps_owner.hip): the same boxes and bound, but the last
+        # column block's pad-only groups stay out of its box - never more pairs than the two-sweep column pass, a few less
+        assert 0.8 * out[2][3] <= out[1][3] <= out[2][3], (out[2][3], out[1][3])
+    else:
+        assert out[2][3] == out[1][3]                               # the same blocks of pairs evaluated
     pa, pb = out[2][2], out[1][2]
     assert np.max(np.abs(pa[:13] - pb[:13])) < 2e-6
     assert abs(pa[13] - pb[13]) <= 3e-6 * pa[13]

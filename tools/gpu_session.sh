@@ -41,6 +41,13 @@ case $step in
     python tools/shard_window.py 2>&1 | grep -v "$quiet" > $out/shard_window_c1_allranks.log
     [ -z "$SKIP_C2" ] && python tools/shard_window.py 200000 20 affine 2>&1 | grep -v "$quiet" > $out/shard_window_c2_allranks.log
     tail -8 $out/shard_window_c*_allranks.log ;;
+  shard_trace) # per-kernel cost of ONE rank's iteration:  shard_trace "8,3,19" "8,3,3" ...  (world,rank,iteration)
+    for spec in "$@"; do
+      name=$(echo $spec | tr ',' '_')
+      SHARD_TRACE=$spec rocprofv3 --kernel-trace --stats -d $out/kt_$name -o b -- python tools/shard_window.py $SHARD_ARGS > $out/trace_$name.log 2>&1
+      python tools/rocpd_summary.py $(ls $out/kt_$name/*.db $out/kt_$name/*/*.db 2>/dev/null | head -1) > $out/shard_trace_$name.txt
+      grep "^# rank" $out/trace_$name.log; head -16 $out/shard_trace_$name.txt
+    done ;;
   bench)      # the driver's own command
     python bench.py "$@" > $out/bench_default_line_1gpu.json 2> $out/bench.err; line $out/bench_default_line_1gpu.json ;;
   c1)         # C1 alone, with env A/B:  c1 NAME=value ...   (each assignment is one run)

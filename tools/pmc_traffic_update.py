@@ -8,7 +8,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = ([a for a in sys.argv[1:] if not a.startswith("--")] or ["r6"])[0]
 
 
 def table(name):
@@ -38,7 +38,7 @@ def sweep_entry(t, what):
         return int(round(sum(per[k] * calls[k] for k in keys) / tot)) if tot else None
 
     fused = [k for k in per if k.startswith("k_colpass_mfma<true")]       # the fused single sweep of a rigid iteration
-    resid = [k for k in per if k.startswith(("k_colpass_queue<true", "k_colpass_cull<true"))]  # ... and the residual-form one (round 5)
+    resid = [k for k in per if k.startswith(("k_colpass_queue<true", "k_colpass_cull<true", "k_colpass_owner"))]  # ... and the residual-form one (rounds 5, 6)
     dominant = fused + resid + [k for k in per if k.startswith("k_rowpass")]  # what bench.py's roofline is quoted on
     return {"rowpass_hbm_bytes_per_launch": mean("k_rowpass"), "colpass_hbm_bytes_per_launch": mean("k_colpass"),
             "fused_sweep_hbm_bytes_per_launch": mean_of(fused), "resid_sweep_hbm_bytes_per_launch": mean_of(resid),
@@ -69,13 +69,16 @@ if t:
                              "how": "sum over every kernel of an EM iteration of (2*FETCH_SIZE + WRITE_SIZE)*1024 x launches, "
                                     "divided by the number of iterations (launches of k_fr_terms); " + how % "filterreg_500k",
                              "round": int(tag[1:])}
-try:  # the code the passes were taken at (run this right after tools/profile_round.sh, before the next commit)
-    import subprocess
+# The code the passes were taken at.  [r6] The file is only written for a CLEAN tree of kernel sources: run the passes at a commit
+# (tools/profile_round.sh), then this script before anything under probreg_amd/ or include/ changes - with local modifications
+# there the traffic would be attributed to a commit that did not produce it, so the script refuses (--allow-dirty overrides and
+# records the fact).
+import subprocess
 
-    head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], universal_newlines=True).strip()
-    dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "probreg_amd", "include"], universal_newlines=True).strip())
-    out["_taken_at"] = {"commit": head, "kernel_sources_modified_since": dirty, "profiles_tag": tag}
-except Exception:
-    pass
+head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], universal_newlines=True).strip()
+dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "probreg_amd", "include"], universal_newlines=True).strip()
+if dirty and "--allow-dirty" not in sys.argv:
+    sys.exit("pmc_traffic_update: kernel sources differ from HEAD (%s):\n%s\ncommit (or stash) first, or pass --allow-dirty" % (head, dirty))
+out["_taken_at"] = {"commit": head, "kernel_sources_modified_since": bool(dirty), "profiles_tag": tag}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "how"} for k, v in out.items()}, indent=1))

@@ -107,6 +107,38 @@ def replay(world, rank):
     return es, its, cps
 
 
+if os.environ.get("SHARD_TRACE"):
+    # SHARD_TRACE=world,rank,iteration[,reps]: that one whole iteration (E-step + all-reduce + M-step) in a loop and nothing else -
+    # under `rocprofv3 --kernel-trace --stats` this is the per-kernel cost of one rank's iteration (tools/gpu_session.sh shard_trace)
+    f = [int(v) for v in os.environ["SHARD_TRACE"].split(",")]
+    world, rank, it = f[0], f[1], f[2]
+    reps = f[3] if len(f) > 3 else 200
+    rows = dist.spatial_shard(tgt, rank, world) if world > 1 else np.arange(n)
+    p2 = engine.CpdPlan()
+    p2.set_source(src - cy)
+    p2.set_target(tgt[rows] - cx, n_global=n)
+    p2.init_sums()
+    if KIND == "rigid":
+        p2.set_moments_only(1)
+    view = params_view(p2)
+    saved = torch.from_numpy(states[it].copy()).cuda()
+    for j in range(max(it - 2, 0), it):   # the engine's memory and the column minima of the iterations before
+        p2.set_params(states[j])
+        p2.estep(0.0)
+    p2.set_comm(comm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        view.copy_(saved)
+        p2.estep(0.0)
+        p2.mstep(KIND_ID, True)
+    torch.cuda.synchronize()
+    print("# rank %d of %d, EM iteration %d: %.4f ms per whole iteration (incl. the state-restoring copy), engine %s" % (
+        rank, world, it, (time.perf_counter() - t0) / reps * 1e3, p2.last_estep_engines()))
+    p2.set_comm(None)
+    p2.close()
+    sys.exit(0)
+
 WORLDS = (1, 2, 4, 8)
 per_rank = {}   # (world, rank) -> (E-step, whole iteration minus the copy) per EM iteration
 copy_us = []
