@@ -97,7 +97,10 @@ int prg_cpd_engine_bounds(int64_t m, int64_t n_local, double* col_bound, double*
  * the vector-pipe sweeps run over a device-built work queue (need-masks -> units -> persistent waves,
  * csrc/cpd_sweeps_queue.hip), smaller problems on the grid; 2 - the queue always; 0 - always one wave per (128-point block,
  * 512-point segment) whether it finds work or not (the culled sweeps of csrc/cpd_sweeps_packed.hip).  Same pairs, same
- * arithmetic, exact either way; tests / measurements. */
+ * arithmetic, exact either way; tests / measurements.  [r6] Under mode 1 the SINGLE sweep of a rigid iteration
+ * (prg_cpd_set_moments_only) is the owner sweep of csrc/cpd_sweeps_owner.hip wherever it runs on the vector pipe - the column
+ * block's workgroup finds its cells through the chunk / group hierarchy of the kd-ordered clouds, no queue, no build pass
+ * (DESIGN.md 3.1g); 3 - round 5's default: mode 1 without the owner sweep (the residual-form sweep over the queue / grid). */
 int prg_cpd_set_sparse_engine(prg_cpd* h, int mode);
 /* ... and for both sweeps of the last E-step: 1 = matrix cores, 0 = vector pipe (column pass, row pass).  An E-step that ran as a
  * single sweep (prg_cpd_last_estep_fused) has no row pass: row_engine and prg_cpd_last_estep_lean report 0 for it. */

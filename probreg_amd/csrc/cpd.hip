@@ -596,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void k_colfinal_resid(float4* __restrict__ 
                                                            float* __restrict__ colmin, float* __restrict__ colmin_g,
                                                            float* __restrict__ gmeta, unsigned* __restrict__ stat, int slot,
                                                            const unsigned char* __restrict__ colflag, const QueueView qv,
-                                                           double* __restrict__ mompart) {
+                                                           double* __restrict__ mompart, int flag_shift) {
     const int64_t i_own = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (QUEUE) queue_reset(qv);
     const bool valid = i_own < n;
@@ -658,7 +658,8 @@ __global__ __launch_bounds__(kBlock) void k_colfinal_resid(float4* __restrict__ 
         }
     } else {
         // the wave's 64 columns lie in one 128-column block: lane l looks at the flag of plane p0 + l, a ballot gives the live planes
-        const unsigned char* __restrict__ fl = colflag + (i >> 7) * nseg;
+        // (flag_shift: log2 of the columns a flag stands for - 7, or 6 when the owner sweep ran with one column per lane)
+        const unsigned char* __restrict__ fl = colflag + (i >> flag_shift) * nseg;
         for (int p0 = 0; p0 < nseg; p0 += 64) {
             unsigned long long live = __ballot(p0 + lane < nseg && fl[p0 + lane] != 0);
             while (live) {
@@ -1858,7 +1859,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     const bool use_owner = allow_resid && h->sparse_engine == 1 && !owner_env_off;
     const int PO = use_owner ? prg::owner_planes(h->N, h->M) : 0;
     // (sized for the engine that can run: with the work queue the vector pipe's column pass never goes through the grid of planes)
-    const int64_t resid_elems = !allow_resid ? 0 : use_owner ? (int64_t)3 * PO * h->Ncap + (prg::ceil_div(h->N, 128) * PO + 64) / 8 + 8
+    const int64_t resid_elems = !allow_resid ? 0 : use_owner ? (int64_t)3 * PO * h->Ncap + (prg::ceil_div(h->N, 64) * PO + 64) / 8 + 8
                                 : use_queue ? 3 * qcol_elems : (int64_t)3 * PA * h->Ncap + (prg::ceil_div(h->N, 128) * PA + 64) / 8 + 8;
     PRG_TRY(ensure_buffer(&h->colpart, &h->colpart_elems,
                           std::max<int64_t>(std::max<int64_t>(std::max<int64_t>((int64_t)std::max(PA, PAm) * h->Ncap, qcol_elems), fused_elems), resid_elems)));
@@ -1868,7 +1869,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
     if (use_queue) PRG_TRY(prg::prepare_queues(h));
     if (use_cull) {  // per-workgroup counters of evaluated (wave, group) blocks (prg_cpd_pair_counts)
         const int64_t need = std::max<int64_t>(
-            std::max<int64_t>(prg::ceil_div(h->N, 128) * std::max(PA, PO), prg::ceil_div(h->M, 128) * PB),
+            std::max<int64_t>(std::max<int64_t>(prg::ceil_div(h->N, 128) * PA, prg::ceil_div(h->N, 64) * PO), prg::ceil_div(h->M, 128) * PB),
             std::max<int64_t>(prg::ceil_div(h->N, prg::kMfmaWgPoints) * PAm, prg::ceil_div(h->M, prg::kMfmaWgPoints) * PBm));
         if (need > h->wg_cap) {
             if (h->wgcount) {
@@ -2067,12 +2068,12 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         if (col_queue)
             k_colfinal_resid<true><<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), 0, h->Ncap, h->N, h->pt1,
                                                                      h->params, w, m_over_n, h->D, h->colmin, h->colmin + h->Ncap, h->tmeta,
-                                                                     h->motion, slot, nullptr, queue_view(h->qcol, true), h->mompart);
+                                                                     h->motion, slot, nullptr, queue_view(h->qcol, true), h->mompart, 7);
         else
             k_colfinal_resid<false><<<nblk_f, kBlock, 0, h->stream>>>(h->tgt4, reinterpret_cast<const float*>(h->colpart), col_owner ? PO : PA, h->Ncap, h->N, h->pt1,
                                                                       h->params, w, m_over_n, h->D, h->colmin, h->colmin + h->Ncap, h->tmeta,
                                                                       h->motion, slot, prg::resid_flags(h, col_owner ? PO : PA), queue_view(h->qcol, false),
-                                                                      h->mompart);
+                                                                      h->mompart, col_owner && prg::owner_cols_per_lane() == 1 ? 6 : 7);
         if (ev) {
             PRG_HIP(hipEventRecord(ev[3], h->stream));
             PRG_HIP(hipEventRecord(ev[4], h->stream));

@@ -56,6 +56,8 @@ int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  
 // ---- the single sweep of a rigid iteration on the vector pipe, found and run by the column block's owner (cpd_sweeps_owner.hip) ----
 constexpr int kOwnerWaves = 8;       // waves of the workgroup that owns 128 columns
 constexpr int kOwnerMaxPlanes = 32;  // parts the stream is dealt out over per column block at most (partial planes of the merge)
+constexpr int kOwnerColsPerLane = 1; // default of owner_cols_per_lane() (PRG_OWNER_CPL): measured below
+int owner_cols_per_lane();           // 1 or 2: a wave of the owner sweep owns 64 or 128 columns
 int owner_planes(int64_t owned_points, int64_t streamed_points);
 // (min, A, Ux, Uy, Uz, R) -> colpart[plane][6][Ncap] + touched flags (resid_flags): what k_colfinal_resid<false> reads
 void launch_colpass_owner(prg_cpd* h, bool use_seed, int planes);

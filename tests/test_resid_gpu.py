@@ -68,9 +68,10 @@ def test_resid_sweep_moments_equal_the_two_sweep_engine(n, m, w, sparse, warm):
     assert abs(a[22] - b[22]) < 2e-6 * n_p                          # sum pt1 |x|^2
     assert np.max(np.abs(out[2][1] - out[1][1])) < 1e-6             # pt1
     if sparse == 1:
-        # [r6] the default single sweep is the owner sweep (csrc/cpd_sweeps_owner.hip): the same boxes and bound, but the last
-        # column block's pad-only groups stay out of its box - never more pairs than the two-sweep column pass, a few less
-        assert 0.8 * out[2][3] <= out[1][3] <= out[2][3], (out[2][3], out[1][3])
+        # [r6] the default single sweep is the owner sweep (csrc/cpd_sweeps_owner.hip): the same group boxes and bound, but a wave owns
+        # 64 columns instead of 128 (a smaller box: measured 27.6e6 pairs against 39.1e6 here) and the last column block's pad-only
+        # groups stay out of its box - never more pairs than the two-sweep column pass
+        assert 0.4 * out[2][3] <= out[1][3] <= out[2][3], (out[2][3], out[1][3])
     else:
         assert out[2][3] == out[1][3]                               # the same blocks of pairs evaluated
     pa, pb = out[2][2], out[1][2]

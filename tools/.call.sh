@@ -1,5 +1,3 @@
-for m in 0 32768; do for rep in 1 2; do PRG_EMBED_DEDUP_MIN=$m python bench.py --workload filterreg_500k --steps 20 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('filterreg dedup_min $m: %.1f it/s %.4f ms' % (d['value'], d['ms_per_step']))"; done; done
-PRG_EMBED_DEDUP=0 python bench.py --workload filterreg_500k --steps 20 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('filterreg two stages: %.1f it/s %.4f ms' % (d['value'], d['ms_per_step']))"
-PRG_EMBED_DEDUP_MIN=0 rocprofv3 --kernel-trace --stats -d gpurun_out/r6_c4kt2 -o b -- python bench.py --workload filterreg_500k --steps 20 --warmup 3 > /dev/null 2>&1
-python tools/rocpd_summary.py $(ls gpurun_out/r6_c4kt2/*.db gpurun_out/r6_c4kt2/*/*.db 2>/dev/null | head -1) | head -12
-PRG_EMBED_DEDUP_MIN=0 bash tools/gpu_session.sh pytest tests/test_filterreg_gpu.py tests/test_filterreg_claim_gpu.py tests/test_feature_lattice_gpu.py "tests/test_fullsize_gpu.py::test_filterreg_c4_500k_vs_oracle"
+PRG_OWNER_CPL=1 bash tools/gpu_session.sh pytest tests/test_resid_gpu.py tests/test_edge_gpu.py "tests/test_fullsize_gpu.py::test_cpd_bench_config_vs_oracle_dense_and_late[C1_rigid_100k]" tests/test_world8_gpu.py::test_eight_ranks_on_one_gpu_match_the_unsharded_oracle
+bash tools/gpu_session.sh c1 PRG_OWNER_CPL=1 "PRG_OWNER_CPL=1 PRG_OWNER_PLANES=1" "PRG_OWNER_CPL=1 PRG_OWNER_PLANES=3"
+for spec in 1,0,12 1,0,19 8,3,7 8,3,9 8,3,19; do for c in 2 1; do echo "spec $spec cpl $c: $(PRG_OWNER_CPL=$c SHARD_TRACE=$spec,100 python tools/shard_window.py 2>&1 | grep '^# rank')"; done; done

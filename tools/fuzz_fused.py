@@ -14,7 +14,7 @@ rigid AND affine (which keeps the two sweeps: lean matrix-core row pass, then th
 
 [r5] `big` cases append single-iteration comparisons at 100k ... 250k points (the oracle costs ~8 ... 50 s per E-step there).
 
-    python tools/fuzz_fused.py [cases] [seed] [big cases] [max points]
+    python tools/fuzz_fused.py [cases] [seed] [big cases] [max points] [long cases at >= 100k]
 """
 import os
 import sys
@@ -125,6 +125,18 @@ def main():
         kind = "affine" if c % 2 else "rigid"
         record(run_case(rng, "B%d" % c, n, n, 3, kind, str(rng.choice(["surface", "aniso", "clusters"])), 0.0, 1, True, False, False,
                         int(rng.integers(0, 10 ** 6))))
+    # [r6] whole stretches of registrations at >= 100k points: 10 ... 14 EM iterations from the identity (the fused sweep, its masks, the
+    # hand-over to the owner sweep at these sizes; affine: both matrix-core sweeps, the lean row pass and the hand-over), shapes and
+    # far offsets as above - the oracle's E-steps cost ~6 ... 12 s each on the bench host
+    longs = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+    for c in range(longs):
+        m = int(rng.integers(100000, 130001))
+        n = int(rng.integers(100000, 130001))
+        kind = "affine" if c % 3 == 2 else "rigid"
+        shape = str(rng.choice(shapes))
+        record(run_case(rng, "L%d" % c, m, n, 3, kind, shape, float(rng.choice([0.0, 0.0, 0.1])), int(rng.integers(10, 15)),
+                        True, rng.random() < 0.3, False, int(rng.integers(0, 10 ** 6))))
+    cases += longs
     print("%d cases, %d out of tolerance, worst %.2e (max of transform errors and 10 x sigma2 error; tolerance 1e-4); worst sigma2 error "
           "rigid %.2e affine %.2e (tolerance 1e-5), %.0f s" % (cases + big, bad, worst, worst_s2["rigid"], worst_s2["affine"], time.time() - t0))
 

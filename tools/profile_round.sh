@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (run through gpurun from the repo root):  bash tools/profile_round.sh r2
 # rocprofv3 kernel traces of the default bench line and PMC passes (FETCH_SIZE and WRITE_SIZE need separate passes;
 # never combined with system / runtime traces) for C1, C3 and C4; summaries land in gpurun_out/prof_<tag>/*.txt.
-tag=${1:-r5}
+tag=${1:-r6}
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 mkdir -p $out
@@ -35,20 +35,32 @@ sum --pmc $(db $out/c1_FETCH_SIZE) $(db $out/c1_WRITE_SIZE) $(db $out/c1_SQ_INST
 # 3. measured logs, no profiler: whole registrations, the 8-rank window of E-steps, both engines and the switch along
 # registrations (surface / volume / 10:1:1, sizes, shards)
 python tools/time_registration.py 2>&1 | grep -v "amdgpu.ids" > $out/${tag}_whole_registrations_100k.log
-python tools/shard_window.py 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window.log
-configs='100000:30:surface:1 30000:30:surface:1 250000:30:surface:1 100000:120:volume:1 100000:72:aniso:1 100000:30:surface:8'
-[ -n "$SKIP_SWITCH" ] && configs=''   # (round 4: the engine-switch logs were taken on their own, profiles/r4_engine_switch_*)
+python tools/shard_window.py 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window_c1_allranks.log
+configs=''   # [r6] the engine-switch A/B (tools/mfma_vs_valu.py) compares the TWO-sweep engines; RUN_SWITCH=1 takes it again
+[ -n "$RUN_SWITCH" ] && configs='100000:30:surface:1 30000:30:surface:1 250000:30:surface:1 100000:120:volume:1 100000:72:aniso:1 100000:30:surface:8'   # (round 4: the engine-switch logs were taken on their own, profiles/r4_engine_switch_*)
 [ -n "$PROFILE_FULL" ] && configs="$configs 12000:30:surface:1 50000:30:surface:1 400000:26:surface:1 100000:30:surface:4 100000:30:surface:2"
 for cfg in $configs; do
   IFS=: read n its kind world <<< "$cfg"
   python tools/mfma_vs_valu.py $n $its $kind $world 2>&1 | grep -v "amdgpu.ids" > $out/${tag}_engine_switch_${kind}_${n}_w${world}.log
 done
 
+# 3a. which kernels one rank's iteration is made of (rank 3 of 8 / the one GPU; dense, mid, late), with the owner sweep and with round 5's engines
+for spec in 8,3,3 8,3,9 8,3,19 1,0,19; do
+  name=$(echo $spec | tr ',' '_')
+  SHARD_TRACE=$spec rocprofv3 --kernel-trace --stats -d $out/st_$name -o b -- python tools/shard_window.py > $out/st_$name.log 2>&1
+  (grep "^# rank" $out/st_$name.log; sum $(db $out/st_$name) | head -14) > $out/${tag}_shard_trace_$name.txt
+  if [ $spec != 8,3,3 ]; then
+    PRG_OWNER_SWEEP=0 SHARD_TRACE=$spec rocprofv3 --kernel-trace --stats -d $out/sq_$name -o b -- python tools/shard_window.py > $out/sq_$name.log 2>&1
+    (grep "^# rank" $out/sq_$name.log; sum $(db $out/sq_$name) | head -14) > $out/${tag}_shard_trace_${name}_round5_engines.txt
+  fi
+  rm -rf $out/st_$name $out/sq_$name
+done
+
 # 3b. C2 (the 8-GPU configuration): HBM traffic of its two sweeps, and the shard replay the 6x projection rests on
 c2="python bench.py --workload affine_200k --steps 20 --warmup 1 --no-cpu-baseline"
 pmc c2 $c2
 sum --pmc $(db $out/c2_FETCH_SIZE) $(db $out/c2_WRITE_SIZE) > $out/${tag}_affine_200k_pmc.txt
-[ -z "$SKIP_SHARD_C2" ] && python tools/shard_window.py 200000 20 affine 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window_c2.log
+[ -z "$SKIP_SHARD_C2" ] && python tools/shard_window.py 200000 20 affine 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^HIP version\|^ROCm\|^Hostname\|^Librccl" > $out/${tag}_shard_window_c2_allranks.log
 
 # 4. C3 and C4: kernel traces and HBM traffic
 c3="python bench.py --workload nonrigid_50k --steps 20 --warmup 2 --no-dense-compare"
