@@ -6,10 +6,10 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one EM iteration (transform + E-step + fp64 moment reduction + [all-reduce] + device M-step) of RigidCPD on
-BASELINE.json's config C1 - the E-step as the registration's own loop runs it: while sigma2 is large ONE fused sweep over the pairs
-(the rigid M-step's moments from per-column sums; PROBREG_BENCH_TWO_SWEEPS=1 keeps the column pass + row pass),
-afterwards the culled column pass + row pass: synthetic N = M = 100 000 3-D points, fp32 pair
-arithmetic, w = 0.  With N GPUs the SAME problem is solved with the target cloud sharded over the ranks ("scaling":
+BASELINE.json's config C1 - the E-step as the registration's own loop runs it: ONE sweep over the pairs per iteration in every regime
+(the rigid M-step's moments from per-column sums: the fused matrix-core sweep while sigma2 is large, DESIGN.md 3.1e, the residual-form
+sweep of the column blocks' owners on the vector pipe afterwards, 3.1f / 3.1g; PROBREG_BENCH_TWO_SWEEPS=1 keeps the column pass +
+row pass): synthetic N = M = 100 000 3-D points, fp32 pair arithmetic, w = 0.  With N GPUs the SAME problem is solved with the target cloud sharded over the ranks ("scaling":
 "strong"); one all-reduce of 32 doubles per iteration.  Inputs are resident in HBM before the timed region.
 
 THE TIMED WINDOW IS PINNED: the E-step's cost depends on sigma2 (the sweeps skip blocks whose every pair is an exact
@@ -394,8 +394,8 @@ def bench_cpd(workload, steps, warmup, tuning="", pairs_log=None):
     out["roofline"] = {
         "bound": "valu",
         "kernel": "the E-step's dominant pair sweep: rigid - ONE sweep per iteration in every regime (the fused matrix-core sweep "
-                  "k_colpass_mfma<FUSED> while sigma2 is large, the residual-form vector-pipe sweep k_colpass_queue<RESID> / "
-                  "k_colpass_cull<RESID> afterwards; den, P1, PX sums from the column side, one exponential per pair and iteration); "
+                  "k_colpass_mfma<FUSED> while sigma2 is large, the residual-form vector-pipe sweep run by the column blocks' owners, "
+                  "k_colpass_owner, afterwards; den, P1, PX sums from the column side, one exponential per pair and iteration); "
                   "affine - the row pass (k_rowpass_mfma / k_rowpass_queue) of its two sweeps",
         "achieved": row_tf,
         "peak": VALU_F32_PEAK_TFLOPS,
