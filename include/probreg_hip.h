@@ -73,6 +73,12 @@ typedef struct prg_cpd prg_cpd;
 int prg_cpd_create(prg_cpd** out, int device, void* hip_stream);
 int prg_cpd_destroy(prg_cpd* h);
 
+/* [r6] The order a CPD plan stores a cloud in (sorted position -> original index): the in-order walk of a left-aligned kd-tree
+ * with 32-point leaves - every aligned run of 2^k leaves (the 32-point groups, 128-point blocks, 256-point chunks and 512-point
+ * blocks the sweeps cull by) is one axis-aligned cell of the cloud.  on_device != 0: built on the GPU, level by
+ * level (csrc/spatial_order.hip, what prg_cpd_set_source / prg_cpd_set_target run); 0: the host build (csrc/morton.h).  Both give
+ * the same cells.  No reference counterpart (probreg keeps the caller's order); tests and tools. */
+int prg_spatial_order(const float* points_hd, int64_t n, int dim, int on_device, int* perm_host);
 /* Engine options, before the clouds are uploaded (all default to 1): Morton-sort the source / the target at
  * upload (every output keeps the caller's point order) and skip (wave, 32-point group) blocks whose every pair
  * is an exact zero in fp32.  The non-rigid path keeps the source unsorted. */

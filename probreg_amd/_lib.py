@@ -63,6 +63,7 @@ SIGNATURES = {
     "prg_device_count": [_c.POINTER(_i)],
     "prg_cpd_create": [_pp, _i, _vp],
     "prg_cpd_destroy": [_vp],
+    "prg_spatial_order": [_vp, _i64, _i, _i, _vp],
     "prg_cpd_set_options": [_vp, _i, _i, _i],
     "prg_cpd_set_dense_engine": [_vp, _i, _d],
     "prg_cpd_last_estep_engine": [_vp, _c.POINTER(_i)],

@@ -1281,7 +1281,9 @@ int ensure_buffer(T** p, int64_t* have, int64_t need) {
 // capacity: the cloud + room for the segments' rounding to 256-point multiples + prefetch slack
 int cap_for(int64_t n) { return (int)prg::round_up(n + 64 * prg::kSuper + 1024, 1024); }
 
-// Morton (Z-curve) order of a cloud: sorted position -> original index (morton.h), uploaded as the plan's permutation.
+// Spatial order of a cloud: sorted position -> original index, as the plan's device permutation.  [r6] The kd-tree order of
+// morton.h, built on the device (spatial_order.hip: ~2 ms per 100k points; PRG_SPATIAL_ORDER=kd_host: the host build, 17 ms;
+// =morton: the Z-curve of rounds 1 - 5).
 int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int** perm_dev, double* ext2 = nullptr,
                        float* box = nullptr) {
     std::vector<float> host((size_t)n * dim);
@@ -1302,12 +1304,18 @@ int morton_permutation(prg_cpd* h, const float* pts_hd, int64_t n, int dim, int*
             }
         }
     }
-    const std::vector<int> perm = prg::spatial_order(host.data(), n, dim);
     if (*perm_dev) (void)hipFree(*perm_dev);
     *perm_dev = nullptr;
     PRG_HIP(hipMalloc((void**)perm_dev, (size_t)n * sizeof(int)));
+    static const std::string order = getenv("PRG_SPATIAL_ORDER") ? getenv("PRG_SPATIAL_ORDER") : "";
+    if (order != "morton" && order != "kd_host") {
+        // the caller's layout, [n][dim] floats, goes to the staging buffer (where k_pack_cloud reads it anyway) and is ordered there
+        PRG_TRY(prg::ensure_stage(h, (size_t)n * dim * sizeof(float)));
+        PRG_HIP(hipMemcpyAsync(h->stage, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        return prg::device_kd_order((const float*)h->stage, n, dim, *perm_dev, h->stream);
+    }
+    const std::vector<int> perm = order == "morton" ? prg::morton_order(host.data(), n, dim) : prg::kd_order(host.data(), n, dim);
     PRG_HIP(hipMemcpy(*perm_dev, perm.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
-    (void)h;
     return PRG_OK;
 }
 

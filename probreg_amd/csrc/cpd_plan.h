@@ -217,6 +217,8 @@ namespace prg {
 struct UniqueId { char bytes[PRG_COMM_ID_BYTES]; };  // ncclUniqueId
 int comm_all_reduce_f64(prg_comm* c, double* buf_dev, int64_t count, hipStream_t st);
 int ensure_stage(prg_cpd* h, size_t bytes);
+// kd-tree order of a cloud built on the device (spatial_order.hip): pts_dev [n][dim] floats in the caller's order -> perm_dev [n]
+int device_kd_order(const float* pts_dev, int64_t n, int dim, int* perm_dev, hipStream_t st, int leaf = 32);
 // non-rigid (cpd_nonrigid.hip)
 int nonrigid_displacement(prg_cpd* h, const double** gw_out);  // G W of the current W (device, [M][3])
 int nonrigid_gw(prg_cpd* h, const double* w3, double* out3);  // out3[m][3] = G * w3[m][3] (fp64)

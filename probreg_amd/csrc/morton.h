@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace prg {
@@ -75,17 +76,20 @@ std::vector<int> morton_order(const T* pts, int64_t n, int dim) {
 // cell of the cloud, never two pieces either side of a jump of a space-filling curve.  Only the last leaf may be partial.
 // What it buys over the Z-curve (CPU count on C1's clouds at EM iteration 19, 128 x 32 box tests at the 2^-48 bound): 2.92e8
 // evaluated pairs instead of 3.67e8; at the noise floor 1.40e8 instead of 1.93e8 (Hilbert: 3.10e8 / 1.53e8).
-// One-off host work at upload: O(n log n) (std::nth_element per node), ~10 ms per 100k points.
+// One-off host work at upload: O(n log n) (std::nth_element per node; the top subtrees on threads of their own).
 template <typename T>
-void kd_order_rec(const T* pts, int dim, int* idx, int64_t n, int leaf) {
+struct KdPoint { T c[3]; int i; };  // the coordinates travel with the index: partitioning reads memory in order, not through it
+
+template <typename T>
+void kd_order_rec(KdPoint<T>* p, int dim, int64_t n, int leaf, int spawn_depth) {
+    std::vector<std::thread> helpers;  // left subtrees of the top levels, each on a thread of its own (joined below)
     while (n > leaf) {
         T lo[3], hi[3];
-        for (int k = 0; k < dim; ++k) lo[k] = hi[k] = pts[(int64_t)idx[0] * dim + k];
+        for (int k = 0; k < dim; ++k) lo[k] = hi[k] = p[0].c[k];
         for (int64_t i = 1; i < n; ++i)
             for (int k = 0; k < dim; ++k) {
-                const T v = pts[(int64_t)idx[i] * dim + k];
-                lo[k] = std::min(lo[k], v);
-                hi[k] = std::max(hi[k], v);
+                lo[k] = std::min(lo[k], p[i].c[k]);
+                hi[k] = std::max(hi[k], p[i].c[k]);
             }
         int ax = 0;
         for (int k = 1; k < dim; ++k)
@@ -95,30 +99,40 @@ void kd_order_rec(const T* pts, int dim, int* idx, int64_t n, int leaf) {
         while (2 * left < leaves) left *= 2;  // largest power of two < leaves
         const int64_t cut = left * leaf;
         // (ties broken by the index: the order is a function of the cloud alone)
-        std::nth_element(idx, idx + cut, idx + n, [pts, dim, ax](int a, int b) {
-            const T va = pts[(int64_t)a * dim + ax], vb = pts[(int64_t)b * dim + ax];
-            return va < vb || (va == vb && a < b);
+        std::nth_element(p, p + cut, p + n, [ax](const KdPoint<T>& a, const KdPoint<T>& b) {
+            return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.i < b.i);
         });
-        kd_order_rec(pts, dim, idx, cut, leaf);  // left: a full power-of-two subtree (recursion depth <= log2 n)
-        idx += cut;                              // right: iterate
+        // left: a full power-of-two subtree (recursion depth <= log2 n); the big ones near the root run concurrently with the rest
+        if (spawn_depth > 0 && cut >= 4096) {
+            KdPoint<T>* sub = p;
+            helpers.emplace_back([sub, dim, cut, leaf, spawn_depth]() { kd_order_rec(sub, dim, cut, leaf, spawn_depth - 1); });
+        } else {
+            kd_order_rec(p, dim, cut, leaf, 0);
+        }
+        if (spawn_depth > 0) --spawn_depth;
+        p += cut;  // right: iterate
         n -= cut;
     }
+    for (std::thread& t : helpers) t.join();
 }
 
 template <typename T>
 std::vector<int> kd_order(const T* pts, int64_t n, int dim, int leaf = 32) {
     std::vector<int> perm((size_t)n);
-    std::iota(perm.begin(), perm.end(), 0);
-    if (n > leaf) kd_order_rec(pts, dim, perm.data(), n, leaf);
+    if (n <= leaf) {
+        std::iota(perm.begin(), perm.end(), 0);
+        return perm;
+    }
+    std::vector<KdPoint<T>> p((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) p[(size_t)i].c[k] = k < dim ? pts[i * dim + k] : (T)0;
+        p[(size_t)i].i = (int)i;
+    }
+    // (part of every registration through the public API, tools/time_registration.py: the subtrees of the top four levels run on
+    // threads of their own)
+    kd_order_rec(p.data(), dim, n, leaf, n >= 16384 ? 4 : 0);
+    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = p[(size_t)i].i;
     return perm;
-}
-
-// The order the CPD plan stores its clouds in: the kd-tree order above; PRG_SPATIAL_ORDER=morton restores the Z-curve of
-// rounds 1 - 5 (A/B runs).
-template <typename T>
-std::vector<int> spatial_order(const T* pts, int64_t n, int dim) {
-    static const bool morton = getenv("PRG_SPATIAL_ORDER") && std::string(getenv("PRG_SPATIAL_ORDER")) == "morton";
-    return morton ? morton_order(pts, n, dim) : kd_order(pts, n, dim);
 }
 
 }  // namespace prg

@@ -83,7 +83,7 @@ def bisection_shards(points, world_size):
     """Row indices of every rank's shard: recursive bisection of the cloud across the widest axis of the current cell, the
     ranks split in halves and the points in proportion (shard sizes are ``shard_bounds``'s: near-equal counts).  Every shard is
     ONE axis-aligned cell of the cloud for any world size - a contiguous run of a space-filling curve can be two pieces
-    either side of one of the curve's jumps.  Deterministic (stable sorts; ties keep the caller's order)."""
+    either side of one of the curve's jumps.  Deterministic (a function of the cloud alone)."""
     p = np.asarray(points, dtype=np.float64)
     n = p.shape[0]
     out = [None] * int(world_size)
@@ -97,7 +97,8 @@ def bisection_shards(points, world_size):
         cnt = _shard_start(n, mid, world_size) - _shard_start(n, r0, world_size)
         q = p[idx]
         ax = int(np.argmax(q.max(axis=0) - q.min(axis=0))) if len(idx) else 0
-        order = np.argsort(q[:, ax], kind="stable")
+        # (a selection, not a sort: O(n) per cell; numpy's introselect is a function of its input alone, so every rank cuts alike)
+        order = np.argpartition(q[:, ax], cnt) if 0 < cnt < len(idx) else np.arange(len(idx))
         stack.append((idx[order[:cnt]], r0, mid))
         stack.append((idx[order[cnt:]], mid, r1))
     return out

@@ -25,6 +25,18 @@ def _current_device_and_stream(device=None):
     return (0 if device is None else int(device)), 0
 
 
+def spatial_order(points, on_device=True):
+    """The order a CPD plan stores ``points`` (n, 2|3) in: sorted position -> original index (prg_spatial_order; the kd-tree
+    order of DESIGN.md 3.1b, built on the GPU as the plans do, or on the host)."""
+    import numpy as np
+
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    perm = np.empty(pts.shape[0], dtype=np.int32)
+    check(lib.prg_spatial_order(pts.ctypes.data_as(ctypes.c_void_p), int(pts.shape[0]), int(pts.shape[1]), 1 if on_device else 0,
+                                perm.ctypes.data_as(ctypes.c_void_p)))
+    return perm
+
+
 def engine_bounds(m, n_local):
     """(column bound, row bound) of the dense-regime engine switch for a source of ``m`` points and a local target of
     ``n_local``: evaluated pairs per owned point below which the matrix-core sweep is left (prg_cpd_engine_bounds; host
