@@ -36,11 +36,11 @@ case $step in
     PRG_SPATIAL_ORDER=morton PROBREG_SHARD_CUT=morton python tools/shard_window.py 2>&1 | grep -v "$quiet" > $out/shard_window_c1_allranks_morton.log
     python tools/shard_window.py 2>&1 | grep -v "$quiet" > $out/shard_window_c1_allranks.log
     python tools/shard_window.py 200000 20 affine 2>&1 | grep -v "$quiet" > $out/shard_window_c2_allranks.log
-    tail -8 $out/shard_window_c1_allranks_morton.log $out/shard_window_c1_allranks.log $out/shard_window_c2_allranks.log ;;
+    for f in $out/shard_window_c*.log; do tail -n 8 $f; done ;;
   shards)     # every rank's shard of 1 / 2 / 4 / 8 over the bench window, C1 and C2
     python tools/shard_window.py 2>&1 | grep -v "$quiet" > $out/shard_window_c1_allranks.log
     [ -z "$SKIP_C2" ] && python tools/shard_window.py 200000 20 affine 2>&1 | grep -v "$quiet" > $out/shard_window_c2_allranks.log
-    tail -8 $out/shard_window_c*_allranks.log ;;
+    for f in $out/shard_window_c*_allranks.log; do tail -n 8 $f; done ;;
   shard_trace) # per-kernel cost of ONE rank's iteration:  shard_trace "8,3,19" "8,3,3" ...  (world,rank,iteration)
     for spec in "$@"; do
       name=$(echo $spec | tr ',' '_')
