@@ -1951,7 +1951,11 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // above the matrix-core column pass': same command, lower end at 0.5 / 0.75 / 1.0 / 1.4 of the column pass' bound:
         // 828 / 841 / 855 / 859 it/s (profiles/r5_fused_lower_bound.log); 1.4 hands over at EM iteration 12 of C1 (0.64 -> 0.57 ms)
         static const double fused_scale = getenv("PRG_FUSED_RCOL_SCALE") ? atof(getenv("PRG_FUSED_RCOL_SCALE")) : -1.0;
-        ea.r_col_bound_fused = ea.r_col_bound * (fused_scale > 0.0 ? fused_scale : allow_resid ? 1.4 : 0.5);
+        // [r6] with the clouds in kd-tree order and the owner sweep below it the C1 window is flat from 1.0 to 2.8 (906 / 909 / 912 / 910
+        // it/s at 1.0 / 1.4 / 2.0 / 2.8, profiles/r6_fused_lower_bound.log: the optimum is bracketed); target shards, whose ranks leave
+        // the matrix cores at their own iteration, do better the later they leave: 8 ranks 4.10 -> 3.99 ms per window at 1.4 -> 1.0
+        // (0.7: 4.02), 4 ranks 6.51 -> 6.42.  1.0 it is.
+        ea.r_col_bound_fused = ea.r_col_bound * (fused_scale > 0.0 ? fused_scale : allow_resid ? 1.0 : 0.5);
         ea.r_row_bound = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, true);
         ea.r_row_bound_full = r_row_env > 0.0 ? r_row_env : engine_row_bound(h->M, h->N, false);  // (the device knows which applies)
         ea.streamed_col = (double)h->M;

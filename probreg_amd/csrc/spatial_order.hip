@@ -59,7 +59,11 @@ __global__ __launch_bounds__(kBlock) void k_kd_bbox(const float* __restrict__ pt
         const int64_t j = perm[i];
         for (int k = 0; k < dim; ++k) v[k] = f2o(pts[j * dim + k]);
     }
-    // a wave that lies in ONE segment (all of them near the root) reduces first: six atomics per wave
+    // a wave that lies in ONE segment (all of them near the root) reduces first, the waves of a workgroup then combine in LDS:
+    // six atomics per workgroup while the segments are long (every same-address atomic is served on its own: 1563 waves x 6 on the
+    // root's box cost 110 us)
+    __shared__ unsigned sh[kBlock / 64][6];
+    __shared__ int shseg[kBlock / 64];
     const int seg0 = __shfl(seg, 0, 64);
     const bool uniform = __all(seg == seg0 && in);
     if (uniform) {
@@ -72,14 +76,41 @@ __global__ __launch_bounds__(kBlock) void k_kd_bbox(const float* __restrict__ pt
                 hi[k] = max(hi[k], (unsigned)__shfl_xor((int)hi[k], off, 64));
             }
         if ((threadIdx.x & 63) == 0)
-            for (int k = 0; k < dim; ++k) {
-                atomicMin(&bbox[seg * 6 + k], lo[k]);
-                atomicMax(&bbox[seg * 6 + 3 + k], hi[k]);
+            for (int k = 0; k < 3; ++k) {
+                sh[threadIdx.x >> 6][k] = lo[k];
+                sh[threadIdx.x >> 6][3 + k] = hi[k];
             }
     } else if (in) {
         for (int k = 0; k < dim; ++k) {
             atomicMin(&bbox[seg * 6 + k], v[k]);
             atomicMax(&bbox[seg * 6 + 3 + k], v[k]);
+        }
+    }
+    if ((threadIdx.x & 63) == 0) shseg[threadIdx.x >> 6] = uniform ? seg : -1;
+    __syncthreads();
+    if (threadIdx.x < kBlock / 64) {  // one lane per wave: merge into the first wave of the same segment, that one does the atomics
+        const int w = threadIdx.x, sg = shseg[w];
+        if (sg >= 0) {
+            int first = w;
+            for (int q = 0; q < w; ++q)
+                if (shseg[q] == sg) { first = q; break; }
+            if (first == w) {
+                unsigned lo[3], hi[3];
+                for (int k = 0; k < 3; ++k) {
+                    lo[k] = sh[w][k];
+                    hi[k] = sh[w][3 + k];
+                }
+                for (int q = w + 1; q < kBlock / 64; ++q)
+                    if (shseg[q] == sg)
+                        for (int k = 0; k < 3; ++k) {
+                            lo[k] = min(lo[k], sh[q][k]);
+                            hi[k] = max(hi[k], sh[q][3 + k]);
+                        }
+                for (int k = 0; k < dim; ++k) {
+                    atomicMin(&bbox[sg * 6 + k], lo[k]);
+                    atomicMax(&bbox[sg * 6 + 3 + k], hi[k]);
+                }
+            }
         }
     }
 }
