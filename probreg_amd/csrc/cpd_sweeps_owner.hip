@@ -31,6 +31,10 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct alignas(64) Quad { float4 q[4]; };
+struct alignas(128) Oct { float4 q[8]; };
+#ifndef PRG_OWNER_OCT
+#define PRG_OWNER_OCT 0
+#endif
 struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; };
 
 constexpr double kLog2e = 1.4426950408889634;
@@ -173,6 +177,54 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
             }
             int g = __builtin_amdgcn_readlane(g_mine, __builtin_ctzll(mask2));
             mask2 &= mask2 - 1;
+#if PRG_OWNER_OCT
+            // two quads (8 streamed points) per scalar-load round trip: scalar loads return out of order, so every wait is a wait for
+            // all of them - issuing two 64-byte loads together doubles the arithmetic a wave has between a load and its wait
+            const Oct* __restrict__ op = reinterpret_cast<const Oct*>(z4);
+            Oct oa = op[(int64_t)g * 4];
+            for (;;) {
+                const int jn = mask2 ? __builtin_ctzll(mask2) : -1;
+                mask2 &= mask2 - 1;  // (0 stays 0)
+                const int gnext = jn >= 0 ? __builtin_amdgcn_readlane(g_mine, jn) : -1;
+                const Oct* __restrict__ q = op + (int64_t)g * 4;
+                const Oct* __restrict__ qn = op + (int64_t)(gnext >= 0 ? gnext : g) * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const Oct no = (t < 3) ? q[t + 1] : qn[0];
+#pragma unroll
+                    for (int h2 = 0; h2 < 8; h2 += kOwnerSub) {
+                        T dx[kOwnerSub], dy[kOwnerSub], dz[kOwnerSub], d2[kOwnerSub];
+#pragma unroll
+                        for (int cc = 0; cc < kOwnerSub; ++cc) {
+                            dx[cc] = x - C::splat(oa.q[h2 + cc].x);
+                            dy[cc] = y - C::splat(oa.q[h2 + cc].y);
+                            dz[cc] = z - C::splat(oa.q[h2 + cc].z);
+                            d2[cc] = C::fma(dz[cc], dz[cc], C::fma(dy[cc], dy[cc], C::fma(dx[cc], dx[cc], C::splat(oa.q[h2 + cc].w))));
+                        }
+                        T cmn = d2[0];
+#pragma unroll
+                        for (int cc = 1; cc < kOwnerSub; ++cc) cmn = C::min(cmn, d2[cc]);
+                        if (C::any_less(cmn, run)) {
+                            const T nm = C::min(run, cmn);
+                            const T noff = C::coff(kk, nm);
+                            const T f = C::exp2(noff - off);
+                            s *= f; ux *= f; uy *= f; uz *= f; rr *= f;
+                            run = nm;
+                            off = noff;
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < kOwnerSub; ++cc) {
+                            const T pr = C::exp2(C::fma(d2[cc], C::splat(kk), off));
+                            s += pr;
+                            ux = C::fma(pr, dx[cc], ux);
+                            uy = C::fma(pr, dy[cc], uy);
+                            uz = C::fma(pr, dz[cc], uz);
+                            rr = C::fma(pr, d2[cc], rr);
+                        }
+                    }
+                    oa = no;
+                }
+#else
             Quad qa = zp[(int64_t)g * 8];
             for (;;) {
                 const int jn = mask2 ? __builtin_ctzll(mask2) : -1;
@@ -216,6 +268,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
                     }
                     qa = nq;
                 }
+#endif
                 if (gnext < 0) break;
                 g = gnext;
             }

@@ -1,1 +1,4 @@
-for sc in 0.7 1.0; do PRG_FUSED_RCOL_SCALE=$sc SKIP_C2=1 TAG=r6sc$sc bash tools/gpu_session.sh shards > /dev/null 2>&1; echo "scale $sc"; sed -n 11,16p gpurun_out/r6sc${sc}_shards/shard_window_c1_allranks.log; grep "^sum\|whole iterations (max over ranks), +  0" gpurun_out/r6sc${sc}_shards/shard_window_c1_allranks.log; done
+bash tools/gpu_session.sh tests
+cp gpurun_out/r6_tests/pytest_gpu.log gpurun_out/r6_pytest_gpu_durations_final.log
+python __graft_entry__.py smoke
+bash tools/gpu_session.sh bench
