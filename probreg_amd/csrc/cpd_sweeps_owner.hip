@@ -31,20 +31,22 @@ namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 struct alignas(64) Quad { float4 q[4]; };
-struct alignas(128) Oct { float4 q[8]; };
-#ifndef PRG_OWNER_OCT
-#define PRG_OWNER_OCT 0
-#endif
+
 struct alignas(32) GroupMeta { float lo[3]; float hi[3]; float aux; float pad; };
 
 constexpr double kLog2e = 1.4426950408889634;
 constexpr float kCullLog2 = -prg::kCullExp;
 constexpr int kWaves = prg::kOwnerWaves;
 constexpr int kThreads = 64 * kWaves;
-#ifndef PRG_OWNER_SUB
-#define PRG_OWNER_SUB 2
+// streamed points per rescale check (their differences stay in registers between the check and the accumulation): 4 with one
+// column per lane (60 VGPRs), 2 with two (72; 4 would spill).  Measured with one column per lane, C1's sweeps of iterations 12 / 19:
+// 1 point 0.534 / 0.128 ms, 2 points 0.530 / 0.114, 4 points 0.490 / 0.105 (late 9 150 / 9 900 / 10 500 it/s); two quads per
+// scalar-load round trip (128-byte loads, 34 SGPRs spilled to lanes): 0.521 / 0.112 - no gain, removed.
+#ifdef PRG_OWNER_SUB
+template <int CPL> struct OwnerSub { static constexpr int value = PRG_OWNER_SUB; };
+#else
+template <int CPL> struct OwnerSub { static constexpr int value = CPL == 1 ? 4 : 2; };
 #endif
-constexpr int kOwnerSub = PRG_OWNER_SUB;  // streamed points per rescale check (2: 64 VGPRs without spills, 8 waves per SIMD)
 
 __device__ __forceinline__ float box_dist2(const float (&alo)[3], const float (&ahi)[3], const GroupMeta& g) {
     float d2 = 0.f;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
                                                             unsigned char* __restrict__ colflag) {
     typedef Cols<CPL> C;
     typedef typename C::T T;
-    constexpr int kCols = 64 * CPL, kOwnGroups = kCols / 32;
+    constexpr int kCols = 64 * CPL, kOwnGroups = kCols / 32, kOwnerSub = OwnerSub<CPL>::value;
     __shared__ typename C::S partr[kWaves][6][64];
     __shared__ int arrived, wave_groups[kWaves];
     if (threadIdx.x == 0) arrived = 0;
@@ -177,54 +179,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
             }
             int g = __builtin_amdgcn_readlane(g_mine, __builtin_ctzll(mask2));
             mask2 &= mask2 - 1;
-#if PRG_OWNER_OCT
-            // two quads (8 streamed points) per scalar-load round trip: scalar loads return out of order, so every wait is a wait for
-            // all of them - issuing two 64-byte loads together doubles the arithmetic a wave has between a load and its wait
-            const Oct* __restrict__ op = reinterpret_cast<const Oct*>(z4);
-            Oct oa = op[(int64_t)g * 4];
-            for (;;) {
-                const int jn = mask2 ? __builtin_ctzll(mask2) : -1;
-                mask2 &= mask2 - 1;  // (0 stays 0)
-                const int gnext = jn >= 0 ? __builtin_amdgcn_readlane(g_mine, jn) : -1;
-                const Oct* __restrict__ q = op + (int64_t)g * 4;
-                const Oct* __restrict__ qn = op + (int64_t)(gnext >= 0 ? gnext : g) * 4;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const Oct no = (t < 3) ? q[t + 1] : qn[0];
-#pragma unroll
-                    for (int h2 = 0; h2 < 8; h2 += kOwnerSub) {
-                        T dx[kOwnerSub], dy[kOwnerSub], dz[kOwnerSub], d2[kOwnerSub];
-#pragma unroll
-                        for (int cc = 0; cc < kOwnerSub; ++cc) {
-                            dx[cc] = x - C::splat(oa.q[h2 + cc].x);
-                            dy[cc] = y - C::splat(oa.q[h2 + cc].y);
-                            dz[cc] = z - C::splat(oa.q[h2 + cc].z);
-                            d2[cc] = C::fma(dz[cc], dz[cc], C::fma(dy[cc], dy[cc], C::fma(dx[cc], dx[cc], C::splat(oa.q[h2 + cc].w))));
-                        }
-                        T cmn = d2[0];
-#pragma unroll
-                        for (int cc = 1; cc < kOwnerSub; ++cc) cmn = C::min(cmn, d2[cc]);
-                        if (C::any_less(cmn, run)) {
-                            const T nm = C::min(run, cmn);
-                            const T noff = C::coff(kk, nm);
-                            const T f = C::exp2(noff - off);
-                            s *= f; ux *= f; uy *= f; uz *= f; rr *= f;
-                            run = nm;
-                            off = noff;
-                        }
-#pragma unroll
-                        for (int cc = 0; cc < kOwnerSub; ++cc) {
-                            const T pr = C::exp2(C::fma(d2[cc], C::splat(kk), off));
-                            s += pr;
-                            ux = C::fma(pr, dx[cc], ux);
-                            uy = C::fma(pr, dy[cc], uy);
-                            uz = C::fma(pr, dz[cc], uz);
-                            rr = C::fma(pr, d2[cc], rr);
-                        }
-                    }
-                    oa = no;
-                }
-#else
             Quad qa = zp[(int64_t)g * 8];
             for (;;) {
                 const int jn = mask2 ? __builtin_ctzll(mask2) : -1;
@@ -268,7 +222,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(7, 8))
                     }
                     qa = nq;
                 }
-#endif
                 if (gnext < 0) break;
                 g = gnext;
             }
