@@ -1981,6 +1981,7 @@ static int estep_impl(prg_cpd* h, double w, hipEvent_t* ev) {
         // the forced pass to 1e-5 up to 128 with w = 0 / 0.1 and on a 2-rank shard.  64 makes every matrix-core row pass of C1 lean.)
         ea.lean_factor = h->lean_factor >= 0.0 ? h->lean_factor : lean_env >= 0.0 ? lean_env : 64.0;
         ea.fused_allowed = allow_fused ? 1 : 0;
+        ea.resid_allowed = allow_resid ? 1 : 0;
         static const double fused_factor_env = getenv("PRG_FUSED_FACTOR") ? atof(getenv("PRG_FUSED_FACTOR")) : -1.0;
         ea.fused_factor = fused_factor_env >= 0.0 ? fused_factor_env : h->fused_factor;
         ea.reset = h->eng_reset ? 1 : 0;

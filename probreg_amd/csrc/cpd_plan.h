@@ -42,6 +42,7 @@ struct EngineArgs {  // host -> k_chunk_meta_bbox, by value
     float tbox[6];
     int slot, have_colmin, forced, reset;
     int fused_allowed;            // this E-step feeds a rigid M-step and nothing else (prg_cpd_iterate / prg_cpd_set_moments_only)
+    int resid_allowed;            // ... and below the matrix cores it would run as ONE residual-form sweep on the vector pipe (exact at any amplification)
     unsigned seq;
     EngineDecision* dev;
     EngineDecision* host;

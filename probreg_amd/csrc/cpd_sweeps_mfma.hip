@@ -769,7 +769,13 @@ __global__ __launch_bounds__(kBlock) void k_chunk_meta_bbox(const BoxMeta* __res
     // has a factor of its own, far above the lean pass')
     const bool fused_ok = eng.tsum && eng.tsum[3] > 0.0 && sigma2 * (double)eng.dim * eng.fused_factor * eng.owned_col >= eng.tsum[3];
     const bool fused_try = eng.fused_allowed && fused_ok && !row_off;
-    const bool dense = ok && (eng.forced || r_col >= (fused_try ? eng.r_col_bound_fused : eng.r_col_bound));
+    bool dense = ok && (eng.forced || r_col >= (fused_try ? eng.r_col_bound_fused : eng.r_col_bound));
+    // [r6] A caller that wants moments only, past the fused sweep's amplification limit (sigma2 small against the cloud's extent:
+    // two clusters far apart, a 10:1:1 box): what competes is TWO matrix-core sweeps against ONE residual-form sweep on the vector
+    // pipe, which is exact at any amplification.  Measured from identical states (tools/single_sweep_ab.py, 100k points): clusters
+    // 1.59 against 1.42 ms with 44 % of the pairs needed, the box 0.95 against 0.61 ms with 18 %; fully dense it is 2.6 against
+    // 3.1 ms - the matrix cores keep such an E-step only while at least 60 % of the pairs are needed.
+    if (dense && !eng.forced && eng.fused_allowed && eng.resid_allowed && !fused_try && !(r_col >= 0.6 * eng.streamed_col)) dense = false;
     if (!fused_try && !(r_row >= (lean_ok ? eng.r_row_bound : eng.r_row_bound_full))) row_off = 1;
     // the column pass needs exponent offsets before it sees the data: from the previous E-step's column minima, or - first
     // E-step, no minima yet - none at all when the farthest target / source pair is still above the flush threshold

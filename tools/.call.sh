@@ -1,3 +1,8 @@
-for rep in 1 2 3; do for v in 0 1; do PRG_SPLAT_P4=$v python bench.py --workload filterreg_500k --steps 20 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('filterreg splat per point $v: %.1f it/s %.4f ms' % (d['value'], d['ms_per_step']))"; done; done
-bash tools/gpu_session.sh pytest tests/test_filterreg_gpu.py tests/test_filterreg_claim_gpu.py tests/test_feature_lattice_gpu.py tests/test_fullsize_gpu.py::test_filterreg_c4_500k_vs_oracle tests/test_resid_gpu.py tests/test_edge_gpu.py
-python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-workloads 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C1: %.1f it/s late %.0f' % (d['value'], d['late_it_s']))"
+mkdir -p gpurun_out/r6_ab
+for cfg in aniso:100000:1:0 clusters:100000:1:0 volume:100000:1:0 surface:100000:1:0; do
+  IFS=: read shape n world rank <<< "$cfg"
+  its=24; [ $shape = volume ] && its=60; [ $shape = aniso ] && its=48
+  python tools/single_sweep_ab.py $n $its $shape $world $rank 2>&1 | grep -v "amdgpu.ids" > gpurun_out/r6_ab/single_sweep_ab_${shape}_${n}_w${world}r${rank}.log
+  tail -1 gpurun_out/r6_ab/single_sweep_ab_${shape}_${n}_w${world}r${rank}.log | sed "s/^/$cfg /"
+done
+bash tools/gpu_session.sh pytest tests/test_fused_gpu.py tests/test_resid_gpu.py tests/test_mfma_gpu.py tests/test_lean_gpu.py tests/test_cpd_gpu.py
