@@ -34,6 +34,11 @@
 // checks the widest bracket and falls back to the VALU sweeps beyond); k_colfinal reproduces the offset bit for bit.
 #include <math.h>
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "cpd_sweeps.h"
 
 namespace {
@@ -824,20 +829,58 @@ namespace prg {
 // all of them take the same time in the dense regime, so the grid runs in ceil(blocks * S / 768) rounds: S is chosen in
 // [4, 32] to waste the least of the last round (C1: 196 blocks x 19 segments = 4.85 rounds; the first version's 196 x 5 =
 // 1.28 rounds lost 36 %); a segment holds at most 64 chunks (one ballot of box tests).
+// [r6] How long a dense launch of `blocks` x ceil(chunks / cps) workgroups lasts, in chunk units: the chip takes workgroups in grid
+// order (block index fastest, so every block's LAST segment - the short one when cps does not divide the chunks - goes out last)
+// as its 768 slots come free.  Simulated, because the remainder matters: a 1/8 shard of C1 (25 blocks, 391 chunks) cut into 28
+// segments of 14 runs 14 units; cut into 30 of 13 + one of 1 it runs 13 - the 25 short workgroups slip into the 18 free slots
+// and behind each other - where round 4's "rounds x chunks per workgroup" priced it at 26.  `over`: a workgroup's own cost (loading and
+// splitting its 512 points, writing its partial plane) in chunk units.
+static double mfma_dense_makespan(int64_t blocks, int64_t chunks, int64_t cps, double over) {
+    const int64_t segs = ceil_div(chunks, cps), rem = chunks - (segs - 1) * cps;
+    std::vector<double> slot(768, 0.0);  // min-heap of the times at which the chip's workgroup slots come free
+    auto later = [](double a, double b) { return a > b; };
+    double end = 0.0;
+    for (int64_t y = 0; y < segs; ++y) {
+        const double d = (double)(y + 1 < segs ? cps : rem) + over;
+        for (int64_t x = 0; x < blocks; ++x) {
+            std::pop_heap(slot.begin(), slot.end(), later);
+            const double t = slot.back() + d;
+            slot.back() = t;
+            std::push_heap(slot.begin(), slot.end(), later);
+            end = std::max(end, t);
+        }
+    }
+    return end;
+}
+
 int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S) {
     const int64_t chunks = ceil_div(streamed_points, kChunk);
     if (S <= 0) {
-        const int64_t blocks = ceil_div(owned_points, kWgPoints), slots = 768;
-        double best = 1e30;
-        S = 1;
-        for (int64_t cand = 4; cand <= 32; ++cand) {
-            const int64_t cps = ceil_div(chunks, std::min<int64_t>(cand, chunks));
-            const int64_t segs = ceil_div(chunks, cps);
-            const double cost = (double)ceil_div(blocks * segs, slots) * (double)cps;  // rounds x chunks per workgroup
-            if (cost < best * 0.999) {
-                best = cost;
-                S = (int)cand;
+        const int64_t blocks = ceil_div(owned_points, kWgPoints);
+        // (asked several times per E-step with the plan's two or three shapes: remembered)
+        static std::mutex mu;
+        static std::map<std::pair<int64_t, int64_t>, int> memo;
+        static const bool old_model = getenv("PRG_MFMA_SEG_MODEL") && atoi(getenv("PRG_MFMA_SEG_MODEL")) == 4;  // round 4's count of rounds
+        std::lock_guard<std::mutex> lock(mu);
+        const auto key = std::make_pair(blocks, chunks);
+        const auto hit = memo.find(key);
+        if (hit != memo.end()) {
+            S = hit->second;
+        } else {
+            double best = 1e30;
+            S = 1;
+            for (int64_t cand = 4; cand <= 32; ++cand) {
+                const int64_t cps = ceil_div(chunks, std::min<int64_t>(cand, chunks));
+                if (cps > 64) continue;  // (one ballot of box tests covers 64 chunks)
+                const int64_t segs = ceil_div(chunks, cps);
+                const double cost = old_model ? (double)ceil_div(blocks * segs, (int64_t)768) * (double)cps
+                                              : mfma_dense_makespan(blocks, chunks, cps, 0.15);
+                if (cost < best * 0.999) {
+                    best = cost;
+                    S = (int)cand;
+                }
             }
+            memo[key] = S;
         }
     }
     const int64_t cps = ceil_div(chunks, std::min<int64_t>(S, chunks));
