@@ -83,8 +83,9 @@ def cpu_baseline_and_parity(n_full, kind="rigid"):
     from oracle import cpd_c, cpd_numpy as co
     from probreg_amd import cpd, synthetic
 
-    # [r6] 20k / 40k / 60k after one untimed call (the OpenMP pool's start-up sat in the 10k point of round 5's fit: +71 %)
-    sizes, iters = (20000, 40000, 60000), 2
+    # [r6] 30k / 45k / 60k after one untimed call (the OpenMP pool's start-up sat in the 10k point of round 5's fit: +71 %; a 20k
+    # point - 0.4 s of work on 128 threads - still read +12 ... +32 % from box to box)
+    sizes, iters = (30000, 45000, 60000), 2
     per_iter, last = [], None
     w_src, w_tgt, _ = synthetic.rigid_pair(4000, seed=0)
     cpd_c.expectation_step(w_src, w_tgt, co.squared_kernel_sum_closed_form(w_src, w_tgt), 0.0)
