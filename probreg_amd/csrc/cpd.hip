@@ -1752,8 +1752,10 @@ static int mfma_fine_segments(int64_t owned, int64_t streamed, int max_planes) {
 // culling sweep only makes the matrix cores faster near the crossover - leaving at this bound is then slightly early, never late)
 static double engine_leave_below(int64_t owned, int64_t streamed, double tau, double delta, double c_v) {
     static const int seg = getenv("PRG_MFMA_SEG") ? atoi(getenv("PRG_MFMA_SEG")) : 0;
-    const double cps = (double)prg::mfma_chunks_per_seg(owned, streamed, seg);
-    const double wgs = (double)prg::ceil_div(owned, prg::kMfmaWgPoints) * (double)prg::mfma_planes(owned, streamed, seg);
+    // (segments as round 4 cut them: the rule the constants were fitted with, see mfma_chunks_per_seg_model)
+    const int cps_i = seg ? prg::mfma_chunks_per_seg(owned, streamed, seg) : prg::mfma_chunks_per_seg_model(owned, streamed);
+    const double cps = (double)cps_i;
+    const double wgs = (double)prg::ceil_div(owned, prg::kMfmaWgPoints) * (double)prg::ceil_div(prg::ceil_div(streamed, 256), cps_i);
     const double late = std::max(0.0, 1.0 - 768.0 / wgs) * tau / (768.0 * 512.0 * 256.0);
     return std::max(0.0, cps * tau + delta) / (c_v - late) / (double)owned;  // pairs per owned point
 }

@@ -52,6 +52,7 @@ void launch_fused_mfma(prg_cpd* h, int S, bool first, bool fine, const EngineDec
 void launch_rowpass_mfma(prg_cpd* h, int S, bool fine, bool lean, bool stream);  // lean: without the residual sums (plane 4)
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S);  // partial planes those segments occupy
 int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S);  // 256-point chunks one workgroup walks
+int mfma_chunks_per_seg_model(int64_t owned_points, int64_t streamed_points);  // ... under round 4's rule (the engine switch's cost model)
 
 // ---- the single sweep of a rigid iteration on the vector pipe, found and run by the column block's owner (cpd_sweeps_owner.hip) ----
 constexpr int kOwnerWaves = 8;       // waves of the workgroup that owns 128 columns

@@ -887,6 +887,25 @@ int mfma_chunks_per_seg(int64_t owned_points, int64_t streamed_points, int S) {
     return (int)std::min<int64_t>(cps, 64);
 }
 
+// Round 4's segment rule (whole rounds of the chip x chunks per workgroup): what the engine switch's cost model was fitted with
+// (cpd.hip: engine_leave_below) - its constants describe launches cut this way, and its bounds are held to measured crossovers
+// (tests/test_host_logic.py), so the model keeps this rule while the launches themselves follow the simulated schedule above.
+int mfma_chunks_per_seg_model(int64_t owned_points, int64_t streamed_points) {
+    const int64_t chunks = ceil_div(streamed_points, kChunk), blocks = ceil_div(owned_points, kWgPoints);
+    double best = 1e30;
+    int64_t best_cps = chunks;
+    for (int64_t cand = 4; cand <= 32; ++cand) {
+        const int64_t cps = ceil_div(chunks, std::min<int64_t>(cand, chunks));
+        const int64_t segs = ceil_div(chunks, cps);
+        const double cost = (double)ceil_div(blocks * segs, (int64_t)768) * (double)cps;
+        if (cost < best * 0.999) {
+            best = cost;
+            best_cps = cps;
+        }
+    }
+    return (int)std::min<int64_t>(best_cps, 64);
+}
+
 int mfma_planes(int64_t owned_points, int64_t streamed_points, int S) {
     const int cps = mfma_chunks_per_seg(owned_points, streamed_points, S);
     return (int)ceil_div(ceil_div(streamed_points, kChunk), cps);
